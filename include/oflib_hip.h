@@ -1,0 +1,157 @@
+/*
+ * oflib_hip.h -- C ABI of libofl_hip.so: the MI355X (gfx950) kernels behind the dense
+ * flow warp / compose hot path of oflibpytorch.
+ *
+ * The reference (oflibpytorch v2.1.1) is pure Python and has no FFI layer of its own; the
+ * arithmetic of this path lives in two ATen call sites.  The entry points below are what a
+ * binding for exactly that path replaces:
+ *
+ *   ofl_warp_bwd_f32        <- F.grid_sample(target, normalise_coords(grid - flow))
+ *                              src/oflibpytorch/utils.py:541-555 (+ normalise_coords :445-466),
+ *                              with the mask channel / threshold / AND of Flow.apply
+ *                              (flow_class.py:896-898, 921-934) and the vector add of
+ *                              combine_with mode 3 (flow_class.py:1804, 1808; __add__ :450-488)
+ *                              fused in.
+ *   ofl_splat_fwd_f32 +     <- density.scatter_add_ / grid_data.scatter_add_ and the normalise
+ *   ofl_splat_finalize_f32     pass of grid_from_unstructured_data (utils.py:1061-1154), with
+ *                              get_flow_endpoints (:1045-1058), the zero-flow occlusion rule and
+ *                              un-occlude fill of apply_s_flow (:1157-1205) and Flow.apply's mask
+ *                              channel (flow_class.py:880-898, 921-923) fused in.
+ *   ofl_flow_flags_f32      <- get_valid_vecs' isfinite().all() (utils.py:98), threshold_vectors
+ *                              (:623-643), is_zero_flow (:919-938), Flow.is_zero
+ *                              (flow_class.py:1226-1244): the data-dependent early-exit tests.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP); nothing is allocated or freed inside;
+ *   - images are planar N-C-H-W, rows contiguous (stride_w = 1, stride_h = W, channel stride
+ *     = H*W); the batch stride of every input is explicit, in ELEMENTS, and may be 0 to
+ *     broadcast one batch element (the reference's 1<->N `expand`, utils.py:527-537);
+ *   - masks are 1 byte per pixel, 0 = False, anything else = True (torch.bool storage);
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - return value: 0 on success, OFL_E_* (< 0) for rejected arguments, or a positive
+ *     hipError_t from the launch.
+ *   - all arithmetic is IEEE fp32 in the reference's operation order (no fast-math, no
+ *     implicit contraction); masks are bit-exact with the reference's PyTorch-CPU path.
+ */
+#ifndef OFLIB_HIP_H
+#define OFLIB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFL_OK 0
+#define OFL_E_NULL -1      /* a required pointer is NULL */
+#define OFL_E_SHAPE -2     /* n, c, h or w out of range (all must be >= 1; h*w < 2^24, utils.py:1118) */
+#define OFL_E_ARG -3       /* inconsistent optional arguments */
+
+/* library / build identification: returns e.g. 10 for 0.1.0 */
+int ofl_version(void);
+
+/* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,
+ * Flow.apply flow_class.py:943-946): 0 none, 1 round-half-even, 2 round then clamp to [0,255] */
+#define OFL_ROUND_NONE 0
+#define OFL_ROUND_RINT 1
+#define OFL_ROUND_U8 2
+
+/*
+ * Backward ("t"-reference) bilinear warp, zero padding, align_corners=True.
+ *
+ *   p        = (gx, gy) - flow_sign * flow[n]                       (fp32)
+ *   G[n,c]   = bilinear(src[n,c], p)                                 (taps outside the image = 0)
+ *   dst[n,c] = addend ? a_sign * addend[n,c] + g_sign * G[n,c] : G[n,c]      (then `round_mode`)
+ *   valid[n] = (bilinear(src_mask ? src_mask[n] : 1, p) > 0.99999f) & (flow_mask ? flow_mask[n] : 1)
+ *
+ * flow      [*,2,H,W] fp32, flow_sign = +1 or -1 (exact negation; Flow.invert('t') of an 's' flow)
+ * src       [*,C,H,W] fp32
+ * src_mask  [*,H,W] u8 or NULL (all True)      -- the mask warped as an extra channel
+ * flow_mask [*,H,W] u8 or NULL (all True)      -- ANDed after the warp
+ * addend    [*,C,H,W] fp32 or NULL; may alias `flow` (mode-3 composition, C = 2)
+ * dst       [N,C,H,W] fp32, contiguous         -- must not alias an input
+ * valid     [N,H,W] u8 or NULL (not wanted)
+ * flow_flags / src_flags: optional int32[N] / int32[N] (or NULL): flag words (see
+ *           ofl_flow_flags_f32) of the `flow` operand (with flow_mask) and, when C == 2 and
+ *           src is itself a flow field, of `src` (with src_mask), OR-ed in as a by-product of the
+ *           same pass.  The caller zeroes them beforehand.
+ */
+int ofl_warp_bwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                     const float* src, int64_t src_bs,
+                     const uint8_t* src_mask, int64_t src_mask_bs,
+                     const uint8_t* flow_mask, int64_t flow_mask_bs,
+                     const float* addend, int64_t addend_bs, float a_sign, float g_sign,
+                     float* dst, uint8_t* valid,
+                     int32_t* flow_flags, int32_t* src_flags,
+                     int32_t n, int32_t c, int32_t h, int32_t w,
+                     int32_t round_mode, void* stream);
+
+/*
+ * Forward ("s"-reference) splat, pass 1: scatter-add of weight * value into `accum`.
+ *
+ *   (x, y)  = xy ? (xy_x[n], xy_y[n]) : (gx, gy) + flow_sign * flow[n]
+ *   zero    = occlude && |flow_u| < 1e-3f && |flow_v| < 1e-3f         (strict, per component)
+ *   wmask   = (weight_mask ? weight_mask[n] : 1) && !zero
+ *   accum[n,0]       += w_corner * wmask                              (density)
+ *   accum[n,1+c]     += w_corner * wmask * data_sign * data[n,c]
+ *   accum[n,1+C]     += w_corner * wmask * (chan_mask_a & chan_mask_b)   (only if with_mask_chan)
+ *
+ * accum [N, 1 + C + with_mask_chan, H, W] fp32 workspace, zeroed by the caller.
+ * Either `flow` (endpoints computed in-kernel, get_flow_endpoints) or `xs`/`ys` (explicit
+ * positions, grid_from_unstructured_data) must be given; occlude requires `flow`.
+ */
+int ofl_splat_fwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                      const float* xs, const float* ys, int64_t xy_bs,
+                      const float* data, int64_t data_bs, float data_sign,
+                      const uint8_t* weight_mask, int64_t weight_mask_bs,
+                      const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
+                      const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+                      int32_t with_mask_chan, int32_t occlude,
+                      float* accum,
+                      int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
+/*
+ * Forward splat, pass 2: normalise, masks, un-occlude fill.
+ *
+ *   den        = accum[n,0];  dcl = max(den, 1e-3f)
+ *   dst[n,c]   = accum[n,1+c] / dcl ;  mch = accum[n,1+C] / dcl
+ *   where (weight_mask & zero & den == 0) [occlude only]:  dst[n,c] = data_sign*data[n,c], mch = chan masks
+ *   density[n] = den                      (optional)
+ *   warped[n]  = den > 0                  (optional; apply_s_flow's returned mask)
+ *   valid[n]   = mch > 0.99999f           (optional; requires with_mask_chan)
+ *   then `round_mode` on dst.
+ */
+int ofl_splat_finalize_f32(const float* accum,
+                           const float* flow, int64_t flow_bs,
+                           const float* data, int64_t data_bs, float data_sign,
+                           const uint8_t* weight_mask, int64_t weight_mask_bs,
+                           const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
+                           const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+                           int32_t with_mask_chan, int32_t occlude,
+                           float* dst, float* density, uint8_t* warped, uint8_t* valid,
+                           int32_t n, int32_t c, int32_t h, int32_t w,
+                           int32_t round_mode, void* stream);
+
+/*
+ * Per-batch-element flag word of a flow field (OR-ed into flags[n]; caller zeroes):
+ *   bit 0 (1)  some component is NaN / +-Inf
+ *   bit 1 (2)  some component != 0
+ *   bit 2 (4)  some component outside (-thr, thr)
+ *   bit 3 (8)  some component != 0 where mask is True
+ *   bit 4 (16) some component outside (-thr, thr) where mask is True
+ * mask [*,H,W] u8 or NULL (all True).
+ */
+#define OFL_FLAG_NONFINITE 1
+#define OFL_FLAG_NZ 2
+#define OFL_FLAG_NZ_THR 4
+#define OFL_FLAG_NZ_MASKED 8
+#define OFL_FLAG_NZ_THR_MASKED 16
+
+int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
+                       const uint8_t* mask, int64_t mask_bs, float thr,
+                       int32_t* flags, int32_t n, int32_t h, int32_t w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFLIB_HIP_H */

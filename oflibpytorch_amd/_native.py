@@ -1,0 +1,181 @@
+"""ctypes binding of libofl_hip.so (C ABI: include/oflib_hip.h) and the tensor-level primitives the
+host-side mirror of the reference API is written against.
+
+This is the ONLY compute backend of the package.  There is no CPU fallback: if the HIP library
+cannot be loaded, or no HIP device is visible, every primitive raises ``NativeUnavailable``.
+Tensors that live on the CPU are staged to the current HIP device for the launch (the reference
+accepts CPU tensors; the arithmetic still runs in the HIP kernels) and results are returned on the
+HIP device -- callers move them where the reference would have put them.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _build
+
+FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
+ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
+THRESHOLD = 1e-3
+
+_SYMBOLS = ("ofl_version", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_flow_flags_f32")
+_lib = None
+
+
+class NativeUnavailable(RuntimeError):
+    """The HIP backend (libofl_hip.so + a visible HIP device) is required and missing."""
+
+
+def load_library(path: str = None):
+    """dlopen libofl_hip.so and declare the C ABI.  Never touches the GPU (usable in CPU-only checks)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.LIB_PATH
+    if not os.path.exists(path):
+        try:
+            _build.build()
+        except Exception as exc:  # noqa: BLE001
+            raise NativeUnavailable("oflibpytorch_amd: %s is missing and could not be built: %s" % (path, exc))
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:
+        raise NativeUnavailable("oflibpytorch_amd: cannot load %s: %s" % (path, exc))
+    p, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    lib.ofl_version.argtypes = []
+    lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p,
+                                     i32, i32, i32, i32, i32, p]
+    lib.ofl_splat_fwd_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p,
+                                      i32, i32, i32, i32, p]
+    lib.ofl_splat_finalize_f32.argtypes = [p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p,
+                                           i32, i32, i32, i32, i32, p]
+    lib.ofl_flow_flags_f32.argtypes = [p, i64, p, i64, f32, p, i32, i32, i32, p]
+    for name in _SYMBOLS:
+        getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return _SYMBOLS
+
+
+def device() -> torch.device:
+    """The HIP device the kernels run on (torch's current device)."""
+    if not torch.cuda.is_available():
+        raise NativeUnavailable("oflibpytorch_amd: no HIP device visible -- this package has no CPU fallback "
+                                "(its compute path is libofl_hip.so on MI355X)")
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError("oflibpytorch_amd: %s failed with status %d" % (what, rc))
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _planes(t: torch.Tensor, dev, dtype, n: int, what: str):
+    """Stage tensor [Nb, (C,) H, W] for a kernel: on `dev`, `dtype`, planes contiguous; returns
+    (tensor to keep alive, batch stride in elements -- 0 broadcasts one batch element)."""
+    if t.device != dev:
+        t = t.to(dev)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    nb = t.shape[0]
+    if nb != n and nb != 1:
+        raise ValueError("oflibpytorch_amd: %s batch size %d cannot broadcast to %d" % (what, nb, n))
+    if nb > 1 and t.stride(0) == 0:
+        t, nb = t[:1], 1          # an `expand`ed batch (utils.py:533-537) is a broadcast, not N copies
+    if not t[0].is_contiguous():
+        t = t.contiguous()
+    return t, (0 if nb == 1 else t.stride(0))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------------
+def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
+    """Flag word per batch element (bits: FLAG_*), int32 tensor [N] on the HIP device (no host sync)."""
+    lib, dev = load_library(), device()
+    n, _, h, w = vecs.shape
+    v, vbs = _planes(vecs, dev, torch.float32, n, "flow")
+    m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+    flags = torch.zeros(n, dtype=torch.int32, device=dev)
+    _check(lib.ofl_flow_flags_f32(_ptr(v), vbs, _ptr(m), mbs, THRESHOLD, _ptr(flags), n, h, w, _stream(dev)),
+           "ofl_flow_flags_f32")
+    return flags
+
+
+def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
+             a_sign=1.0, g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False):
+    """G-family kernel (include/oflib_hip.h: ofl_warp_bwd_f32).
+
+    flow [Nf,2,H,W], src [Ns,C,H,W], masks [*,H,W] bool or None, addend [*,C,H,W] or None.
+    Returns (dst [N,C,H,W] fp32, valid [N,H,W] bool | None, flow_flags int32[N] | None, src_flags | None),
+    all on the HIP device, N = max batch.
+    """
+    lib, dev = load_library(), device()
+    c, h, w = src.shape[1:]
+    n = max(flow.shape[0], src.shape[0], 1 if src_mask is None else src_mask.shape[0],
+            1 if flow_mask is None else flow_mask.shape[0], 1 if addend is None else addend.shape[0])
+    f, fbs = _planes(flow, dev, torch.float32, n, "flow")
+    s, sbs = _planes(src, dev, torch.float32, n, "source")
+    sm, smbs = (None, 0) if src_mask is None else _planes(src_mask, dev, torch.bool, n, "source mask")
+    fm, fmbs = (None, 0) if flow_mask is None else _planes(flow_mask, dev, torch.bool, n, "flow mask")
+    ad, adbs = (None, 0) if addend is None else _planes(addend, dev, torch.float32, n, "addend")
+    dst = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+    valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
+    ff = torch.zeros(n, dtype=torch.int32, device=dev) if want_flags else None
+    sf = torch.zeros(n, dtype=torch.int32, device=dev) if (want_flags and want_src_flags) else None
+    _check(lib.ofl_warp_bwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(s), sbs, _ptr(sm), smbs, _ptr(fm), fmbs,
+                                _ptr(ad), adbs, float(a_sign), float(g_sign), _ptr(dst), _ptr(valid), _ptr(ff),
+                                _ptr(sf), n, c, h, w, int(round_mode), _stream(dev)), "ofl_warp_bwd_f32")
+    return dst, valid, ff, sf
+
+
+def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
+              chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False,
+              round_mode=ROUND_NONE):
+    """P-family kernels (ofl_splat_fwd_f32 + ofl_splat_finalize_f32).
+
+    Either flow [Nf,2,H,W] (endpoints computed in-kernel) or explicit positions xs, ys [N,H,W].
+    Returns (dst [N,C,H,W], valid | None, density | None, warped | None) on the HIP device.
+    """
+    lib, dev = load_library(), device()
+    c, h, w = data.shape[1:]
+    n = max(data.shape[0], 1 if flow is None else flow.shape[0], 1 if xs is None else xs.shape[0],
+            1 if weight_mask is None else weight_mask.shape[0], 1 if chan_mask_a is None else chan_mask_a.shape[0],
+            1 if chan_mask_b is None else chan_mask_b.shape[0])
+    f, fbs = (None, 0) if flow is None else _planes(flow, dev, torch.float32, n, "flow")
+    x, xbs = (None, 0) if xs is None else _planes(xs, dev, torch.float32, n, "x")
+    y, ybs = (None, 0) if ys is None else _planes(ys, dev, torch.float32, n, "y")
+    if x is not None and xbs != ybs:
+        x, y = x.expand(n, h, w).contiguous(), y.expand(n, h, w).contiguous()
+        xbs = ybs = h * w
+    d, dbs = _planes(data, dev, torch.float32, n, "data")
+    wm, wmbs = (None, 0) if weight_mask is None else _planes(weight_mask, dev, torch.bool, n, "mask")
+    ca, cabs = (None, 0) if chan_mask_a is None else _planes(chan_mask_a, dev, torch.bool, n, "mask")
+    cb, cbbs = (None, 0) if chan_mask_b is None else _planes(chan_mask_b, dev, torch.bool, n, "mask")
+    mch = 1 if want_valid else 0
+    occ = 1 if (occlude and f is not None) else 0
+    accum = torch.zeros((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+    st = _stream(dev)
+    _check(lib.ofl_splat_fwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
+                                 float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
+                                 _ptr(accum), n, c, h, w, st), "ofl_splat_fwd_f32")
+    dst = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+    valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
+    density = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_density else None
+    warped = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_warped else None
+    _check(lib.ofl_splat_finalize_f32(_ptr(accum), _ptr(f), fbs, _ptr(d), dbs, float(data_sign), _ptr(wm), wmbs,
+                                      _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ, _ptr(dst), _ptr(density),
+                                      _ptr(warped), _ptr(valid), n, c, h, w, int(round_mode), st),
+           "ofl_splat_finalize_f32")
+    return dst, valid, density, warped

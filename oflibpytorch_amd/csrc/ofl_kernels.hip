@@ -1,0 +1,536 @@
+// ofl_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for the dense flow warp / compose hot path.
+//
+// Everything here is HBM-bound gather / scatter / elementwise work: there is no dense contraction,
+// so no MFMA.  What matters is (1) every input byte read ~once and every output byte written once,
+// (2) 64-lane wavefronts reading / writing 256 contiguous bytes per instruction, (3) a
+// workgroup -> tile order that keeps a tile's neighbours on the same XCD (each XCD has its own L2),
+// (4) fp32 arithmetic in exactly the reference's operation order (bit-exact masks).
+//
+// Compiled with -ffp-contract=off -fno-fast-math; the only fused multiply-adds are the explicit
+// __builtin_fmaf calls that restate the contraction in the reference's CPU grid-sampler.
+//
+// C ABI: include/oflib_hip.h (reference call sites cited there).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "oflib_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr float kValidThr = 0.99999f;  // flow_class.py:922
+constexpr float kZeroThr = 1e-3f;      // utils.py:23, :642
+constexpr float kDenMin = 1e-3f;       // utils.py:1144
+constexpr int kXcds = 8;
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float unnormalise(float p, float size_m1, float half_size_m1) {
+    // normalise_coords (utils.py:462-465) followed by the grid sampler's align_corners un-normalise
+    float g = p * 2.0f;
+    g = g / size_m1;  // IEEE correctly-rounded divide (no fast-math)
+    g = g - 1.0f;
+    return (g + 1.0f) * half_size_m1;
+}
+
+__device__ __forceinline__ float apply_round(float r, int mode) {
+    if (mode != OFL_ROUND_NONE) {
+        r = rintf(r);  // round-half-even == torch.round
+        if (mode == OFL_ROUND_U8) r = fminf(fmaxf(r, 0.0f), 255.0f);
+    }
+    return r;
+}
+
+__device__ __forceinline__ int flag_bits(float u, float v, bool valid) {
+    int f = 0;
+    const bool nf = !(isfinite(u) && isfinite(v));
+    const bool nz = !(u == 0.0f) || !(v == 0.0f);
+    const bool nzt = !((u < kZeroThr) && (u > -kZeroThr)) || !((v < kZeroThr) && (v > -kZeroThr));
+    if (nf) f |= OFL_FLAG_NONFINITE;
+    if (nz) f |= OFL_FLAG_NZ | (valid ? OFL_FLAG_NZ_MASKED : 0);
+    if (nzt) f |= OFL_FLAG_NZ_THR | (valid ? OFL_FLAG_NZ_THR_MASKED : 0);
+    return f;
+}
+
+// OR-reduce a per-lane flag word over the 64-lane wavefront (5 ballots, no LDS)
+__device__ __forceinline__ int wave_or_flags(int f) {
+    int r = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+        if (__ballot((f >> b) & 1) != 0ull) r |= (1 << b);
+    return r;
+}
+
+// XCD-aware block -> logical tile id: hardware deals blocks round-robin over the 8 XCDs, so block b
+// and b+8 share an L2.  Give every XCD one contiguous range of logical tiles (speed only).
+__device__ __forceinline__ int64_t logical_block(int64_t per_xcd) {
+    const int64_t b = blockIdx.x;
+    return (b % kXcds) * per_xcd + b / kXcds;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward warp  (ofl_warp_bwd_f32)
+// ------------------------------------------------------------------------------------------------
+struct WarpParams {
+    const float* flow; int64_t flow_bs;
+    const float* src; int64_t src_bs;
+    const uint8_t* src_mask; int64_t src_mask_bs;
+    const uint8_t* flow_mask; int64_t flow_mask_bs;
+    const float* addend; int64_t addend_bs;
+    float* dst; uint8_t* valid;
+    int32_t* flow_flags; int32_t* src_flags;
+    int32_t n, c, h, w;
+    float flow_sign, a_sign, g_sign;
+    int32_t round_mode;
+    float wm1, hm1, half_wm1, half_hm1;
+    int32_t tiles_x, tiles_y;
+    int64_t total_tiles, per_xcd;
+};
+
+constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
+constexpr int kRows = 4;     // rows per thread (independent pixels in flight per lane)
+constexpr int kTileH = 4 * kRows;  // 4 wavefronts per 256-thread block
+
+// CT = compile-time channel count (0: run-time p.c)
+template <int CT, bool VALID, bool ADD, bool FLAGS>
+__global__ __launch_bounds__(256) void warp_bwd_kernel(const WarpParams p) {
+    const int64_t tile = logical_block(p.per_xcd);
+    if (tile >= p.total_tiles) return;
+    const int tx = (int)(tile % p.tiles_x);
+    const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
+    const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = tx * kTileW + lane;
+    const int w = p.w, h = p.h;
+    const int64_t hw = (int64_t)h * w;
+    const int C = CT ? CT : p.c;
+
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const float* __restrict__ fv = fu + hw;
+    const float* __restrict__ sb = p.src + n * p.src_bs;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
+    const float* __restrict__ ab = ADD ? p.addend + n * p.addend_bs : nullptr;
+    float* __restrict__ db = p.dst + (int64_t)n * C * hw;
+
+    int fflags = 0, sflags = 0;
+
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int y = ty * kTileH + wave * kRows + r;
+        if (x >= w || y >= h) continue;
+        const int64_t pix = (int64_t)y * w + x;
+        const float u = fu[pix], v = fv[pix];
+        bool fmv = true;
+        if (VALID || FLAGS) fmv = fm ? (fm[pix] != 0) : true;
+        if (FLAGS) {
+            fflags |= flag_bits(u, v, fmv);
+            if (p.src_flags) {
+                const bool smv = sm ? (sm[pix] != 0) : true;
+                sflags |= flag_bits(sb[pix], sb[hw + pix], smv);
+            }
+        }
+        // sample position: grid - flow (utils.py:549), flow_sign = -1 restates Flow(-vecs)
+        const float px = (float)x - p.flow_sign * u;
+        const float py = (float)y - p.flow_sign * v;
+        const float sx = unnormalise(px, p.wm1, p.half_wm1);
+        const float sy = unnormalise(py, p.hm1, p.half_hm1);
+        const float x_w = floorf(sx), y_n = floorf(sy);
+        const float ww = sx - x_w, e = 1.0f - ww;
+        const float nn = sy - y_n, s = 1.0f - nn;
+        const float nw = s * e, ne = s * ww, sw = nn * e, se = nn * ww;
+        const float x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+        const bool x0ok = (x_w > -1.0f) && (x_w < (float)w);
+        const bool x1ok = (x_e > -1.0f) && (x_e < (float)w);
+        const bool y0ok = (y_n > -1.0f) && (y_n < (float)h);
+        const bool y1ok = (y_s > -1.0f) && (y_s < (float)h);
+        // clamped integer taps (always addressable); out-of-range taps are zeroed by the selects
+        const int ix0 = x0ok ? (int)x_w : 0, ix1 = x1ok ? (int)x_e : 0;
+        const int iy0 = y0ok ? (int)y_n : 0, iy1 = y1ok ? (int)y_s : 0;
+        const int64_t o_nw = (int64_t)iy0 * w + ix0, o_ne = (int64_t)iy0 * w + ix1;
+        const int64_t o_sw = (int64_t)iy1 * w + ix0, o_se = (int64_t)iy1 * w + ix1;
+        const bool k_nw = x0ok && y0ok, k_ne = x1ok && y0ok, k_sw = x0ok && y1ok, k_se = x1ok && y1ok;
+
+        if (VALID) {
+            float m_nw, m_ne, m_sw, m_se;
+            if (sm) {
+                m_nw = k_nw ? (float)(sm[o_nw] != 0) : 0.0f;
+                m_ne = k_ne ? (float)(sm[o_ne] != 0) : 0.0f;
+                m_sw = k_sw ? (float)(sm[o_sw] != 0) : 0.0f;
+                m_se = k_se ? (float)(sm[o_se] != 0) : 0.0f;
+            } else {
+                m_nw = k_nw ? 1.0f : 0.0f; m_ne = k_ne ? 1.0f : 0.0f;
+                m_sw = k_sw ? 1.0f : 0.0f; m_se = k_se ? 1.0f : 0.0f;
+            }
+            float mr = m_nw * nw;
+            mr = __builtin_fmaf(m_ne, ne, mr);
+            mr = __builtin_fmaf(m_sw, sw, mr);
+            mr = __builtin_fmaf(m_se, se, mr);
+            p.valid[(int64_t)n * hw + pix] = (uint8_t)((mr > kValidThr) && fmv);
+        }
+
+#pragma unroll
+        for (int ch = 0; ch < (CT ? CT : 1); ++ch) {
+            for (int cc = ch; cc < C; cc += (CT ? C : 1)) {
+                const float* __restrict__ sp = sb + (int64_t)cc * hw;
+                const float v_nw = k_nw ? sp[o_nw] : 0.0f;
+                const float v_ne = k_ne ? sp[o_ne] : 0.0f;
+                const float v_sw = k_sw ? sp[o_sw] : 0.0f;
+                const float v_se = k_se ? sp[o_se] : 0.0f;
+                float rr = v_nw * nw;
+                rr = __builtin_fmaf(v_ne, ne, rr);
+                rr = __builtin_fmaf(v_sw, sw, rr);
+                rr = __builtin_fmaf(v_se, se, rr);
+                if (ADD) rr = p.a_sign * ab[(int64_t)cc * hw + pix] + p.g_sign * rr;
+                db[(int64_t)cc * hw + pix] = apply_round(rr, p.round_mode);
+            }
+        }
+    }
+
+    if (FLAGS) {
+        fflags = wave_or_flags(fflags);
+        if (lane == 0 && fflags) atomicOr(&p.flow_flags[n], fflags);
+        if (p.src_flags) {
+            sflags = wave_or_flags(sflags);
+            if (lane == 0 && sflags) atomicOr(&p.src_flags[n], sflags);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward splat, pass 1 (ofl_splat_fwd_f32): global fp32 atomics into a zeroed accumulator
+// ------------------------------------------------------------------------------------------------
+struct SplatParams {
+    const float* flow; int64_t flow_bs; float flow_sign;
+    const float* xs; const float* ys; int64_t xy_bs;
+    const float* data; int64_t data_bs; float data_sign;
+    const uint8_t* weight_mask; int64_t weight_mask_bs;
+    const uint8_t* chan_mask_a; int64_t chan_mask_a_bs;
+    const uint8_t* chan_mask_b; int64_t chan_mask_b_bs;
+    int32_t with_mask_chan, occlude;
+    float* accum;          // pass 1 out / pass 2 in
+    float* dst; float* density; uint8_t* warped; uint8_t* valid;   // pass 2 out
+    int32_t n, c, h, w;
+    int32_t round_mode;
+    int32_t tiles_x, tiles_y;
+    int64_t total_tiles, per_xcd;
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
+    const int64_t tile = logical_block(p.per_xcd);
+    if (tile >= p.total_tiles) return;
+    const int tx = (int)(tile % p.tiles_x);
+    const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
+    const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = tx * kTileW + lane;
+    const int w = p.w, h = p.h;
+    const int64_t hw = (int64_t)h * w;
+    const int C = CT ? CT : p.c;
+    const int planes = 1 + C + (p.with_mask_chan ? 1 : 0);
+    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+
+    const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
+    const float* __restrict__ db = p.data + n * p.data_bs;
+    const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
+    const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
+    const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
+    float* __restrict__ acc = p.accum + (int64_t)n * planes * hw;
+
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int y = ty * kTileH + wave * kRows + r;
+        if (x >= w || y >= h) continue;
+        const int64_t pix = (int64_t)y * w + x;
+        float xv, yv;
+        bool zero = false;
+        if (fu) {
+            const float u = fu[pix], v = fu[hw + pix];
+            xv = p.flow_sign * u + (float)x;  // get_flow_endpoints utils.py:1056-1057
+            yv = p.flow_sign * v + (float)y;
+            if (p.occlude) zero = (u < kZeroThr) && (u > -kZeroThr) && (v < kZeroThr) && (v > -kZeroThr);
+        } else {
+            xv = p.xs[n * p.xy_bs + pix];
+            yv = p.ys[n * p.xy_bs + pix];
+        }
+        const bool wm = wmk ? (wmk[pix] != 0) : true;
+        if (!wm || zero) continue;  // weight * 0: contributes exactly nothing (utils.py:1123)
+
+        const float x0 = floorf(xv), y0 = floorf(yv);
+        const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+        const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
+        const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
+        float wx[2], wy[2];
+        wx[0] = (x1 - xv) * (x0 == x0s ? 1.0f : 0.0f);  // utils.py:1110
+        wx[1] = (xv - x0) * (x1 == x1s ? 1.0f : 0.0f);
+        wy[0] = (y1 - yv) * (y0 == y0s ? 1.0f : 0.0f);  // utils.py:1111
+        wy[1] = (yv - y0) * (y1 == y1s ? 1.0f : 0.0f);
+        const int ixs[2] = {(int)x0s, (int)x1s};
+        const int iys[2] = {(int)y0s, (int)y1s};
+
+        float mval = 0.0f;
+        if (p.with_mask_chan) mval = ((cma ? cma[pix] != 0 : true) && (cmb ? cmb[pix] != 0 : true)) ? 1.0f : 0.0f;
+
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) {
+                const float wgt = wy[ky] * wx[kx];  // utils.py:1114
+                if (wgt == 0.0f) continue;          // adding +-0 never changes an accumulator that starts at +0
+                const int64_t pos = (int64_t)iys[ky] * w + ixs[kx];  // utils.py:1118 (exact for h*w < 2^24)
+                atomicAdd(&acc[pos], wgt);
+#pragma unroll
+                for (int ch = 0; ch < (CT ? CT : 1); ++ch)
+                    for (int cc = ch; cc < C; cc += (CT ? C : 1))
+                        atomicAdd(&acc[(int64_t)(1 + cc) * hw + pos], wgt * (p.data_sign * db[(int64_t)cc * hw + pix]));
+                if (p.with_mask_chan) atomicAdd(&acc[(int64_t)(1 + C) * hw + pos], wgt * mval);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward splat, pass 2 (ofl_splat_finalize_f32)
+// ------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p) {
+    const int64_t tile = logical_block(p.per_xcd);
+    if (tile >= p.total_tiles) return;
+    const int tx = (int)(tile % p.tiles_x);
+    const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
+    const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = tx * kTileW + lane;
+    const int w = p.w, h = p.h;
+    const int64_t hw = (int64_t)h * w;
+    const int C = CT ? CT : p.c;
+    const int planes = 1 + C + (p.with_mask_chan ? 1 : 0);
+
+    const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
+    const float* __restrict__ db = p.data + n * p.data_bs;
+    const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
+    const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
+    const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
+    const float* __restrict__ acc = p.accum + (int64_t)n * planes * hw;
+    float* __restrict__ dst = p.dst + (int64_t)n * C * hw;
+
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+        const int y = ty * kTileH + wave * kRows + r;
+        if (x >= w || y >= h) continue;
+        const int64_t pix = (int64_t)y * w + x;
+        const float den = acc[pix];
+        const float dcl = den < kDenMin ? kDenMin : den;  // clamp_min utils.py:1144
+        const bool warped = den > 0.0f;                    // utils.py:1197
+        bool fill = false;
+        if (p.occlude && fu && !warped) {                  // un-occlude utils.py:1198-1203
+            const float u = fu[pix], v = fu[hw + pix];
+            const bool zero = (u < kZeroThr) && (u > -kZeroThr) && (v < kZeroThr) && (v > -kZeroThr);
+            const bool wm = wmk ? (wmk[pix] != 0) : true;
+            fill = zero && wm;
+        }
+#pragma unroll
+        for (int ch = 0; ch < (CT ? CT : 1); ++ch)
+            for (int cc = ch; cc < C; cc += (CT ? C : 1)) {
+                float val = fill ? p.data_sign * db[(int64_t)cc * hw + pix] : acc[(int64_t)(1 + cc) * hw + pix] / dcl;
+                dst[(int64_t)cc * hw + pix] = apply_round(val, p.round_mode);
+            }
+        if (p.density) p.density[(int64_t)n * hw + pix] = den;
+        if (p.warped) p.warped[(int64_t)n * hw + pix] = (uint8_t)warped;
+        if (p.valid) {
+            float mch;
+            if (fill)
+                mch = ((cma ? cma[pix] != 0 : true) && (cmb ? cmb[pix] != 0 : true)) ? 1.0f : 0.0f;
+            else
+                mch = acc[(int64_t)(1 + C) * hw + pix] / dcl;
+            p.valid[(int64_t)n * hw + pix] = (uint8_t)(mch > kValidThr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow flags (ofl_flow_flags_f32)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict__ flow, int64_t flow_bs,
+                                                         const uint8_t* __restrict__ mask, int64_t mask_bs,
+                                                         int32_t* __restrict__ flags, int64_t hw) {
+    const int n = blockIdx.y;
+    const float* fu = flow + n * flow_bs;
+    const uint8_t* mk = mask ? mask + n * mask_bs : nullptr;
+    int f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x)
+        f |= flag_bits(fu[i], fu[hw + i], mk ? (mk[i] != 0) : true);
+    f = wave_or_flags(f);
+    if ((threadIdx.x & 63) == 0 && f) atomicOr(&flags[n], f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+inline int check_dims(int32_t n, int32_t c, int32_t h, int32_t w) {
+    if (n < 1 || c < 1 || h < 1 || w < 1) return OFL_E_SHAPE;
+    if ((int64_t)h * w >= (1ll << 24)) return OFL_E_SHAPE;  // fp32 position index limit, utils.py:1118
+    return OFL_OK;
+}
+
+inline void tile_grid(int32_t n, int32_t h, int32_t w, int32_t& tiles_x, int32_t& tiles_y, int64_t& total,
+                      int64_t& per_xcd, unsigned& grid) {
+    tiles_x = (w + kTileW - 1) / kTileW;
+    tiles_y = (h + kTileH - 1) / kTileH;
+    total = (int64_t)tiles_x * tiles_y * n;
+    per_xcd = (total + kXcds - 1) / kXcds;
+    grid = (unsigned)(per_xcd * kXcds);
+}
+
+template <int CT>
+int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
+    const bool valid = p.valid != nullptr, add = p.addend != nullptr, flags = p.flow_flags != nullptr;
+#define OFL_LAUNCH_W(V, A, F)                                                                  \
+    if (valid == V && add == A && flags == F) {                                                \
+        hipLaunchKernelGGL((warp_bwd_kernel<CT, V, A, F>), dim3(grid), dim3(256), 0, st, p);    \
+        return (int)hipGetLastError();                                                         \
+    }
+    OFL_LAUNCH_W(false, false, false) OFL_LAUNCH_W(true, false, false)
+    OFL_LAUNCH_W(false, true, false) OFL_LAUNCH_W(true, true, false)
+    OFL_LAUNCH_W(false, false, true) OFL_LAUNCH_W(true, false, true)
+    OFL_LAUNCH_W(false, true, true) OFL_LAUNCH_W(true, true, true)
+#undef OFL_LAUNCH_W
+    return OFL_E_ARG;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+__attribute__((visibility("default"))) int ofl_version(void) { return 10; }
+
+__attribute__((visibility("default"))) int ofl_warp_bwd_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
+    const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
+    const float* addend, int64_t addend_bs, float a_sign, float g_sign, float* dst, uint8_t* valid,
+    int32_t* flow_flags, int32_t* src_flags, int32_t n, int32_t c, int32_t h, int32_t w, int32_t round_mode,
+    void* stream) {
+    if (!flow || !src || !dst) return OFL_E_NULL;
+    int rc = check_dims(n, c, h, w);
+    if (rc) return rc;
+    if (src_flags && (c != 2 || !flow_flags)) return OFL_E_ARG;
+    if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
+    if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
+    WarpParams p;
+    p.flow = flow; p.flow_bs = flow_bs; p.src = src; p.src_bs = src_bs;
+    p.src_mask = src_mask; p.src_mask_bs = src_mask_bs; p.flow_mask = flow_mask; p.flow_mask_bs = flow_mask_bs;
+    p.addend = addend; p.addend_bs = addend_bs; p.dst = dst; p.valid = valid;
+    p.flow_flags = flow_flags; p.src_flags = src_flags;
+    p.n = n; p.c = c; p.h = h; p.w = w;
+    p.flow_sign = flow_sign; p.a_sign = a_sign; p.g_sign = g_sign; p.round_mode = round_mode;
+    p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
+    p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
+    unsigned grid;
+    tile_grid(n, h, w, p.tiles_x, p.tiles_y, p.total_tiles, p.per_xcd, grid);
+    hipStream_t st = (hipStream_t)stream;
+    switch (c) {
+        case 1: return launch_warp<1>(p, grid, st);
+        case 2: return launch_warp<2>(p, grid, st);
+        case 3: return launch_warp<3>(p, grid, st);
+        case 4: return launch_warp<4>(p, grid, st);
+        default: return launch_warp<0>(p, grid, st);
+    }
+}
+
+static int fill_splat(SplatParams& p, const float* flow, int64_t flow_bs, const float* data, int64_t data_bs,
+                      float data_sign, const uint8_t* weight_mask, int64_t weight_mask_bs,
+                      const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b,
+                      int64_t chan_mask_b_bs, int32_t with_mask_chan, int32_t occlude, int32_t n, int32_t c,
+                      int32_t h, int32_t w, unsigned& grid) {
+    int rc = check_dims(n, c, h, w);
+    if (rc) return rc;
+    if (occlude && !flow) return OFL_E_ARG;
+    if (!(data_sign == 1.0f || data_sign == -1.0f)) return OFL_E_ARG;
+    p.flow = flow; p.flow_bs = flow_bs; p.data = data; p.data_bs = data_bs; p.data_sign = data_sign;
+    p.weight_mask = weight_mask; p.weight_mask_bs = weight_mask_bs;
+    p.chan_mask_a = chan_mask_a; p.chan_mask_a_bs = chan_mask_a_bs;
+    p.chan_mask_b = chan_mask_b; p.chan_mask_b_bs = chan_mask_b_bs;
+    p.with_mask_chan = with_mask_chan; p.occlude = occlude;
+    p.n = n; p.c = c; p.h = h; p.w = w;
+    tile_grid(n, h, w, p.tiles_x, p.tiles_y, p.total_tiles, p.per_xcd, grid);
+    return OFL_OK;
+}
+
+__attribute__((visibility("default"))) int ofl_splat_fwd_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, const float* xs, const float* ys, int64_t xy_bs,
+    const float* data, int64_t data_bs, float data_sign, const uint8_t* weight_mask, int64_t weight_mask_bs,
+    const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+    int32_t with_mask_chan, int32_t occlude, float* accum, int32_t n, int32_t c, int32_t h, int32_t w,
+    void* stream) {
+    if (!data || !accum) return OFL_E_NULL;
+    if (!flow && !(xs && ys)) return OFL_E_NULL;
+    if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
+    SplatParams p = {};
+    unsigned grid;
+    int rc = fill_splat(p, flow, flow_bs, data, data_bs, data_sign, weight_mask, weight_mask_bs, chan_mask_a,
+                        chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, n, c, h, w, grid);
+    if (rc) return rc;
+    p.flow_sign = flow_sign; p.xs = xs; p.ys = ys; p.xy_bs = xy_bs; p.accum = accum;
+    hipStream_t st = (hipStream_t)stream;
+    switch (c) {
+        case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(splat_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(splat_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, p); break;
+    }
+    return (int)hipGetLastError();
+}
+
+__attribute__((visibility("default"))) int ofl_splat_finalize_f32(
+    const float* accum, const float* flow, int64_t flow_bs, const float* data, int64_t data_bs, float data_sign,
+    const uint8_t* weight_mask, int64_t weight_mask_bs, const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
+    const uint8_t* chan_mask_b, int64_t chan_mask_b_bs, int32_t with_mask_chan, int32_t occlude, float* dst,
+    float* density, uint8_t* warped, uint8_t* valid, int32_t n, int32_t c, int32_t h, int32_t w,
+    int32_t round_mode, void* stream) {
+    if (!accum || !data || !dst) return OFL_E_NULL;
+    if (valid && !with_mask_chan) return OFL_E_ARG;
+    if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
+    SplatParams p = {};
+    unsigned grid;
+    int rc = fill_splat(p, flow, flow_bs, data, data_bs, data_sign, weight_mask, weight_mask_bs, chan_mask_a,
+                        chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, n, c, h, w, grid);
+    if (rc) return rc;
+    p.accum = const_cast<float*>(accum);
+    p.dst = dst; p.density = density; p.warped = warped; p.valid = valid; p.round_mode = round_mode;
+    hipStream_t st = (hipStream_t)stream;
+    switch (c) {
+        case 1: hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(splat_finalize_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(splat_finalize_kernel<0>, dim3(grid), dim3(256), 0, st, p); break;
+    }
+    return (int)hipGetLastError();
+}
+
+__attribute__((visibility("default"))) int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
+                                                              const uint8_t* mask, int64_t mask_bs, float thr,
+                                                              int32_t* flags, int32_t n, int32_t h, int32_t w,
+                                                              void* stream) {
+    if (!flow || !flags) return OFL_E_NULL;
+    int rc = check_dims(n, 2, h, w);
+    if (rc) return rc;
+    if (thr != kZeroThr) return OFL_E_ARG;  // the reference's DEFAULT_THRESHOLD is the only value on the path
+    const int64_t hw = (int64_t)h * w;
+    int64_t bx = (hw + 255) / 256;
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(flow_flags_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, flow,
+                       flow_bs, mask, mask_bs, flags, hw);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,595 @@
+"""`Flow`: host-side mirror of the reference's flow object for the warp / compose hot path.
+
+Same constructor, properties, operators and method signatures as ``oflibpytorch.Flow`` (reference
+``src/oflibpytorch/flow_class.py``; cited per method).  The object is a thin container -- `vecs`
+N-2-H-W fp32, `mask` N-H-W bool, `ref` 's'/'t', `device` -- and every warp / splat / composition is
+one fused launch of the HIP kernels in ``libofl_hip.so`` (see :mod:`oflibpytorch_amd._native`).
+
+Differences from the reference that do not change results:
+  * validation is one fused reduction (finiteness + the four zero tests) per tensor version,
+    cached on the object, instead of a pass per predicate per call;
+  * an all-True default mask is kept implicit (`None`) until somebody asks for `.mask`;
+  * intermediates produced by the kernels are not re-validated eagerly.
+"""
+import warnings
+from typing import Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _native
+from .utils import (get_valid_vecs, get_valid_ref, get_valid_mask, get_valid_device, get_valid_padding,
+                    get_valid_shape, get_pure_pytorch, move_axis, from_matrix, from_transforms, resize_flow,
+                    apply_flow, _flags_to_host, _griddata_unavailable)
+
+FlowAlias = 'Flow'
+_VALID_THR = 0.99999   # flow_class.py:922
+
+
+class Flow(object):
+    # ------------------------------------------------------------------------------------------
+    # construction / properties (flow_class.py:37-236)
+    # ------------------------------------------------------------------------------------------
+    def __init__(self, flow_vectors, ref: str = None, mask=None, device=None):
+        self._flag_cache = None
+        self._pending_flags = None
+        self._mask = None
+        self._vecs = get_valid_vecs(flow_vectors, error_string="Error setting flow vectors: ", _check_finite=False)
+        self._device = self._vecs.device
+        try:
+            self.ref = ref
+            if mask is not None:
+                m = get_valid_mask(mask, desired_shape=self.shape, error_string="Error setting flow mask: ")
+                self._mask = m.to(self._vecs.device)
+        except (TypeError, ValueError):
+            self._mask = None
+            self._require_finite("Error setting flow vectors: ")   # the vecs error comes first in the reference
+            raise
+        self._require_finite("Error setting flow vectors: ")
+        self.device = device
+
+    @classmethod
+    def _wrap(cls, vecs: torch.Tensor, ref: str, mask, device=None, flags: torch.Tensor = None) -> FlowAlias:
+        """Internal: wrap tensors that are valid by construction (kernel outputs, views of validated flows).
+        `flags` is the device-side flag word a kernel produced as a by-product, read lazily."""
+        obj = cls.__new__(cls)
+        obj._vecs, obj._ref, obj._mask = vecs, ref, mask
+        obj._device = vecs.device if device is None else device
+        obj._flag_cache, obj._pending_flags = None, flags
+        if obj._vecs.device != obj._device:
+            obj._vecs = obj._vecs.to(obj._device)
+        if obj._mask is not None and obj._mask.device != obj._device:
+            obj._mask = obj._mask.to(obj._device)
+        return obj
+
+    # -- flags: finiteness + zero tests, one fused reduction per tensor version ------------------
+    def _flags(self) -> list:
+        key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+        if self._flag_cache is None or self._flag_cache[0] != key:
+            if self._pending_flags is not None and self._pending_flags[0] == key:
+                dev_flags = self._pending_flags[1]
+            else:
+                dev_flags = _native.flow_flags(self._vecs, self._mask)
+            self._pending_flags = None
+            self._flag_cache = (key, _flags_to_host(dev_flags))
+        return self._flag_cache[1]
+
+    def _set_pending_flags(self, dev_flags):
+        if dev_flags is not None:
+            key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+            self._pending_flags = (key, dev_flags)
+
+    def _require_finite(self, error_string: str):
+        if any(f & _native.FLAG_NONFINITE for f in self._flags()):                     # utils.py:98
+            raise ValueError(error_string + "Input contains NaN, Inf or -Inf values")
+
+    def _all_zero(self, bit: int) -> bool:
+        return not any(f & bit for f in self._flags())
+
+    @property
+    def vecs(self) -> torch.Tensor:
+        """Flow vectors N-2-H-W, fp32 (flow_class.py:68-80)"""
+        return self._vecs
+
+    @vecs.setter
+    def vecs(self, input_vecs):
+        v = get_valid_vecs(input_vecs, error_string="Error setting flow vectors: ", _check_finite=False)
+        old = self._vecs
+        self._vecs, self._flag_cache, self._pending_flags = v, None, None
+        try:
+            self._require_finite("Error setting flow vectors: ")
+        except ValueError:
+            self._vecs, self._flag_cache = old, None
+            raise
+
+    @property
+    def vecs_numpy(self) -> np.ndarray:
+        """N-H-W-2 float32 numpy view of the vectors (flow_class.py:95-110)"""
+        return np.moveaxis(self._vecs.detach().cpu().numpy(), 1, -1)
+
+    @property
+    def ref(self) -> str:
+        """'s' (source) or 't' (target) reference (flow_class.py:112-148)"""
+        return self._ref
+
+    @ref.setter
+    def ref(self, input_ref: str = None):
+        self._ref = get_valid_ref(input_ref)
+
+    @property
+    def mask(self) -> torch.Tensor:
+        """Validity mask N-H-W bool (flow_class.py:159-172).  An all-True default is materialised on first use."""
+        if self._mask is None:
+            self._mask = torch.ones(self.shape, dtype=torch.bool, device=self._vecs.device)
+            self._flag_cache = None if self._flag_cache is None else \
+                ((self._vecs._version, (id(self._mask), self._mask._version)), self._flag_cache[1])
+        return self._mask
+
+    @mask.setter
+    def mask(self, input_mask=None):
+        if input_mask is None:
+            self._mask = None
+        else:
+            m = get_valid_mask(input_mask, desired_shape=self.shape, error_string="Error setting flow mask: ")
+            self._mask = m.to(self._vecs.device)
+        self._flag_cache, self._pending_flags = None, None
+
+    @property
+    def mask_numpy(self) -> np.ndarray:
+        """flow_class.py:188-205"""
+        return self.mask.detach().cpu().numpy()
+
+    @property
+    def device(self) -> torch.device:
+        """flow_class.py:207-213"""
+        return self._device
+
+    @device.setter
+    def device(self, input_device=None):
+        device = self._vecs.device if input_device is None else get_valid_device(input_device)
+        self._device = device
+        if self._vecs.device != device:
+            self._vecs = self._vecs.to(device)
+            self._flag_cache = None if self._flag_cache is None else \
+                ((self._vecs._version, self._flag_cache[0][1]), self._flag_cache[1])
+        if self._mask is not None and self._mask.device != device:
+            flags = None if self._flag_cache is None else self._flag_cache[1]
+            self._mask = self._mask.to(device)
+            if flags is not None:
+                self._flag_cache = ((self._vecs._version, (id(self._mask), self._mask._version)), flags)
+
+    @property
+    def shape(self) -> tuple:
+        """(N, H, W) (flow_class.py:228-236)"""
+        return (self._vecs.shape[0],) + tuple(self._vecs.shape[2:])
+
+    @classmethod
+    def zero(cls, shape, ref: str = None, mask=None, device=None) -> FlowAlias:
+        """All-zero flow of shape (H, W) or (N, H, W) (flow_class.py:238-258)"""
+        dims = get_valid_shape(shape)
+        return cls(torch.zeros(dims[0], 2, dims[1], dims[2]), ref, mask, device)
+
+    @classmethod
+    def from_matrix(cls, matrix, shape, ref: str = None, mask=None, device=None, matrix_is_inverse: bool = None) -> FlowAlias:
+        """flow_class.py:260-292"""
+        device = get_valid_device(device) if device is not None else None
+        return cls(from_matrix(matrix, shape, ref, matrix_is_inverse), ref, mask, device)
+
+    @classmethod
+    def from_transforms(cls, transform_list: list, shape, ref: str = None, mask=None, device=None,
+                        padding: list = None) -> FlowAlias:
+        """flow_class.py:294-328"""
+        device = get_valid_device(device) if device is not None else None
+        return cls(from_transforms(transform_list, shape, ref, padding), ref, mask, device)
+
+    # ------------------------------------------------------------------------------------------
+    # copies, indexing (flow_class.py:376-448)
+    # ------------------------------------------------------------------------------------------
+    def copy(self) -> FlowAlias:
+        return Flow(self._vecs, self._ref, self._mask, self._device)
+
+    def to_device(self, device) -> FlowAlias:
+        device = get_valid_device(device)
+        return Flow(self._vecs.to(device), self._ref, None if self._mask is None else self._mask.to(device), device)
+
+    def __str__(self) -> str:
+        return "Flow object, reference {}, batch size {}, shape {}*{}, device {}; ".format(
+            self._ref, *self.shape, self._device) + self.__repr__()
+
+    def select(self, item: int = None) -> FlowAlias:
+        if item is None:
+            return self
+        if not isinstance(item, int):
+            raise TypeError("Error selecting from flow object: item needs to be an integer")
+        try:
+            return Flow(self._vecs[item], self._ref, self.mask[item], self._device)
+        except IndexError:
+            raise IndexError("Error selecting from flow object: item {} out of bounds for flow with batch size {}"
+                             .format(item, self.shape[0]))
+
+    def __getitem__(self, item) -> FlowAlias:
+        # index H, W (then N, 2) the way a tensor of shape H-W-N-2 would be indexed (flow_class.py:433-448)
+        vecs = self._vecs.permute(2, 3, 0, 1).__getitem__(item).permute(2, 3, 0, 1)
+        mask = self.mask.permute(1, 2, 0).__getitem__(item).permute(2, 0, 1)
+        return Flow(vecs, self._ref, mask, self._device)
+
+    # ------------------------------------------------------------------------------------------
+    # arithmetic (flow_class.py:450-692)
+    # ------------------------------------------------------------------------------------------
+    def _binary_operand(self, other, verb_ing: str, names: tuple):
+        if isinstance(other, (np.ndarray, torch.Tensor)):
+            ov = get_valid_vecs(other, desired_shape=self.shape, error_string="Error adding to flow: ")
+            om = None
+        elif isinstance(other, Flow):
+            ov, om = other._vecs, other._mask
+        else:
+            raise TypeError("Error {}: {} is not a flow object, numpy array, or torch tensor".format(verb_ing, names[0]))
+        if self.shape[0] != ov.shape[0] and self.shape[0] != 1 and ov.shape[0] != 1:
+            raise ValueError("Error {}: {} batch dimensions don't match, and neither is 1".format(verb_ing, names[1]))
+        if self.shape[1:] != tuple(ov.shape[2:]):
+            raise ValueError("Error {}: {} flow objects are not the same shape".format(verb_ing, names[1]))
+        return ov.to(self._device), (None if om is None else om.to(self._device))
+
+    def _and_masks(self, other_mask):
+        if self._mask is None and other_mask is None:
+            return None
+        if self._mask is None:
+            return other_mask if other_mask.shape[0] >= self.shape[0] else other_mask.expand(self.shape).clone()
+        if other_mask is None:
+            return self._mask
+        return self._mask & other_mask
+
+    def __add__(self, other) -> FlowAlias:
+        """Vector sum, masks ANDed -- not a composition (flow_class.py:450-488)"""
+        ov, om = self._binary_operand(other, "adding to flow", ("Addend", "Augend and addend"))
+        vecs = self._vecs + ov
+        mask = self._and_masks(om)
+        if mask is not None and mask.shape[0] != vecs.shape[0]:
+            mask = mask.expand(vecs.shape[0], -1, -1)
+        return Flow._wrap(vecs, self._ref, mask, self._device)
+
+    def __sub__(self, other) -> FlowAlias:
+        """flow_class.py:490-531"""
+        ov, om = self._binary_operand(other, "subtracting from flow", ("Subtrahend", "Minuend and subtrahend"))
+        vecs = self._vecs - ov
+        mask = self._and_masks(om)
+        if mask is not None and mask.shape[0] != vecs.shape[0]:
+            mask = mask.expand(vecs.shape[0], -1, -1)
+        return Flow._wrap(vecs, self._ref, mask, self._device)
+
+    def _scalar_or_field(self, other, verb_ing: str, noun: str):
+        """Operand of * / **: number, list of 2, or array of shape 2, H-W, 2-H-W, H-W-2, N-2-H-W."""
+        try:
+            return float(other)
+        except (TypeError, ValueError):
+            pass
+        if isinstance(other, list):
+            if len(other) != 2:
+                raise ValueError("Error {} flow: {} list not length 2".format(verb_ing, noun))
+            other = torch.tensor(other)
+        elif isinstance(other, np.ndarray):
+            other = torch.tensor(other)
+        if not isinstance(other, torch.Tensor):
+            raise TypeError("Error {} flow: {} cannot be converted to float, or isn't a list, numpy array, or torch "
+                            "tensor".format(verb_ing, noun))
+        hw = self.shape[1:]
+        if other.dim() == 1 and other.shape[0] == 2:
+            other = other.view(1, 2, 1, 1)
+        elif other.dim() == 2 and tuple(other.shape) == hw:
+            other = other.view(1, 1, *hw)
+        elif other.dim() == 3 and tuple(other.shape) == (2,) + hw:
+            other = other.unsqueeze(0)
+        elif other.dim() == 3 and tuple(other.shape) == hw + (2,):
+            other = move_axis(other, -1, 0).unsqueeze(0)
+        elif other.dim() == 4 and tuple(other.shape[2:]) == hw and other.shape[1] == 2 and \
+                (self.shape[0] == 1 or other.shape[0] == 1 or self.shape[0] == other.shape[0]):
+            pass
+        else:
+            raise ValueError("Error {} flow: {} array or tensor needs to be of size 2, of the shape of the flow object "
+                             "(H-W), or 2-H-W or H-W-2, or N-2-H-W".format(verb_ing, noun))
+        return other.to(self._device)
+
+    def _result_of(self, vecs) -> FlowAlias:
+        mask = self._mask
+        if mask is not None and vecs.shape[0] != self.shape[0]:
+            mask = mask.repeat(vecs.shape[0], 1, 1)
+        return Flow(vecs, self._ref, mask, self._device)
+
+    def __mul__(self, other) -> FlowAlias:
+        """flow_class.py:533-580"""
+        o = self._scalar_or_field(other, "multiplying", "Multiplier")
+        if isinstance(o, float):
+            return Flow._wrap(self._vecs * o, self._ref, self._mask, self._device) if np.isfinite(o) \
+                else Flow(self._vecs * o, self._ref, self._mask, self._device)
+        return self._result_of(self._vecs * o)
+
+    def __truediv__(self, other) -> FlowAlias:
+        """flow_class.py:582-629"""
+        return self._result_of(self._vecs / self._scalar_or_field(other, "dividing", "Divisor"))
+
+    def __pow__(self, other) -> FlowAlias:
+        """flow_class.py:631-678"""
+        return self._result_of(self._vecs ** self._scalar_or_field(other, "exponentiating", "Exponent"))
+
+    def __neg__(self) -> FlowAlias:
+        """flow_class.py:680-692"""
+        return self * -1
+
+    # ------------------------------------------------------------------------------------------
+    # resize / pad (flow_class.py:694-753) -- thin PyTorch wrappers, not on the kernel path
+    # ------------------------------------------------------------------------------------------
+    def resize(self, scale) -> FlowAlias:
+        resized = resize_flow(self._vecs, scale)
+        sc = [scale, scale] if isinstance(scale, (float, int)) else scale
+        m = F.interpolate(self.mask.float().unsqueeze(1), scale_factor=sc, mode='bilinear',
+                          align_corners=False).squeeze(1)
+        return Flow(resized, self._ref, torch.round(m), device=self._device)
+
+    def pad(self, padding: list = None, mode: str = None) -> FlowAlias:
+        mode = 'constant' if mode is None else mode
+        if mode not in ('constant', 'reflect', 'replicate'):
+            raise ValueError("Error padding flow: Mode should be one of "
+                             "'constant', 'reflect', or 'replicate', but instead got '{}'".format(mode))
+        padding = get_valid_padding(padding, "Error padding flow: ")
+        lrtb = (padding[2], padding[3], padding[0], padding[1])
+        return Flow._wrap(F.pad(self._vecs, lrtb, mode=mode), self._ref,
+                          F.pad(self.mask.unsqueeze(1), lrtb).squeeze(1), self._device)
+
+    def unpad(self, padding: list = None) -> FlowAlias:
+        padding = get_valid_padding(padding, "Error padding flow: ")
+        h, w = self.shape[1:3]
+        if sum(padding[0:2]) > h - 1 or sum(padding[2:4]) > w - 1:
+            raise ValueError("Error unpadding flow: one or more dimensions cut to zero or less")
+        return self[padding[0]:h - padding[1], padding[2]:w - padding[3]]
+
+    # ------------------------------------------------------------------------------------------
+    # apply (flow_class.py:755-959)
+    # ------------------------------------------------------------------------------------------
+    def apply(self, target, target_mask: torch.Tensor = None, return_valid_area: bool = None,
+              consider_mask: bool = None, padding: list = None, cut: bool = None):
+        """Warp `target` (tensor H-W / C-H-W / N-C-H-W, or a Flow) with this flow.  One fused kernel launch: the
+        target's mask rides along as an extra channel, is thresholded at 0.99999 and ANDed with the flow mask in
+        the same pass (reference: cat + apply_flow + gt + and, flow_class.py:896-934)."""
+        return_valid_area = False if return_valid_area is None else return_valid_area
+        if not isinstance(return_valid_area, bool):
+            raise TypeError("Error applying flow: Return_valid_area needs to be a boolean")
+        consider_mask = True if consider_mask is None else consider_mask
+        if not isinstance(consider_mask, bool):
+            raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
+        cut = True if cut is None else cut
+        if not isinstance(cut, bool):
+            raise TypeError("Error applying flow: Cut needs to be a boolean")
+        if padding is not None:
+            padding = get_valid_padding(padding, "Error applying flow: ")
+            if self.shape[1] + padding[0] + padding[1] != target.shape[-2] or \
+                    self.shape[2] + padding[2] + padding[3] != target.shape[-1]:
+                raise ValueError("Error applying flow: Padding values do not match flow and target shape difference")
+
+        return_dtype, return_2d, return_3d = torch.float, False, False
+        if isinstance(target, Flow):
+            return_flow = True
+            t, tmask = target._vecs, target._mask
+        elif isinstance(target, torch.Tensor):
+            return_flow = False
+            if target.dim() == 4:
+                t = target
+            elif target.dim() == 3:
+                t, return_3d = target.unsqueeze(0), True
+            elif target.dim() == 2:
+                t, return_2d = target.unsqueeze(0).unsqueeze(0), True
+            else:
+                raise ValueError("Error applying flow: Target needs to have the shape H-W (2 dimensions)"
+                                 ", C-H-W (3 dimensions), or N-C-H-W (4 dimensions)")
+            tmask = None
+            if target_mask is not None:
+                if not isinstance(target_mask, torch.Tensor):
+                    raise TypeError("Error applying flow: Target_mask needs to be a torch tensor")
+                if target_mask.dim() == 2:
+                    target_mask = target_mask.unsqueeze(0)
+                if tuple(target_mask.shape) != (t.shape[0],) + tuple(t.shape[2:]):
+                    raise ValueError("Error applying flow: Target_mask needs to match the target shape")
+                if target_mask.dtype != torch.bool:
+                    raise TypeError("Error applying flow: Target_mask needs to have dtype 'bool'")
+                if not return_valid_area:
+                    warnings.warn("Warning applying flow: a mask is passed, but return_valid_area is False - so the "
+                                  "mask passed will not affect the output, but possibly make the function slower.")
+                tmask = target_mask
+            return_dtype = target.dtype
+        else:
+            raise TypeError("Error applying flow: Target needs to be either a flow object or a torch tensor")
+        need_valid = return_flow or return_valid_area
+
+        if padding is None:
+            if tuple(target.shape[-2:]) != self.shape[-2:]:
+                raise ValueError("Error applying flow: Flow and target have to have the same shape")
+            flow = self
+        else:
+            # 't': zero padding is irrelevant outside the flow area; 's': replicate avoids artefacts at the
+            # border of the flow area (flow_class.py:906-913).  Padded mask is False, so the un-padded
+            # formulas below hold for the padded flow as they stand.
+            flow = self.pad(padding, mode='constant' if self._ref == 't' else 'replicate')
+
+        rm = _native.ROUND_NONE
+        if not return_flow and not return_dtype.is_floating_point:
+            rm = _native.ROUND_U8 if return_dtype == torch.uint8 else _native.ROUND_RINT
+        warped, valid = flow._warp(t, tmask, need_valid, consider_mask, rm)
+
+        if padding is not None and cut:
+            win = (slice(padding[0], padding[0] + self.shape[1]), slice(padding[2], padding[2] + self.shape[2]))
+            warped = warped[..., win[0], win[1]]
+            if valid is not None:
+                valid = valid[..., win[0], win[1]]
+
+        if return_flow:
+            return Flow._wrap(warped, target._ref, valid, self._device)
+        if not return_dtype.is_floating_point:
+            if not get_pure_pytorch():
+                warped = warped.to(return_dtype)         # PURE_PYTORCH keeps the rounded values as floats (:943-949)
+        else:
+            warped = warped.to(return_dtype)
+        if (return_2d or return_3d) and warped.shape[0] == 1:
+            warped = warped[0, 0] if return_2d else warped[0]
+        return (warped, valid) if return_valid_area else warped
+
+    def _warp(self, t: torch.Tensor, tmask, need_valid: bool, consider_mask: bool, round_mode: int = 0):
+        """Core of `apply`: t [Nt,C,H,W] any dtype, tmask [Nt,H,W] bool or None (all True).
+        Returns (warped fp32 [N,C,H,W], valid bool [N,H,W] | None) on self.device."""
+        if self._ref == 's' and not get_pure_pytorch():
+            _griddata_unavailable("Flow.apply(ref='s')")
+        self._require_finite("Error applying flow to a target: ")
+        if self._all_zero(_native.FLAG_NZ_THR):
+            # apply_flow's early exit (utils.py:497-498): every |component| < 1e-3 -> the target (and its mask
+            # channel) pass through unchanged; batch broadcasting as in flow_class.py:895-898, 922-934
+            warped = t.to(torch.float).to(self._device)
+            valid = None
+            if need_valid:
+                valid = torch.ones((t.shape[0],) + tuple(t.shape[2:]), dtype=torch.bool, device=self._device) \
+                    if tmask is None else tmask.to(self._device)
+                if self._ref == 's':                                  # mask & self._mask before the warp (:895)
+                    valid = valid & self.mask if self._mask is not None or valid.shape[0] < self.shape[0] else valid
+                if valid.shape[0] != warped.shape[0]:                 # :896-897
+                    warped = warped.expand(valid.shape[0], -1, -1, -1)
+                if self._ref == 't':                                  # ... or after it (:934)
+                    valid = valid & self.mask if self._mask is not None or valid.shape[0] < self.shape[0] else valid
+            if round_mode:
+                warped = torch.round(warped)
+                if round_mode == _native.ROUND_U8:
+                    warped = torch.clamp(warped, 0, 255)
+            return warped, valid
+        if self._ref == 't':
+            warped, valid, _, _ = _native.warp_bwd(self._vecs, t, src_mask=tmask,
+                                                   flow_mask=self._mask if need_valid else None,
+                                                   want_valid=need_valid, round_mode=round_mode)
+        else:
+            warped, valid, _, _ = _native.splat_fwd(self._vecs, t, weight_mask=self._mask if consider_mask else None,
+                                                    chan_mask_a=tmask, chan_mask_b=self._mask,
+                                                    want_valid=need_valid, occlude=True, round_mode=round_mode)
+        return warped.to(self._device), (None if valid is None else valid.to(self._device))
+
+    # ------------------------------------------------------------------------------------------
+    # switch_ref / invert (flow_class.py:1022-1086)
+    # ------------------------------------------------------------------------------------------
+    def switch_ref(self, mode: str = None) -> FlowAlias:
+        mode = 'valid' if mode is None else mode
+        if mode == 'invalid':
+            return Flow._wrap(self._vecs, 't' if self._ref == 's' else 's', self._mask, self._device)
+        if mode != 'valid':
+            raise ValueError("Error switching flow reference: Mode not recognised, should be 'valid' or 'invalid'")
+        if self._all_zero(_native.FLAG_NZ_MASKED):                                   # flow_class.py:1046
+            return self.switch_ref(mode='invalid')
+        if self._ref == 's':
+            out = self.apply(self)                                                    # one splat: P(f, f||[m], m)
+            out._ref = 't'
+            return out
+        as_s = self.switch_ref(mode='invalid')
+        return (-as_s).apply(as_s)                                                    # one splat: P(-f, f||[m], m)
+
+    def invert(self, ref: str = None) -> FlowAlias:
+        ref = self._ref if ref is None else get_valid_ref(ref)
+        if self._ref == 's':
+            if ref == 's':
+                return self.apply(-self)
+            return Flow._wrap(self._vecs * -1.0, 't', self._mask, self._device)
+        if ref == 's':
+            return Flow._wrap(self._vecs * -1.0, 's', self._mask, self._device)
+        return self.invert('s').switch_ref()
+
+    # ------------------------------------------------------------------------------------------
+    # valid areas (flow_class.py:1088-1172)
+    # ------------------------------------------------------------------------------------------
+    def valid_target(self, consider_mask: bool = None) -> torch.Tensor:
+        consider_mask = True if consider_mask is None else consider_mask
+        if not isinstance(consider_mask, bool):
+            raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
+        if self._ref == 's':
+            area = apply_flow(self._vecs, self.mask.unsqueeze(1).to(torch.float), 's',
+                              self.mask if consider_mask else None).squeeze(1)
+            return area == 1
+        ones = torch.ones((self.shape[0], 1) + self.shape[1:], device=self._device)
+        area = apply_flow(self._vecs, ones, 't').squeeze(1)
+        return (area > 0.9999) & self.mask
+
+    def valid_source(self, consider_mask: bool = None) -> torch.Tensor:
+        consider_mask = True if consider_mask is None else consider_mask
+        if not isinstance(consider_mask, bool):
+            raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
+        if self._ref == 's':
+            ones = torch.ones((self.shape[0], 1) + self.shape[1:], device=self._device)
+            area = apply_flow(-self._vecs, ones, 't').squeeze(1)
+            return (area > 0.9999) & self.mask
+        area = apply_flow(-self._vecs, self.mask.unsqueeze(1).to(torch.float), 's',
+                          self.mask if consider_mask else None).squeeze(1)
+        return area == 1
+
+    # ------------------------------------------------------------------------------------------
+    # zero test (flow_class.py:1226-1244)
+    # ------------------------------------------------------------------------------------------
+    def is_zero(self, thresholded: bool = None, masked: bool = None) -> torch.Tensor:
+        masked = True if masked is None else masked
+        if not isinstance(masked, bool):
+            raise TypeError("Error checking whether flow is zero: Masked needs to be a boolean")
+        thresholded = True if thresholded is None else thresholded
+        if not isinstance(thresholded, bool):
+            raise TypeError("Error checking whether flow is zero: Thresholded needs to be a boolean")
+        if masked:
+            bit = _native.FLAG_NZ_THR_MASKED if thresholded else _native.FLAG_NZ_MASKED
+        else:
+            bit = _native.FLAG_NZ_THR if thresholded else _native.FLAG_NZ
+        return torch.tensor([(f & bit) == 0 for f in self._flags()], dtype=torch.bool, device=self._device)
+
+    # ------------------------------------------------------------------------------------------
+    # composition (flow_class.py:1648-1810)
+    # ------------------------------------------------------------------------------------------
+    def combine_with(self, flow: FlowAlias, mode: int, thresholded: bool = None) -> FlowAlias:
+        """flow_1 (+) flow_2 = flow_3 for two flows of equal shape and reference; `mode` names the unknown.
+        Mode 3 is ONE fused launch (gather of (u, v, mask) + vector add + mask AND)."""
+        if not isinstance(flow, Flow):
+            raise TypeError("Error combining flows: Flow need to be of type 'Flow'")
+        if self.shape != flow.shape:
+            raise ValueError("Error combining flows: Flow fields need to have the same shape, including batch size")
+        if self.ref != flow.ref:
+            raise ValueError("Error combining flows: Flow fields need to have the same reference")
+        if self._device != flow._device:
+            flow = flow.to_device(self._device)
+        if mode not in [1, 2, 3]:
+            raise ValueError("Error combining flows: Mode needs to be 1, 2 or 3")
+        thresholded = False if thresholded is None else thresholded
+        if not isinstance(thresholded, bool):
+            raise TypeError("Error combining flows: Thresholded needs to be a boolean")
+        self._require_finite("Error combining flows: ")
+        flow._require_finite("Error combining flows: ")
+
+        bit = _native.FLAG_NZ_THR_MASKED if thresholded else _native.FLAG_NZ_MASKED
+        if self._all_zero(bit):                                                      # flow_class.py:1729-1737
+            return flow
+        if flow._all_zero(bit):                                                      # :1738-1744
+            return self if mode == 3 else self.invert()
+
+        ref = self._ref
+        if mode == 3:
+            return self._combine3(flow)
+        if mode == 1:
+            if ref == 's':                                                           # :1759-1760
+                flow_inv_t = flow.invert('t')
+                return flow - (flow_inv_t + flow_inv_t.apply(self.switch_ref())).apply(self)
+            return self.invert().apply(flow - self)                                  # :1763
+        if ref == 's':                                                               # mode 2, :1768
+            return self.apply(flow - self)
+        if not get_pure_pytorch():
+            _griddata_unavailable("combine_with(mode=2, ref='t')")
+        return flow - flow.apply(self.invert().apply(self))                          # :1773
+
+    def _combine3(self, flow: FlowAlias) -> FlowAlias:
+        """mode 3: 't'  f3 = f2 + G(f2, f1),  m3 = m2 & theta(G(f2, [m1]))           (flow_class.py:1808)
+                   's'  f3 = f1 + G(-f1, f2), m3 = m1 & theta(G(-f1, [m2]))          (flow_class.py:1804)"""
+        if self._ref == 't':
+            warper, sign, src = flow, 1.0, self
+        else:
+            warper, sign, src = self, -1.0, flow
+        if warper._all_zero(_native.FLAG_NZ_THR):
+            # apply_flow's thresholded early exit inside .apply (utils.py:497): the gather is the identity
+            return warper + Flow._wrap(src._vecs, src._ref, src._and_masks(warper._mask), self._device)
+        vecs, valid, _, _ = _native.warp_bwd(warper._vecs, src._vecs, flow_sign=sign, src_mask=src._mask,
+                                             flow_mask=warper._mask, want_valid=True, addend=warper._vecs)
+        return Flow._wrap(vecs, self._ref, valid, self._device)

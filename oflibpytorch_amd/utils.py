@@ -1,0 +1,446 @@
+"""Host-side mirror of the reference's functional layer for the warp / compose hot path.
+
+Same names, argument meaning, defaults and error behaviour as ``oflibpytorch.utils`` (reference
+``src/oflibpytorch/utils.py``; cited per function); the arithmetic runs in the HIP kernels of
+``libofl_hip.so`` through :mod:`oflibpytorch_amd._native`.  Validation, shape plumbing and the flow
+generators are plain PyTorch host code.
+"""
+import math
+from typing import Any, Union
+
+import numpy as np
+import torch
+
+from . import _native
+
+DEFAULT_THRESHOLD = 1e-3   # utils.py:23
+PURE_PYTORCH = True        # utils.py:24 -- the HIP path implements the PURE_PYTORCH=True behaviour
+
+
+def get_pure_pytorch() -> bool:
+    """utils.py:27-33"""
+    return PURE_PYTORCH
+
+
+def set_pure_pytorch(warn: bool = None):
+    """utils.py:36-51"""
+    global PURE_PYTORCH
+    PURE_PYTORCH = True
+    if bool(warn):
+        print("Pure Pytorch mode set: no use of scipy.interpolate.griddata. Differentiable, significantly faster, "
+              "but more approximate")
+
+
+def unset_pure_pytorch(warn: bool = None):
+    """utils.py:54-69.  The flag is kept for API compatibility; the griddata (Delaunay, CPU-only) variants of
+    the 's'-reference operations are outside the accelerated path and raise NotImplementedError."""
+    global PURE_PYTORCH
+    PURE_PYTORCH = False
+    if bool(warn):
+        print("Pure Pytorch mode unset: scipy.interpolate.griddata used. Not all methods remain differentiable, "
+              "significantly slower, but more accurate")
+
+
+def _griddata_unavailable(what: str):
+    raise NotImplementedError("oflibpytorch_amd: %s with PURE_PYTORCH unset needs scipy.interpolate.griddata, which "
+                              "is outside the MI355X hot path; call set_pure_pytorch()" % what)
+
+
+# ------------------------------------------------------------------------------------------------
+# validators (utils.py:72-232): TypeError for wrong types, ValueError for wrong shapes / values
+# ------------------------------------------------------------------------------------------------
+def _flags_to_host(flags: torch.Tensor) -> list:
+    return [int(v) for v in flags.cpu().tolist()]
+
+
+def get_valid_vecs(vecs: Any, desired_shape: Union[tuple, list] = None, error_string: str = None,
+                   _check_finite: bool = True) -> torch.Tensor:
+    """utils.py:72-118 -> N-2-H-W float tensor.  ``_check_finite=False`` is for internal callers that get the
+    finiteness flag as a by-product of the kernel they are about to launch."""
+    error_string = '' if error_string is None else error_string
+    if not isinstance(vecs, (np.ndarray, torch.Tensor)):
+        raise TypeError(error_string + "Input is not a numpy array or a torch tensor")
+    ndim = len(vecs.shape)
+    if ndim not in (3, 4):
+        raise ValueError(error_string + "Input has {} dimensions, should be 3 or 4".format(ndim))
+    if isinstance(vecs, np.ndarray):
+        vecs = torch.tensor(vecs, dtype=torch.float, device='cpu')
+    if ndim == 3:
+        vecs = vecs.unsqueeze(0)
+    if vecs.shape[1] != 2:
+        if vecs.shape[3] == 2:                      # N-H-W-2 -> N-2-H-W
+            vecs = move_axis(vecs, -1, 1)
+        else:
+            raise ValueError(error_string + "Input needs to be shape (N-)H-W-2 or (N-)2-H-W")
+    vecs = vecs.float()
+    if _check_finite:
+        if vecs.device.type == 'cpu' and not torch.cuda.is_available():
+            finite = bool(torch.isfinite(vecs).all())          # host-only validation (no HIP device at all)
+        else:
+            finite = not any(f & _native.FLAG_NONFINITE for f in _flags_to_host(_native.flow_flags(vecs)))
+        if not finite:
+            raise ValueError(error_string + "Input contains NaN, Inf or -Inf values")
+    if desired_shape is not None:
+        d = get_valid_shape(desired_shape)
+        if vecs.shape[0] != d[0] or vecs.shape[2] != d[1] or vecs.shape[3] != d[2]:
+            raise ValueError(error_string + "Input shape does not match the desired shape")
+    return vecs
+
+
+def get_valid_shape(shape: Any) -> tuple:
+    """utils.py:121-132"""
+    if not isinstance(shape, (list, tuple)):
+        raise TypeError("Error creating flow from matrix: Dims need to be a list or a tuple")
+    if len(shape) not in (2, 3):
+        raise ValueError("Error creating flow from matrix: Dims need to be a list or a tuple of length 2 or 3")
+    if any((not isinstance(item, int) or item <= 0) for item in shape):
+        raise ValueError("Error creating flow from matrix: Dims need to be a list or a tuple of integers above zero")
+    return ((1,) + tuple(shape)) if len(shape) == 2 else tuple(shape)
+
+
+def get_valid_ref(ref: Any) -> str:
+    """utils.py:134-148"""
+    if ref is None:
+        return 't'
+    if not isinstance(ref, str):
+        raise TypeError("Error setting flow reference: Input is not a string")
+    if ref not in ('s', 't'):
+        raise ValueError("Error setting flow reference: Input is not 's' or 't', but {}".format(ref))
+    return ref
+
+
+def get_valid_mask(mask: Any, desired_shape: Union[tuple, list] = None, error_string: str = None) -> torch.Tensor:
+    """utils.py:151-186 -> N-H-W bool tensor"""
+    error_string = '' if error_string is None else error_string
+    if not isinstance(mask, (np.ndarray, torch.Tensor)):
+        raise TypeError(error_string + "Input is not a numpy array or a torch tensor")
+    ndim = len(mask.shape)
+    if ndim not in (2, 3):
+        raise ValueError(error_string + "Input has {} dimensions, should be 2 or 3".format(ndim))
+    if isinstance(mask, np.ndarray):
+        mask = torch.tensor(mask)
+    if mask.dtype != torch.bool and bool(((mask != 0) & (mask != 1)).any()):   # a bool tensor is 0/1 by construction
+        raise ValueError(error_string + "Values must be 0 or 1")
+    if ndim == 2:
+        mask = mask.unsqueeze(0)
+    if desired_shape is not None and tuple(mask.shape) != get_valid_shape(desired_shape):
+        raise ValueError(error_string + "Input shape does not match the desired shape")
+    return mask.to(torch.bool)
+
+
+def get_valid_device(device: Any) -> torch.device:
+    """utils.py:189-212"""
+    if device is None:
+        device = torch.device('cpu')
+    elif not isinstance(device, torch.device):
+        try:
+            device = torch.device(device)
+        except (RuntimeError, TypeError):
+            raise ValueError("Error setting tensor device: Input needs to be a torch.device, or valid input to "
+                             "torch.device(). Instead found {}".format(device))
+    if device.type == 'cuda':
+        if not torch.cuda.is_available():
+            raise ValueError("Error setting tensor device: Input is 'cuda', but cuda is not available")
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+    return device
+
+
+def get_valid_padding(padding: Any, error_string: str = None) -> list:
+    """utils.py:215-232"""
+    error_string = '' if error_string is None else error_string
+    if not isinstance(padding, (list, tuple)):
+        raise TypeError(error_string + "Padding needs to be a list [top, bot, left, right]")
+    if len(padding) != 4:
+        raise ValueError(error_string + "Padding list needs to be a list of length 4 [top, bot, left, right]")
+    if not all(isinstance(item, int) for item in padding):
+        raise ValueError(error_string + "Padding list [top, bot, left, right] items need to be integers")
+    if not all(item >= 0 for item in padding):
+        raise ValueError(error_string + "Padding list [top, bot, left, right] items need to be 0 or larger")
+    return padding
+
+
+# ------------------------------------------------------------------------------------------------
+# tensor helpers (utils.py:235-299)
+# ------------------------------------------------------------------------------------------------
+def move_axis(input_tensor: torch.Tensor, source: int, destination: int) -> torch.Tensor:
+    """np.moveaxis for tensors (utils.py:235-253)"""
+    return torch.movedim(input_tensor, source, destination)
+
+
+def to_numpy(tensor: torch.Tensor, switch_channels: bool = None) -> np.ndarray:
+    """utils.py:256-275"""
+    arr = tensor.detach().cpu().numpy()
+    return np.moveaxis(arr, 1, -1) if switch_channels else arr
+
+
+def to_tensor(array: np.ndarray, switch_channels: str = None, device=None) -> torch.Tensor:
+    """utils.py:278-299"""
+    device = get_valid_device(device)
+    if switch_channels == 'single':
+        array = np.moveaxis(array, -1, 0)
+    elif switch_channels == 'batched':
+        array = np.moveaxis(array, -1, 1)
+    return torch.tensor(array).to(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# flow generators (utils.py:339-442, 646-807) -- O(HW) one-off setup, host PyTorch
+# ------------------------------------------------------------------------------------------------
+def matrix_from_transform(transform: str, values: list) -> torch.Tensor:
+    """3x3 matrix of one transform (utils.py:396-424): translation [dx, dy]; rotation [cx, cy, deg ccw];
+    scaling [cx, cy, factor].  Image convention: y points down."""
+    m = torch.eye(3)
+    if transform == 'translation':
+        m[0, 2], m[1, 2] = values[0], values[1]
+    elif transform in ('rotation', 'scaling'):
+        to_origin = matrix_from_transform('translation', [-values[0], -values[1]])
+        back = matrix_from_transform('translation', [values[0], values[1]])
+        if transform == 'scaling':
+            m[0, 0] = m[1, 1] = values[2]
+        else:
+            a = math.radians(values[2])
+            m[0:2, 0:2] = torch.tensor([[math.cos(a), math.sin(a)], [-math.sin(a), math.cos(a)]])
+        m = back @ m @ to_origin
+    return m
+
+
+def matrix_from_transforms(transform_list: list) -> torch.Tensor:
+    """utils.py:379-393: product of the transforms, first list entry applied first"""
+    m = torch.eye(3)
+    for t in reversed(transform_list):
+        m = m @ matrix_from_transform(t[0], t[1:])
+    return m
+
+
+def reverse_transform_values(transform_list: list) -> list:
+    """utils.py:427-442"""
+    out = []
+    for t in transform_list:
+        name, v = t[0], t[1:]
+        if name == 'translation':
+            out.append([name, -v[0], -v[1]])
+        elif name == 'scaling':
+            out.append([name, v[0], v[1], 1 / v[2]])
+        elif name == 'rotation':
+            out.append([name, v[0], v[1], -v[2]])
+    return out
+
+
+def flow_from_matrix(matrix: torch.Tensor, shape: list) -> torch.Tensor:
+    """'s'-reference flow of a homography: M [x, y, 1]^T dehomogenised, minus [x, y] (utils.py:339-376).
+    matrix N-3-3, shape [N, H, W] -> N-2-H-W"""
+    n, h, w = shape
+    dev = matrix.device
+    gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    hom = torch.stack((gx.float().to(dev), gy.float().to(dev), torch.ones((h, w), device=dev)), dim=-1)   # H-W-3
+    moved = torch.matmul(matrix.float().unsqueeze(1).unsqueeze(1), hom.unsqueeze(-1)).squeeze(-1)      # N-H-W-3
+    pts = moved[..., 0:2] / moved[..., 2:3]
+    return move_axis(pts - hom[..., 0:2], -1, 1)
+
+
+def _validated_matrix(matrix, error_string, device=None):
+    if not isinstance(matrix, (np.ndarray, torch.Tensor)):
+        raise TypeError(error_string + "Matrix needs to be a numpy array or a torch tensor")
+    if isinstance(matrix, np.ndarray):
+        matrix = torch.tensor(matrix)
+    if matrix.dim() == 2:
+        matrix = matrix.unsqueeze(0)
+    if matrix.dim() != 3 or tuple(matrix.shape[1:]) != (3, 3):
+        raise ValueError(error_string + "Matrix needs to be of shape 3-3 or N-3-3")
+    return matrix.float()
+
+
+def from_matrix(matrix, shape, ref: str = None, matrix_is_inverse: bool = None) -> torch.Tensor:
+    """Flow vectors N-2-H-W from a transformation matrix (utils.py:646-726): for 's' the matrix is applied
+    directly, for 't' its inverse gives the backward flow (negated)."""
+    ref = get_valid_ref(ref)
+    matrix = _validated_matrix(matrix, "Error creating flow from matrix: ")
+    dims = get_valid_shape(shape)
+    if dims[0] != matrix.shape[0]:
+        if dims[0] == 1:
+            dims = (matrix.shape[0],) + dims[1:]
+        elif matrix.shape[0] == 1:
+            matrix = matrix.expand(dims[0], -1, -1)
+        else:
+            raise ValueError("Error creating flow from matrix: Batch size of the matrix and shape do not match")
+    matrix_is_inverse = False if matrix_is_inverse is None else matrix_is_inverse
+    if not isinstance(matrix_is_inverse, bool):
+        raise TypeError("Error creating flow from matrix: Matrix_is_inverse needs to be None or a Boolean")
+    if ref == 's':
+        if matrix_is_inverse:
+            raise ValueError("Error creating flow from matrix: Matrix_is_inverse cannot be True when ref is 's'")
+        return flow_from_matrix(matrix, list(dims))
+    if not matrix_is_inverse:
+        matrix = torch.pinverse(matrix)
+    return -flow_from_matrix(matrix, list(dims))
+
+
+def from_transforms(transform_list: list, shape, ref: str = None, padding: list = None) -> torch.Tensor:
+    """Flow vectors N-2-H-W from a list of transforms (utils.py:729-807): 's' uses the forward matrix, 't' the
+    matrix of the reversed transforms (no numerical inverse), negated.  `padding` [top, bot, left, right] grows
+    the field and shifts rotation / scaling centres with it."""
+    ref = get_valid_ref(ref)
+    if padding is not None:
+        padding = get_valid_padding(padding, "Error creating flow from transforms: ")
+        dims = get_valid_shape(shape)
+        shape = dims[:-2] + (dims[-2] + padding[0] + padding[1], dims[-1] + padding[2] + padding[3])
+        if isinstance(transform_list, list):
+            transform_list = [list(t) if isinstance(t, list) else t for t in transform_list]
+            for t in transform_list:
+                if isinstance(t, list) and len(t) == 4 and t[0] in ('rotation', 'scaling'):
+                    t[1] += padding[2]
+                    t[2] += padding[0]
+    if not isinstance(transform_list, list):
+        raise TypeError("Error creating flow from transforms: Transform_list needs to be a list")
+    for t in transform_list:
+        if not isinstance(t, list):
+            raise TypeError("Error creating flow from transforms: Transform_list needs to be a list of lists")
+        if len(t) < 1 or t[0] not in ('translation', 'rotation', 'scaling'):
+            raise ValueError("Error creating flow from transforms: Transform needs to be 'translation', 'rotation' "
+                             "or 'scaling'")
+        if len(t) != (3 if t[0] == 'translation' else 4):
+            raise ValueError("Error creating flow from transforms: Wrong number of values for " + t[0])
+        if not all(isinstance(v, (int, float)) for v in t[1:]):
+            raise ValueError("Error creating flow from transforms: Transform values need to be numbers")
+    dims = get_valid_shape(shape)
+    if ref == 's':
+        m = matrix_from_transforms(transform_list)
+        return flow_from_matrix(m.unsqueeze(0).expand(dims[0], -1, -1), list(dims))
+    m = matrix_from_transforms(list(reversed(reverse_transform_values(transform_list))))
+    return -flow_from_matrix(m.unsqueeze(0).expand(dims[0], -1, -1), list(dims))
+
+
+# ------------------------------------------------------------------------------------------------
+# hot path
+# ------------------------------------------------------------------------------------------------
+def normalise_coords(coords: torch.Tensor, shape: Union[tuple, list]) -> torch.Tensor:
+    """Pixel coordinates (x, y) -> [-1, 1] (utils.py:445-466).  API helper; inside the warp kernel the same
+    four fp32 operations are applied in the same order."""
+    if len(shape) != 2:
+        raise ValueError("Error normalising coords: Given shape needs to be list or tuple of length 2")
+    out = coords.float() * 2
+    out[..., 0] /= (shape[1] - 1)
+    out[..., 1] /= (shape[0] - 1)
+    out -= 1
+    return out
+
+
+def _round_mode(dtype: torch.dtype) -> int:
+    if dtype.is_floating_point:
+        return _native.ROUND_NONE
+    return _native.ROUND_U8 if dtype == torch.uint8 else _native.ROUND_RINT
+
+
+def apply_flow(flow, target: torch.Tensor, ref: str, mask=None) -> torch.Tensor:
+    """Warp `target` with `flow` (utils.py:469-620).  't': backward bilinear gather; 's': forward splat with the
+    zero-flow occlusion rule.  Returns a tensor of the target's shape and dtype on the flow's device."""
+    ref = get_valid_ref(ref)
+    flow = get_valid_vecs(flow, error_string="Error applying flow to a target: ", _check_finite=False)
+    flags = _flags_to_host(_native.flow_flags(flow))
+    if any(f & _native.FLAG_NONFINITE for f in flags):                          # utils.py:98
+        raise ValueError("Error applying flow to a target: Input contains NaN, Inf or -Inf values")
+    if not any(f & _native.FLAG_NZ_THR for f in flags):                         # utils.py:497-498
+        return target
+    if not isinstance(target, torch.Tensor):
+        raise TypeError("Error applying flow to a target: Target needs to be a torch tensor")
+    if target.dim() not in (2, 3, 4):
+        raise ValueError("Error applying flow to a target: Target tensor needs to have shape H-W, C-H-W, or N-C-H-W")
+    if target.shape[-2:] != flow.shape[-2:]:
+        raise ValueError("Error applying flow to a target: Target height and width needs to match flow field array")
+    if mask is not None:
+        mask = get_valid_mask(mask, desired_shape=(flow.shape[0],) + tuple(flow.shape[2:]))
+    dims, dtype = target.dim(), target.dtype
+    t = target if dims == 4 else (target.unsqueeze(0) if dims == 3 else target.unsqueeze(0).unsqueeze(0))
+    if t.shape[0] != flow.shape[0] and t.shape[0] != 1 and flow.shape[0] != 1:
+        raise ValueError("Error applying flow to target: Batch dimensions for flow ({}) and target ({}) don't match"
+                         .format(flow.shape[0], t.shape[0]))
+    rm = _round_mode(dtype)
+    if ref == 't':
+        out = _native.warp_bwd(flow, t, round_mode=rm)[0]
+    else:
+        if not get_pure_pytorch():
+            _griddata_unavailable("apply_flow(ref='s')")
+        out = _native.splat_fwd(flow, t, weight_mask=mask, occlude=True, round_mode=rm)[0]
+    out = out.to(flow.device)
+    if out.shape[0] == 1:
+        if dims == 2:
+            out = out[0, 0]
+        elif dims == 3:
+            out = out[0]
+    elif dims == 2:
+        out = out[:, 0]
+    return out.to(dtype)
+
+
+def resize_flow(flow, scale) -> torch.Tensor:
+    """Bilinear resize of a flow field with the vectors scaled along (utils.py:878-916).  Off the kernel path."""
+    valid_flow = get_valid_vecs(flow, error_string="Error resizing flow: ")
+    if isinstance(scale, (float, int)):
+        scale = [scale, scale]
+    elif isinstance(scale, (tuple, list)):
+        if len(scale) != 2:
+            raise ValueError("Error resizing flow: Scale {} must have a length of 2".format(type(scale)))
+        if not all(isinstance(item, (float, int)) for item in scale):
+            raise ValueError("Error resizing flow: Scale {} items must be integers or floats".format(type(scale)))
+    else:
+        raise TypeError("Error resizing flow: Scale must be an integer, float, or list or tuple of integers or floats")
+    if any(s <= 0 for s in scale):
+        raise ValueError("Error resizing flow: Scale values must be larger than 0")
+    import torch.nn.functional as F
+    resized = F.interpolate(valid_flow, scale_factor=list(scale), mode='bilinear', align_corners=False)
+    resized[:, 0] *= scale[1]
+    resized[:, 1] *= scale[0]
+    return resized.squeeze(0) if len(flow.shape) == 3 else resized
+
+
+def threshold_vectors(vecs: torch.Tensor, threshold: Union[float, int] = None, use_mag: bool = None) -> torch.Tensor:
+    """Zero every component strictly inside (-threshold, threshold) (utils.py:623-643).  API helper (elementwise
+    host-side PyTorch); the kernels apply the same strict test in-register."""
+    threshold = DEFAULT_THRESHOLD if threshold is None else threshold
+    out = vecs.clone()
+    if use_mag:
+        out[torch.norm(vecs, dim=1, keepdim=True).expand(-1, 2, -1, -1) < threshold] = 0
+    else:
+        out[(vecs < threshold) & (vecs > -threshold)] = 0
+    return out
+
+
+def is_zero_flow(flow, thresholded: bool = None) -> torch.Tensor:
+    """Per batch element: are all vectors zero (utils.py:919-938)?  One fused reduction kernel."""
+    flow = get_valid_vecs(flow, error_string="Error checking whether flow is zero: ", _check_finite=False)
+    thresholded = True if thresholded is None else thresholded
+    if not isinstance(thresholded, bool):
+        raise TypeError("Error checking whether flow is zero: Thresholded needs to be a boolean")
+    flags = _native.flow_flags(flow)
+    host = _flags_to_host(flags)
+    if any(f & _native.FLAG_NONFINITE for f in host):
+        raise ValueError("Error checking whether flow is zero: Input contains NaN, Inf or -Inf values")
+    bit = _native.FLAG_NZ_THR if thresholded else _native.FLAG_NZ
+    return torch.tensor([(f & bit) == 0 for f in host], dtype=torch.bool, device=flow.device)
+
+
+def get_flow_endpoints(flow: torch.Tensor, ref: str) -> tuple:
+    """End ('s') / start ('t') point grids x, y of shape N-H-W (utils.py:1045-1058).  API helper; the splat kernel
+    computes the same `s * flow + arange` in-register."""
+    n, _, h, w = flow.shape
+    s = +1 if ref == 's' else -1
+    x = s * flow[:, 0] + torch.arange(w, device=flow.device)[None, None, :]
+    y = s * flow[:, 1] + torch.arange(h, device=flow.device)[None, :, None]
+    return x, y
+
+
+def grid_from_unstructured_data(x: torch.Tensor, y: torch.Tensor, data: torch.Tensor, mask: torch.Tensor = None) -> tuple:
+    """Inverse-bilinear splat of `data` at positions (x, y) onto the regular grid (utils.py:1061-1154).
+    Returns (grid_data N-C-H-W, density N-H-W)."""
+    out, _, density, _ = _native.splat_fwd(None, data, xs=x, ys=y, weight_mask=mask, occlude=False, want_density=True)
+    return out.to(data.device), density.to(data.device)
+
+
+def apply_s_flow(flow: torch.Tensor, data: torch.Tensor, mask: torch.Tensor = None, occlude_zero_flow: bool = None) -> tuple:
+    """Forward warp with an 's'-reference flow (utils.py:1157-1205).  Returns (warped N-C-H-W, mask N-H-W bool of
+    the positions data was warped to)."""
+    occlude_zero_flow = True if occlude_zero_flow is None else occlude_zero_flow
+    out, _, _, warped = _native.splat_fwd(flow, data, weight_mask=mask, occlude=bool(occlude_zero_flow),
+                                          want_warped=True)
+    return out.to(flow.device), warped.to(flow.device)

@@ -1,0 +1,178 @@
+"""Replays a golden case (tests/golden/manifest.json) through the package's public API and compares the
+result with what the reference produced.  Used by the CPU host-logic tier (oracle-backed primitives) and
+by the GPU parity tier (HIP kernels)."""
+import numpy as np
+import torch
+
+import codec
+import oflibpytorch_amd as ofl
+from oflibpytorch_amd import Flow
+
+
+def T(a, device):
+    return None if a is None else torch.tensor(np.asarray(a)).to(device)
+
+
+def _flow(i, f, m, ref, device):
+    return Flow(T(i[f], device), ref, T(i.get(m), device))
+
+
+def _cfg1_fields(golden, device):
+    case = golden.cases["kats.cfg1_inputs"]
+    i, _ = golden.arrays(case)
+    out = {"img": T(i["img_u8"], device).float()}
+    for name in case["args"]["fields"]:
+        v = codec.decode_affine(i[name + "__params"], i[name + "__delta"], i[name + "__esc"])
+        out[name] = Flow(T(v[None], device), name[-1])
+    return out
+
+
+def run_case(case, golden, device):
+    """-> dict name -> torch tensor / python value, keyed like case['out'] (plus '_ref', '_same')."""
+    i, _ = golden.arrays(case)
+    a, op = case["args"], case["op"]
+    d = device
+    if op == 'normalise_coords':
+        return {"out": ofl.normalise_coords(T(i["coords"], d), a["shape"])}
+    if op == 'get_flow_endpoints':
+        x, y = ofl.get_flow_endpoints(T(i["flow"], d), a["ref"])
+        return {"x": x, "y": y}
+    if op == 'threshold_vectors':
+        return {"out": ofl.threshold_vectors(T(i["flow"], d))}
+    if op == 'is_zero_flow':
+        return {"out": ofl.is_zero_flow(T(i["flow"], d), a["thresholded"])}
+    if op == 'apply_flow':
+        tgt = T(i["target"], d)
+        out = ofl.apply_flow(T(i["flow"], d), tgt, a["ref"], T(i.get("mask"), d))
+        return {"out": out, "_same": out is tgt}
+    if op == 'grid_from_unstructured_data':
+        data, den = ofl.grid_from_unstructured_data(T(i["x"], d), T(i["y"], d), T(i["data"], d), T(i.get("mask"), d))
+        return {"data": data, "density": den}
+    if op == 'apply_s_flow':
+        data, m = ofl.apply_s_flow(T(i["flow"], d), T(i["data"], d), T(i.get("mask"), d), a["occlude_zero_flow"])
+        return {"data": data, "mask": m}
+    if op == 'Flow.apply':
+        fl = _flow(i, "f", "m", a["ref"], d)
+        kw = dict(a["kwargs"])
+        if "tf" in i:
+            out = fl.apply(Flow(T(i["tf"], d), a["target_ref"], T(i["tm"], d)), **kw)
+            return {"vecs": out.vecs, "mask": out.mask, "_ref": out.ref}
+        if "target_mask" in i:
+            kw["target_mask"] = T(i["target_mask"], d)
+        out = fl.apply(T(i["target"], d), **kw)
+        return {"warped": out[0], "valid": out[1]} if isinstance(out, tuple) else {"warped": out}
+    if op in ('Flow.switch_ref', 'Flow.invert', 'Flow.is_zero', 'Flow.valid_target', 'Flow.valid_source'):
+        fl = _flow(i, "f", "m", a["ref"], d)
+        if op == 'Flow.switch_ref':
+            out = fl.switch_ref(a.get("mode"))
+        elif op == 'Flow.invert':
+            out = fl.invert(a["arg_ref"])
+        elif op == 'Flow.is_zero':
+            return {"out": fl.is_zero(a["thresholded"], a["masked"])}
+        elif op == 'Flow.valid_target':
+            return {"out": fl.valid_target(a["consider_mask"])}
+        else:
+            return {"out": fl.valid_source(a["consider_mask"])}
+        return {"vecs": out.vecs, "mask": out.mask, "_ref": out.ref}
+    if op == 'Flow.combine_with':
+        f1, f2 = _flow(i, "f1", "m1", a["ref"], d), _flow(i, "f2", "m2", a["ref"], d)
+        out = f1.combine_with(f2, a["mode"], a.get("thresholded"))
+        ret = "flow" if out is f2 else ("self" if out is f1 else "new")
+        return {"vecs": out.vecs, "mask": out.mask, "_ref": out.ref, "_returns": ret}
+    if op == 'combine_flows':
+        mk = (lambda x: np.asarray(x)) if a.get("numpy") else (lambda x: T(x, d))
+        return {"vecs": ofl.combine_flows(mk(i["f1"]), mk(i["f2"]), a["mode"], a["ref"])}
+    if op == 'switch_flow_ref':
+        return {"vecs": ofl.switch_flow_ref(T(i["f"], d), a["ref"])}
+    if op == 'invert_flow':
+        return {"vecs": ofl.invert_flow(T(i["f"], d), a["ref"], a["out_ref"])}
+    if op.startswith('Flow.') and op[5:] in ('add', 'sub', 'neg', 'mul'):
+        f1 = _flow(i, "f1", "m1", a["ref"], d)
+        if op == 'Flow.neg':
+            out = -f1
+        elif op == 'Flow.mul':
+            out = f1 * a["scalar"]
+        else:
+            other = T(i["f2"], d) if a.get("tensor") else _flow(i, "f2", "m2", a["ref"], d)
+            out = f1 + other if op == 'Flow.add' else f1 - other
+        return {"vecs": out.vecs, "mask": out.mask}
+    if op == 'kat_gfud':
+        v = codec.decode_affine(i["flow__params"], i["flow__delta"], i["flow__esc"])
+        vecs = T(np.stack([v, v]), d)                      # the reference test batches two copies
+        x, y = ofl.get_flow_endpoints(vecs, 's')
+        data, den = ofl.grid_from_unstructured_data(x, y, vecs)
+        return {"_data": data, "_density": den}
+    if op == 'kat_cfg1':
+        fields = _cfg1_fields(golden, d)
+        if a["call"] == 'apply':
+            w, m = fields[a["flow"]].apply(fields["img"], return_valid_area=True)
+            return {"_vec": w, "_mask": m}
+        if a["call"] == 'switch_ref':
+            out = fields[a["flow"]].switch_ref()
+        else:
+            out = fields[a["self"]].combine_with(fields[a["flow"]], a["mode"])
+        return {"_vec": out.vecs, "_mask": out.mask}
+    raise KeyError(op)
+
+
+def _np(v):
+    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+def check_case(case, golden, got, exact_values=True, rtol=0.0, atol=0.0, max_mask_flips=0):
+    """Compare `got` (from run_case) with the reference's outputs.  Masks / bools must match bit for bit
+    (up to `max_mask_flips`, only ever > 0 for the atomics-ordered GPU splat); floats exactly or within tol."""
+    _, exp = golden.arrays(case)
+    a, op = case["args"], case["op"]
+    report = {}
+    if op == 'kat_gfud':
+        den, data = _np(got["_density"]), _np(got["_data"])
+        cnt = int(np.count_nonzero(den > 0.95))
+        assert abs(cnt - a["count_batch_of_two"]) <= 2 * max_mask_flips, (cnt, a["count_batch_of_two"])
+        m = np.unpackbits(exp["density_gt_095_packed"])[:den[0].size].reshape(den[0].shape).astype(bool)
+        assert np.count_nonzero((den[0] > 0.95) != m) <= max_mask_flips
+        _cmp(codec.subsample(data[:1], 4), exp["data_sub4"], exact_values, rtol, atol, "data")
+        _cmp(codec.subsample(den[:1], 4), exp["density_sub4"], exact_values, rtol, atol, "density")
+        return report
+    if op == 'kat_cfg1':
+        mask, vec = _np(got["_mask"]), _np(got["_vec"])
+        m = np.unpackbits(exp["mask_packed"])[:mask.size].reshape(mask.shape).astype(bool)
+        flips = int(np.count_nonzero(mask != m))
+        assert flips <= max_mask_flips, "mask flips %d" % flips
+        if max_mask_flips == 0:
+            assert int(mask.sum()) == a["mask_count"]
+        _cmp(codec.subsample(vec, 4), exp["sub4"], exact_values, rtol, atol, "vec")
+        s = float(vec.astype(np.float64).sum())
+        assert abs(s - a["sum"]) <= 1e-6 * max(a["abs_sum"], 1.0), (s, a["sum"])
+        return report
+    for k, e in exp.items():
+        g = _np(got[k])
+        assert g.shape == e.shape, "%s: shape %s != %s" % (k, g.shape, e.shape)
+        assert g.dtype == e.dtype, "%s: dtype %s != %s" % (k, g.dtype, e.dtype)
+        if e.dtype == np.bool_:
+            flips = int(np.count_nonzero(g != e))
+            assert flips <= max_mask_flips, "%s: %d mask bits differ" % (k, flips)
+        else:
+            _cmp(g, e, exact_values, rtol, atol, k)
+    if "out_ref" in a and "_ref" in got and op != 'invert_flow':
+        assert got["_ref"] == a["out_ref"]
+    if "returns" in a and "_returns" in got:
+        assert got["_returns"] == a["returns"], (got["_returns"], a["returns"])
+    if "same_object" in a:
+        assert got["_same"] == a["same_object"]
+    return report
+
+
+def _cmp(g, e, exact, rtol, atol, name):
+    if exact:
+        if g.dtype.kind == 'f':
+            bad = ~((g == e) | (np.isnan(g) & np.isnan(e)))
+        else:
+            bad = g != e
+        n = int(np.count_nonzero(bad))
+        if n:
+            idx = np.argwhere(bad)[0]
+            raise AssertionError("%s: %d of %d values differ, first at %s: got %r expected %r"
+                                 % (name, n, g.size, tuple(idx), g[tuple(idx)], e[tuple(idx)]))
+    else:
+        np.testing.assert_allclose(g, e, rtol=rtol, atol=atol, err_msg=name)

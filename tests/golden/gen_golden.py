@@ -1,0 +1,549 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE (oflibpytorch v2.1.1,
+/root/reference, PyTorch CPU) on small deterministic inputs.
+
+Runs only in the build container (where /root/reference exists).  Nothing of the reference
+travels: the fixtures hold inputs and expected outputs only.  `cv2` is not installed and nothing
+on the hot path calls it, so an empty stub module stands in for the import.
+
+    python tests/golden/gen_golden.py
+
+writes  tests/golden/{prims,flow_apply,flow_ops,kats}.npz  and  tests/golden/manifest.json.
+Each case is  {"id", "op", "args" (json), "in": {name: key}, "out": {name: key}}  where key names an
+array in the group's npz (content-addressed, so inputs shared between cases are stored once).
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+sys.path.insert(0, '/root/reference/src')
+sys.path.insert(0, HERE)
+import codec  # noqa: E402
+import oflibpytorch as of  # noqa: E402
+from oflibpytorch import utils as ofu  # noqa: E402
+
+Flow = of.Flow
+torch.manual_seed(0)
+
+GROUPS = {}
+MANIFEST = []
+
+
+def rec(group, cid, op, args, inputs, outputs):
+    store = GROUPS.setdefault(group, {})
+    cid = group + "." + cid
+    entry = {"id": cid, "group": group, "op": op, "args": args, "in": {}, "out": {}}
+    for kind, d in (("in", inputs), ("out", outputs)):
+        for k, v in d.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy()
+            v = np.ascontiguousarray(v)
+            key = "a" + hashlib.sha1(v.tobytes() + str((v.dtype, v.shape)).encode()).hexdigest()[:16]
+            store[key] = v              # identical arrays (shared inputs) are stored once
+            entry[kind][k] = key
+    assert cid not in [m["id"] for m in MANIFEST], cid
+    MANIFEST.append(entry)
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ------------------------------------------------------------------------------------------------
+def smooth_flow(n, h, w, sigma, seed, cell=12):
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.randn(n, 2, max(h // cell, 2), max(w // cell, 2), generator=g) * sigma
+    return F.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous()
+
+
+def hole_mask(n, h, w, seed):
+    g = np.random.RandomState(seed)
+    m = np.ones((n, h, w), bool)
+    for i in range(n):
+        y0, x0 = g.randint(0, h - 5), g.randint(0, w - 6)
+        m[i, y0:y0 + g.randint(2, 6), x0:x0 + g.randint(3, 8)] = False
+        m[i, g.randint(0, h - 2):, :g.randint(1, 5)] = False
+    return torch.tensor(m)
+
+
+def image(n, c, h, w, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(n, c, h, w, generator=g) * 255
+    if dtype == torch.uint8:
+        return img.round().to(torch.uint8)
+    return img.to(dtype)
+
+
+H, W = 30, 44          # numerics-heavy cases
+HS, WS = 12, 16        # plumbing cases (broadcasts, ranks, dtypes, kwargs)
+
+
+# ------------------------------------------------------------------------------------------------
+# group: prims  (utils.py functions)
+# ------------------------------------------------------------------------------------------------
+def gen_prims():
+    g = 'prims'
+    coords = (torch.rand(3, 17, 2, generator=torch.Generator().manual_seed(1)) - 0.2) * torch.tensor([W * 1.3, H * 1.3])
+    rec(g, 'norm_coords', 'normalise_coords', {"shape": [H, W]}, {"coords": coords},
+        {"out": ofu.normalise_coords(coords, (H, W))})
+
+    f = smooth_flow(2, H, W, 5.0, 11)
+    for ref in 'st':
+        x, y = ofu.get_flow_endpoints(f, ref)
+        rec(g, 'endpoints_' + ref, 'get_flow_endpoints', {"ref": ref}, {"flow": f}, {"x": x, "y": y})
+
+    ft = f.clone() * 1e-3
+    ft[0, :, :10] = 0
+    ft[1, 0, 5, 5] = 1e-3
+    ft[1, 1, 6, 6] = -1e-3
+    ft[1, 1, 7, 7] = 9.99e-4
+    rec(g, 'threshold', 'threshold_vectors', {}, {"flow": ft}, {"out": ofu.threshold_vectors(ft)})
+    fz = torch.zeros(3, 2, 8, 9)
+    fz[1, 0, 2, 2] = 5e-4
+    fz[2, 1, 3, 3] = 2e-3
+    for th in (True, False):
+        rec(g, 'is_zero_flow_%d' % th, 'is_zero_flow', {"thresholded": th}, {"flow": fz},
+            {"out": ofu.is_zero_flow(fz, th)})
+
+    # apply_flow 't': in-range and out-of-range samples
+    f = smooth_flow(3, H, W, 6.0, 12)
+    f[2] += torch.tensor([25.0, -17.0]).view(2, 1, 1)      # pushes samples out of the image
+    img = image(3, 3, H, W, 21)
+    rec(g, 'apply_t_n3', 'apply_flow', {"ref": "t"}, {"flow": f, "target": img},
+        {"out": ofu.apply_flow(f, img, 't')})
+    # plumbing: broadcasts, 2-D / 3-D targets, H-W-2 flows, dtypes (utils.py:510-537, 602-618)
+    f = smooth_flow(3, HS, WS, 3.0, 12)
+    img = image(3, 3, HS, WS, 21)
+    rec(g, 'apply_t_bcast_target', 'apply_flow', {"ref": "t"}, {"flow": f, "target": img[:1]},
+        {"out": ofu.apply_flow(f, img[:1], 't')})
+    rec(g, 'apply_t_bcast_flow', 'apply_flow', {"ref": "t"}, {"flow": f[:1], "target": img},
+        {"out": ofu.apply_flow(f[:1], img, 't')})
+    rec(g, 'apply_t_2d', 'apply_flow', {"ref": "t"}, {"flow": f[0], "target": img[0, 0]},
+        {"out": ofu.apply_flow(f[0], img[0, 0], 't')})
+    rec(g, 'apply_t_2d_n3', 'apply_flow', {"ref": "t"}, {"flow": f, "target": img[0, 0]},
+        {"out": ofu.apply_flow(f, img[0, 0], 't')})
+    rec(g, 'apply_t_3d', 'apply_flow', {"ref": "t"}, {"flow": f[1], "target": img[1]},
+        {"out": ofu.apply_flow(f[1], img[1], 't')})
+    rec(g, 'apply_t_hw2', 'apply_flow', {"ref": "t"}, {"flow": f[1].permute(1, 2, 0).contiguous(), "target": img[1]},
+        {"out": ofu.apply_flow(f[1].permute(1, 2, 0).contiguous(), img[1], 't')})
+    u8 = image(3, 3, HS, WS, 22, torch.uint8)
+    rec(g, 'apply_t_u8', 'apply_flow', {"ref": "t"}, {"flow": f, "target": u8},
+        {"out": ofu.apply_flow(f, u8, 't')})
+    i32 = (image(3, 1, HS, WS, 23) * 3 - 300).round().to(torch.int32)
+    rec(g, 'apply_t_i32', 'apply_flow', {"ref": "t"}, {"flow": f, "target": i32},
+        {"out": ofu.apply_flow(f, i32, 't')})
+    f64 = image(2, 2, HS, WS, 24).double()
+    rec(g, 'apply_t_f64', 'apply_flow', {"ref": "t"}, {"flow": f[:2], "target": f64},
+        {"out": ofu.apply_flow(f[:2], f64, 't')})
+    f = smooth_flow(3, H, W, 6.0, 12)
+    img = image(3, 3, H, W, 21)
+    # integer translation (exact shift; test_flow_class.py:1080-1091 pins equality)
+    tr = torch.zeros(2, 2, H, W)
+    tr[0, 0], tr[0, 1] = 10, -7
+    tr[1, 0], tr[1, 1] = -3, 4
+    rec(g, 'apply_t_translation', 'apply_flow', {"ref": "t"}, {"flow": tr, "target": img[:2]},
+        {"out": ofu.apply_flow(tr, img[:2], 't')})
+    rec(g, 'apply_s_translation', 'apply_flow', {"ref": "s"}, {"flow": tr, "target": img[:2]},
+        {"out": ofu.apply_flow(tr, img[:2], 's')})
+    # early exit: every |v| < 1e-3 -> the target object itself is returned (utils.py:497-498)
+    tiny = torch.full((1, 2, H, W), 5e-4)
+    out = ofu.apply_flow(tiny, img[:1], 't')
+    rec(g, 'apply_t_tiny', 'apply_flow', {"ref": "t", "same_object": bool(out is img[:1]) or out.data_ptr() == img.data_ptr()},
+        {"flow": tiny, "target": img[:1]}, {"out": out})
+    # exactly at threshold: 1e-3 is NOT below threshold -> warps
+    edge = torch.full((1, 2, H, W), 1e-3)
+    rec(g, 'apply_t_thr_edge', 'apply_flow', {"ref": "t"}, {"flow": edge, "target": img[:1]},
+        {"out": ofu.apply_flow(edge, img[:1], 't')})
+    # zero flow on a non-square odd size: goes through the early exit
+    # unit-size corner cases: W == 2, H == 2
+    f22 = torch.tensor([[[[0.3, -0.4], [0.6, 0.2]], [[-0.2, 0.5], [0.1, -0.7]]]])
+    t22 = torch.tensor([[[[1.0, 2.0], [3.0, 4.0]]]])
+    rec(g, 'apply_t_2x2', 'apply_flow', {"ref": "t"}, {"flow": f22, "target": t22},
+        {"out": ofu.apply_flow(f22, t22, 't')})
+    rec(g, 'apply_s_2x2', 'apply_flow', {"ref": "s"}, {"flow": f22, "target": t22},
+        {"out": ofu.apply_flow(f22, t22, 's')})
+
+    # apply_flow 's' with / without mask, broadcasts
+    fs = smooth_flow(3, H, W, 4.0, 13)
+    fs[0, :, 10:20, 10:30] = 0                 # zero-flow block (occlusion rule)
+    fs[1, :, :, :8] = 2e-4                     # below threshold counts as zero
+    m = hole_mask(3, H, W, 5)
+    rec(g, 'apply_s_n3', 'apply_flow', {"ref": "s"}, {"flow": fs, "target": img},
+        {"out": ofu.apply_flow(fs, img, 's')})
+    rec(g, 'apply_s_n3_mask', 'apply_flow', {"ref": "s"}, {"flow": fs, "target": img, "mask": m},
+        {"out": ofu.apply_flow(fs, img, 's', m)})
+    fss = smooth_flow(3, HS, WS, 2.5, 14)
+    fss[0, :, 3:7, 4:10] = 0
+    ms, imgs = hole_mask(3, HS, WS, 6), image(3, 3, HS, WS, 21)
+    rec(g, 'apply_s_bcast_flow', 'apply_flow', {"ref": "s"}, {"flow": fss[:1], "target": imgs, "mask": ms[:1]},
+        {"out": ofu.apply_flow(fss[:1], imgs, 's', ms[:1])})
+    rec(g, 'apply_s_bcast_target', 'apply_flow', {"ref": "s"}, {"flow": fss, "target": imgs[1:2], "mask": ms},
+        {"out": ofu.apply_flow(fss, imgs[1:2], 's', ms)})
+    rec(g, 'apply_s_u8', 'apply_flow', {"ref": "s"}, {"flow": fss, "target": u8, "mask": ms},
+        {"out": ofu.apply_flow(fss, u8, 's', ms)})
+    rec(g, 'apply_s_2d', 'apply_flow', {"ref": "s"}, {"flow": fss[0], "target": imgs[0, 0], "mask": ms[0]},
+        {"out": ofu.apply_flow(fss[0], imgs[0, 0], 's', ms[0])})
+
+    # grid_from_unstructured_data on arbitrary positions (some outside the image)
+    gen = torch.Generator().manual_seed(31)
+    x = torch.rand(2, H, W, generator=gen) * (W + 6) - 3
+    y = torch.rand(2, H, W, generator=gen) * (H + 6) - 3
+    x[0, 0, :5] = torch.tensor([0.0, W - 1.0, -1.0, W + 0.0, 3.0])      # exact-integer / edge positions
+    y[0, 0, :5] = torch.tensor([0.0, H - 1.0, 2.0, 5.0, -1.0])
+    d = image(2, 3, H, W, 32)
+    gd, den = ofu.grid_from_unstructured_data(x, y, d)
+    rec(g, 'gfud_random', 'grid_from_unstructured_data', {}, {"x": x, "y": y, "data": d}, {"data": gd, "density": den})
+    gd, den = ofu.grid_from_unstructured_data(x, y, d, m[:2])
+    rec(g, 'gfud_random_mask', 'grid_from_unstructured_data', {}, {"x": x, "y": y, "data": d, "mask": m[:2]},
+        {"data": gd, "density": den})
+    xs, ys = ofu.get_flow_endpoints(fs, 's')
+    gd, den = ofu.grid_from_unstructured_data(xs, ys, fs)
+    rec(g, 'gfud_flow', 'grid_from_unstructured_data', {}, {"x": xs, "y": ys, "data": fs}, {"data": gd, "density": den})
+
+    # apply_s_flow
+    for occ in (True, False):
+        wd, wm = ofu.apply_s_flow(fs, img, m, occ)
+        rec(g, 'apply_s_flow_occ%d' % occ, 'apply_s_flow', {"occlude_zero_flow": occ},
+            {"flow": fs, "data": img, "mask": m}, {"data": wd, "mask": wm})
+    wd, wm = ofu.apply_s_flow(fs, img)
+    rec(g, 'apply_s_flow_nomask', 'apply_s_flow', {"occlude_zero_flow": None}, {"flow": fs, "data": img},
+        {"data": wd, "mask": wm})
+
+
+# ------------------------------------------------------------------------------------------------
+# group: flow_apply  (Flow.apply, flow_class.py:755-959)
+# ------------------------------------------------------------------------------------------------
+def flow_inputs(fl):
+    return {"f": fl.vecs, "m": fl.mask}
+
+
+def _flow_apply_cases(g, ref, h, w, tag, names):
+    img = image(3, 3, h, w, 41)
+    u8 = image(3, 3, h, w, 42, torch.uint8)
+    tmask = hole_mask(3, h, w, 9)
+    f = smooth_flow(3, h, w, 5.0 if h > 20 else 2.5, 50 + ord(ref))
+    f[1, :, h // 6:h // 2, w // 3:w - 4] = 0
+    f[2] += torch.tensor([0.27 * w, 0.3 * h]).view(2, 1, 1)
+    m = hole_mask(3, h, w, 7)
+    fl = Flow(f, ref, m)
+    fl_nomask = Flow(f, ref)
+    # tensor target, kwargs combinations (flow_class.py:821-959)
+    for name, flow, kw, tgt in [
+        ('plain', fl, {}, img),
+        ('valid', fl, {"return_valid_area": True}, img),
+        ('valid_tmask', fl, {"return_valid_area": True, "target_mask": tmask}, img),
+        ('valid_tmask_nocons', fl, {"return_valid_area": True, "target_mask": tmask, "consider_mask": False}, img),
+        ('nocons', fl, {"consider_mask": False}, img),
+        ('nomask_valid', fl_nomask, {"return_valid_area": True}, img),
+        ('u8_valid', fl, {"return_valid_area": True}, u8),
+        ('u8_plain', fl, {}, u8),
+        ('bcast_target', fl, {"return_valid_area": True, "target_mask": tmask[:1]}, img[:1]),
+        ('bcast_flow', Flow(f[1:2], ref, m[1:2]), {"return_valid_area": True, "target_mask": tmask}, img),
+        ('t3d', Flow(f[0], ref, m[0]), {"return_valid_area": True, "target_mask": tmask[0]}, img[0]),
+        ('t2d', Flow(f[0], ref, m[0]), {"return_valid_area": True}, img[0, 0]),
+        ('t2d_n3', fl, {"return_valid_area": True}, img[0, 0]),
+        ('t3d_n3', fl, {}, img[0]),
+    ]:
+        if name not in names:
+            continue
+        kwj = {k: v for k, v in kw.items() if k != "target_mask"}
+        tm = kw.get("target_mask")
+        tm_in = None if tm is None else tm.clone()
+        out = flow.apply(tgt, **{**kwj, **({"target_mask": tm_in} if tm is not None else {})})
+        outs = {"warped": out[0], "valid": out[1]} if isinstance(out, tuple) else {"warped": out}
+        rec(g, 'apply_%s_%s%s' % (ref, name, tag), 'Flow.apply', {"ref": ref, "kwargs": kwj},
+            {**flow_inputs(flow), "target": tgt, "target_mask": tm}, outs)
+    # Flow target (flow_class.py:839-842, 938)
+    if 'flowtarget' in names:
+        tf = Flow(smooth_flow(3, h, w, 3.0, 77), 't' if ref == 's' else 's', hole_mask(3, h, w, 13))
+        out = fl.apply(tf)
+        rec(g, 'apply_%s_flowtarget%s' % (ref, tag), 'Flow.apply',
+            {"ref": ref, "kwargs": {}, "target_ref": tf.ref, "out_ref": out.ref},
+            {**flow_inputs(fl), "tf": tf.vecs, "tm": tf.mask}, {"vecs": out.vecs, "mask": out.mask})
+    if 'flowtarget_bcast' in names:
+        tf = Flow(smooth_flow(3, h, w, 3.0, 77), 't' if ref == 's' else 's', hole_mask(3, h, w, 13))
+        out = Flow(f[:1], ref, m[:1]).apply(tf)
+        rec(g, 'apply_%s_flowtarget_bcast%s' % (ref, tag), 'Flow.apply',
+            {"ref": ref, "kwargs": {}, "target_ref": tf.ref, "out_ref": out.ref},
+            {"f": f[:1], "m": m[:1], "tf": tf.vecs, "tm": tf.mask}, {"vecs": out.vecs, "mask": out.mask})
+    # padding: flow smaller than target (flow_class.py:830-834, 880-893, 906-934)
+    if 'pad' in names:
+        pad = [3, 5, 4, 2]
+        hf, wf = h - pad[0] - pad[1], w - pad[2] - pad[3]
+        fp = smooth_flow(2, hf, wf, 4.0, 60 + ord(ref))
+        mp = hole_mask(2, hf, wf, 17)
+        flp = Flow(fp, ref, mp)
+        for cut in (True, False):
+            tmc = tmask[:2].clone()
+            out = flp.apply(img[:2], target_mask=tmc, return_valid_area=True, padding=pad, cut=cut)
+            rec(g, 'apply_%s_pad_cut%d%s' % (ref, cut, tag), 'Flow.apply',
+                {"ref": ref, "kwargs": {"return_valid_area": True, "padding": pad, "cut": cut}},
+                {"f": fp, "m": mp, "target": img[:2], "target_mask": tmask[:2]}, {"warped": out[0], "valid": out[1]})
+            out = flp.apply(img[:2], padding=pad, cut=cut)
+            rec(g, 'apply_%s_pad_plain_cut%d%s' % (ref, cut, tag), 'Flow.apply',
+                {"ref": ref, "kwargs": {"padding": pad, "cut": cut}},
+                {"f": fp, "m": mp, "target": img[:2]}, {"warped": out})
+        tfl = Flow(smooth_flow(2, h, w, 3.0, 78), ref, hole_mask(2, h, w, 14))
+        out = flp.apply(tfl, padding=pad, cut=False)
+        rec(g, 'apply_%s_pad_flowtarget%s' % (ref, tag), 'Flow.apply',
+            {"ref": ref, "kwargs": {"padding": pad, "cut": False}, "target_ref": ref, "out_ref": out.ref},
+            {"f": fp, "m": mp, "tf": tfl.vecs, "tm": tfl.mask}, {"vecs": out.vecs, "mask": out.mask})
+    # zero flow: early exit path inside apply_flow (utils.py:497-498)
+    if 'zero' in names:
+        z = Flow(torch.zeros(2, 2, h, w), ref, m[:2])
+        out = z.apply(img[:2], target_mask=tmask[:2].clone(), return_valid_area=True)
+        rec(g, 'apply_%s_zero%s' % (ref, tag), 'Flow.apply', {"ref": ref, "kwargs": {"return_valid_area": True}},
+            {"f": z.vecs, "m": z.mask, "target": img[:2], "target_mask": tmask[:2]}, {"warped": out[0], "valid": out[1]})
+
+
+def gen_flow_apply():
+    g = 'flow_apply'
+    every = ['plain', 'valid', 'valid_tmask', 'valid_tmask_nocons', 'nocons', 'nomask_valid', 'u8_valid', 'u8_plain',
+             'bcast_target', 'bcast_flow', 't3d', 't2d', 't2d_n3', 't3d_n3', 'flowtarget', 'flowtarget_bcast', 'zero']
+    for ref in 'st':
+        _flow_apply_cases(g, ref, H, W, '', ['valid_tmask', 'valid_tmask_nocons', 'flowtarget', 'pad'])
+        _flow_apply_cases(g, ref, HS, WS, '_small', every)
+
+
+# ------------------------------------------------------------------------------------------------
+# group: flow_ops  (switch_ref, invert, combine_with, wrappers, arithmetic)
+# ------------------------------------------------------------------------------------------------
+def _flow_ops_cases(g, ref, h, w, tag, numerics, plumbing):
+    f = smooth_flow(2, h, w, 4.0 if h > 20 else 2.0, 80 + ord(ref))
+    f[1, :, h // 4:h // 2, w // 4:w // 2] = 0
+    m = hole_mask(2, h, w, 19)
+    fl = Flow(f, ref, m)
+    f2 = smooth_flow(2, h, w, 3.0 if h > 20 else 1.5, 90 + ord(ref))
+    m2 = hole_mask(2, h, w, 23)
+    fl2 = Flow(f2, ref, m2)
+    if numerics:
+        out = fl.switch_ref()
+        rec(g, 'switch_ref_' + ref + tag, 'Flow.switch_ref', {"ref": ref, "out_ref": out.ref}, flow_inputs(fl),
+            {"vecs": out.vecs, "mask": out.mask})
+        for oref in ('s', 't', None):
+            out = fl.invert(oref)
+            rec(g, 'invert_%s_%s%s' % (ref, oref, tag), 'Flow.invert', {"ref": ref, "arg_ref": oref, "out_ref": out.ref},
+                flow_inputs(fl), {"vecs": out.vecs, "mask": out.mask})
+        for mode in (1, 2, 3):
+            out = fl.combine_with(fl2, mode)
+            rec(g, 'combine_%s_mode%d%s' % (ref, mode, tag), 'Flow.combine_with',
+                {"ref": ref, "mode": mode, "out_ref": out.ref},
+                {"f1": f, "m1": m, "f2": f2, "m2": m2}, {"vecs": out.vecs, "mask": out.mask})
+            out = of.combine_flows(f, f2, mode, ref)
+            rec(g, 'combine_flows_%s_mode%d%s' % (ref, mode, tag), 'combine_flows', {"ref": ref, "mode": mode},
+                {"f1": f, "f2": f2}, {"vecs": out})
+        for cm in (True, False):
+            rec(g, 'valid_target_%s_%d%s' % (ref, cm, tag), 'Flow.valid_target', {"ref": ref, "consider_mask": cm},
+                flow_inputs(fl), {"out": fl.valid_target(cm)})
+            rec(g, 'valid_source_%s_%d%s' % (ref, cm, tag), 'Flow.valid_source', {"ref": ref, "consider_mask": cm},
+                flow_inputs(fl), {"out": fl.valid_source(cm)})
+    if not plumbing:
+        return
+    out = fl.switch_ref('invalid')
+    rec(g, 'switch_ref_invalid_' + ref + tag, 'Flow.switch_ref', {"ref": ref, "mode": "invalid", "out_ref": out.ref},
+        flow_inputs(fl), {"vecs": out.vecs, "mask": out.mask})
+    for th, ma in [(None, None), (False, True), (True, False), (False, False)]:
+        rec(g, 'is_zero_%s_%s_%s%s' % (ref, th, ma, tag), 'Flow.is_zero', {"ref": ref, "thresholded": th, "masked": ma},
+            flow_inputs(fl), {"out": fl.is_zero(th, ma)})
+    out = of.combine_flows(f[0], f2[0], 3, ref)
+    rec(g, 'combine_flows_%s_3d%s' % (ref, tag), 'combine_flows', {"ref": ref, "mode": 3}, {"f1": f[0], "f2": f2[0]},
+        {"vecs": out})
+    a1, a2 = f[0].permute(1, 2, 0).numpy().copy(), f2[0].permute(1, 2, 0).numpy().copy()
+    out = of.combine_flows(a1, a2, 3, ref)
+    rec(g, 'combine_flows_%s_hw2_numpy%s' % (ref, tag), 'combine_flows', {"ref": ref, "mode": 3, "numpy": True},
+        {"f1": a1, "f2": a2}, {"vecs": out})
+    # early exits of combine_with (flow_class.py:1729-1744)
+    zero = Flow(torch.zeros(2, 2, h, w), ref, m)
+    for mode in (1, 2, 3):
+        out = zero.combine_with(fl2, mode)
+        rec(g, 'combine_%s_selfzero_mode%d%s' % (ref, mode, tag), 'Flow.combine_with',
+            {"ref": ref, "mode": mode, "returns": "flow" if out is fl2 else "new", "out_ref": out.ref},
+            {"f1": zero.vecs, "m1": zero.mask, "f2": f2, "m2": m2}, {"vecs": out.vecs, "mask": out.mask})
+        out = fl.combine_with(zero, mode)
+        rec(g, 'combine_%s_flowzero_mode%d%s' % (ref, mode, tag), 'Flow.combine_with',
+            {"ref": ref, "mode": mode, "returns": "self" if out is fl else "new", "out_ref": out.ref},
+            {"f1": f, "m1": m, "f2": zero.vecs, "m2": zero.mask}, {"vecs": out.vecs, "mask": out.mask})
+    # masked-zero: non-zero vectors only where the mask is False -> is_zero() is True (:1241-1244)
+    fz = torch.zeros(2, 2, h, w)
+    mz = torch.ones(2, h, w, dtype=torch.bool)
+    fz[:, :, :4, :4] = 3.0
+    mz[:, :4, :4] = False
+    flz = Flow(fz, ref, mz)
+    out = flz.combine_with(fl2, 3)
+    rec(g, 'combine_%s_maskedzero%s' % (ref, tag), 'Flow.combine_with',
+        {"ref": ref, "mode": 3, "returns": "flow" if out is fl2 else "new", "out_ref": out.ref},
+        {"f1": fz, "m1": mz, "f2": f2, "m2": m2}, {"vecs": out.vecs, "mask": out.mask})
+    # tiny vectors: thresholded=True takes the early exit, False warps ... through apply_flow's own
+    # thresholded early exit (utils.py:497), i.e. G is the identity
+    tiny = Flow(torch.full((2, 2, h, w), 4e-4), ref, m)
+    for th in (False, True):
+        out = tiny.combine_with(fl2, 3, thresholded=th)
+        rec(g, 'combine_%s_tiny_th%d%s' % (ref, th, tag), 'Flow.combine_with',
+            {"ref": ref, "mode": 3, "thresholded": th, "returns": "flow" if out is fl2 else "new", "out_ref": out.ref},
+            {"f1": tiny.vecs, "m1": tiny.mask, "f2": f2, "m2": m2}, {"vecs": out.vecs, "mask": out.mask})
+        out = fl2.combine_with(tiny, 3, thresholded=th)
+        rec(g, 'combine_%s_tiny2_th%d%s' % (ref, th, tag), 'Flow.combine_with',
+            {"ref": ref, "mode": 3, "thresholded": th, "returns": "self" if out is fl2 else "new", "out_ref": out.ref},
+            {"f1": f2, "m1": m2, "f2": tiny.vecs, "m2": tiny.mask}, {"vecs": out.vecs, "mask": out.mask})
+    # wrappers (flow_operations.py:191-228)
+    out = of.switch_flow_ref(f, ref)
+    rec(g, 'switch_flow_ref_' + ref + tag, 'switch_flow_ref', {"ref": ref}, {"f": f}, {"vecs": out})
+    out = of.switch_flow_ref(f[0], ref)
+    rec(g, 'switch_flow_ref_3d_' + ref + tag, 'switch_flow_ref', {"ref": ref}, {"f": f[0]}, {"vecs": out})
+    for oref in ('s', 't', None):
+        out = of.invert_flow(f, ref, oref)
+        rec(g, 'invert_flow_%s_%s%s' % (ref, oref, tag), 'invert_flow', {"ref": ref, "out_ref": oref}, {"f": f}, {"vecs": out})
+    # arithmetic (flow_class.py:450-549, 680-692)
+    out = fl + fl2
+    rec(g, 'add_' + ref + tag, 'Flow.add', {"ref": ref}, {"f1": f, "m1": m, "f2": f2, "m2": m2}, {"vecs": out.vecs, "mask": out.mask})
+    out = fl - fl2
+    rec(g, 'sub_' + ref + tag, 'Flow.sub', {"ref": ref}, {"f1": f, "m1": m, "f2": f2, "m2": m2}, {"vecs": out.vecs, "mask": out.mask})
+    out = fl + f2
+    rec(g, 'add_tensor_' + ref + tag, 'Flow.add', {"ref": ref, "tensor": True}, {"f1": f, "m1": m, "f2": f2}, {"vecs": out.vecs, "mask": out.mask})
+    rec(g, 'add_bcast_' + ref + tag, 'Flow.add', {"ref": ref}, {"f1": f, "m1": m, "f2": f2[:1], "m2": m2[:1]},
+        {"vecs": (fl + Flow(f2[:1], ref, m2[:1])).vecs, "mask": (fl + Flow(f2[:1], ref, m2[:1])).mask})
+    out = -fl
+    rec(g, 'neg_' + ref + tag, 'Flow.neg', {"ref": ref}, {"f1": f, "m1": m}, {"vecs": out.vecs, "mask": out.mask})
+    out = fl * 2.5
+    rec(g, 'mul_' + ref + tag, 'Flow.mul', {"ref": ref, "scalar": 2.5}, {"f1": f, "m1": m}, {"vecs": out.vecs, "mask": out.mask})
+
+
+def gen_flow_ops():
+    g = 'flow_ops'
+    for ref in 'st':
+        _flow_ops_cases(g, ref, H, W, '', True, False)
+        _flow_ops_cases(g, ref, HS, WS, '_small', True, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# group: kats  (the reference's own known-answer tests + BASELINE.md config-1 values)
+# ------------------------------------------------------------------------------------------------
+def _affine_inputs(prefix, vecs):
+    """Encode a 1-2-H-W affine flow field compactly and exactly (tests/golden/codec.py)."""
+    params, delta, esc = codec.encode_affine(vecs[0].numpy())
+    return {prefix + "__params": params, prefix + "__delta": delta, prefix + "__esc": esc}
+
+
+def _summary(t):
+    """Compact expectation for a big fp32 output: exact values on a stride-4 lattice + float64 sums."""
+    a = t.detach().numpy()
+    return {"sub4": codec.subsample(a, 4)}, {"sum": float(a.astype(np.float64).sum()),
+                                             "abs_sum": float(np.abs(a.astype(np.float64)).sum())}
+
+
+def gen_kats():
+    g = 'kats'
+    # --- test_utils.py:1104-1120 TestGridFromUnstructuredData: count_nonzero(density > 0.95) == 24664 for a
+    #     batch of two identical 100x150 rotation flows (stored once: 12332 per batch element)
+    flow = Flow.from_transforms([['rotation', 50, 75, -20]], (100, 150), ref='s')
+    flow2 = of.batch_flows((flow, flow))
+    x, y = ofu.get_flow_endpoints(flow2.vecs, 's')
+    data, den = ofu.grid_from_unstructured_data(x, y, flow2.vecs)
+    cnt = int(np.count_nonzero(den.numpy() > 0.95))
+    assert cnt == 24664, cnt
+    assert torch.equal(data[0], data[1]) and torch.equal(den[0], den[1])
+    sub_d, sums_d = _summary(data[:1])
+    sub_n, sums_n = _summary(den[:1])
+    rec(g, 'gfud_rotation', 'kat_gfud', {"transforms": [['rotation', 50, 75, -20]], "shape": [100, 150],
+                                         "count_batch_of_two": cnt, "data": sums_d, "density": sums_n},
+        _affine_inputs("flow", flow.vecs),
+        {"density_gt_095_packed": np.packbits(den[0].numpy() > 0.95), "data_sub4": sub_d["sub4"],
+         "density_sub4": sub_n["sub4"]})
+
+    # --- test_flow_class.py:1389-1617 valid_target / valid_source 7x7 boolean KATs (pure-pytorch variants).
+    #     Expected arrays are produced by the reference here; the literal `desired_area_s_pp` of the reference's
+    #     test is asserted against as a cross-check.
+    transforms = [['rotation', 0, 0, 45]]
+    shape = (7, 7)
+    mask_s = np.ones(shape, 'bool'); mask_s[4:, :3] = False
+    mask_t = np.ones(shape, 'bool'); mask_t[:3, 4:] = False
+    f_s_m = Flow.from_transforms(transforms, shape, 's', mask_s)
+    f_t_m = Flow.from_transforms(transforms, shape, 't', mask_t)
+    f_s = Flow.from_transforms(transforms, shape, 's')
+    f_t = Flow.from_transforms(transforms, shape, 't')
+    desired_area_s_pp = np.array([
+        [1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1, 1], [0, 0, 1, 1, 1, 1, 1],
+        [0, 0, 0, 1, 1, 1, 0], [0, 0, 0, 0, 1, 1, 0], [0, 0, 0, 0, 0, 0, 0]]).astype('bool')
+    assert np.array_equal(f_s.valid_target()[0].numpy(), desired_area_s_pp)
+    for name, fl in (('s', f_s), ('t', f_t), ('s_masked', f_s_m), ('t_masked', f_t_m)):
+        for cm in (True, False):
+            rec(g, 'valid_target_%s_%d' % (name, cm), 'Flow.valid_target', {"ref": fl.ref, "consider_mask": cm},
+                flow_inputs(fl), {"out": fl.valid_target(cm)})
+            rec(g, 'valid_source_%s_%d' % (name, cm), 'Flow.valid_source', {"ref": fl.ref, "consider_mask": cm},
+                flow_inputs(fl), {"out": fl.valid_source(cm)})
+
+    # --- BASELINE.md / SURVEY.md 8(c): config-1 values on smudge.png[:300, :400] (BGR, C-H-W)
+    from PIL import Image
+    img = np.array(Image.open('/root/reference/test/smudge.png'))[..., ::-1]   # == cv2.imread (BGR)
+    img = np.ascontiguousarray(np.moveaxis(img[:300, :400], -1, 0))           # 3-300-400 uint8
+    timg = torch.tensor(img).float()
+    assert float(timg.sum()) == 43891908.0
+    fields = {
+        "rot_t": Flow.from_transforms([['rotation', 200, 150, -30]], (300, 400), 't'),
+        "rot_s": Flow.from_transforms([['rotation', 200, 150, -30]], (300, 400), 's'),
+        "sc_t": Flow.from_transforms([['scaling', 100, 50, 0.7]], (300, 400), 't'),
+        "sc_s": Flow.from_transforms([['scaling', 100, 50, 0.7]], (300, 400), 's'),
+        "tr_t": Flow.from_transforms([['translation', 40, 0]], (300, 400), 't'),
+    }
+    inputs = {"img_u8": img}
+    for k, fl in fields.items():
+        inputs.update(_affine_inputs(k, fl.vecs))
+    rec(g, 'cfg1_inputs', 'kat_inputs', {"fields": sorted(fields)}, inputs, {})
+
+    def kat(cid, call, ref, vec_t, mask_t, extra):
+        sub, sums = _summary(vec_t)
+        rec(g, cid, 'kat_cfg1', {"call": call, "ref": ref, "mask_count": int(mask_t.sum()), **sums, **extra}, {},
+            {"mask_packed": np.packbits(mask_t.numpy()), "sub4": sub["sub4"]})
+
+    wt, mt = fields["rot_t"].apply(timg, return_valid_area=True)
+    ws, ms = fields["rot_s"].apply(timg, return_valid_area=True)
+    assert int(mt.sum()) == 99591 and int(ms.sum()) == 100274
+    assert abs(float(wt.double().sum()) - 36876388.645) < 1 and abs(float(ws.double().sum()) - 37024340.638) < 1
+    kat('cfg1_apply_t', 'apply', 't', wt, mt, {"flow": "rot_t"})
+    kat('cfg1_apply_s', 'apply', 's', ws, ms, {"flow": "rot_s"})
+    counts = {}
+    for ref in 'ts':
+        a, b = fields["rot_" + ref], fields["sc_" + ref]
+        for mode in (1, 2, 3):
+            out = a.combine_with(b, mode)
+            counts["%s%d" % (ref, mode)] = int(out.mask.sum())
+            kat('cfg1_combine_%s_mode%d' % (ref, mode), 'combine_with', ref, out.vecs, out.mask,
+                {"self": "rot_" + ref, "flow": "sc_" + ref, "mode": mode})
+    assert counts == {"t1": 99596, "s1": 118314, "t2": 48627, "s2": 100274, "t3": 58800, "s3": 99591}, counts
+    for ref in 'st':
+        out = fields["rot_" + ref].switch_ref()
+        assert int(out.mask.sum()) == (100274 if ref == 's' else 100273)
+        kat('cfg1_switch_ref_' + ref, 'switch_ref', ref, out.vecs, out.mask, {"flow": "rot_" + ref})
+    # README example: rotation (+) translation[40, 0], mode 3, 't': mask count 108000
+    out = fields["rot_t"].combine_with(fields["tr_t"], 3)
+    mag = float(torch.sqrt((out.vecs ** 2).sum(1)).mean())
+    assert int(out.mask.sum()) == 108000, int(out.mask.sum())
+    kat('cfg1_readme_combine', 'combine_with', 't', out.vecs, out.mask,
+        {"self": "rot_t", "flow": "tr_t", "mode": 3, "mean_mag": mag})
+
+
+def main():
+    of.set_pure_pytorch()
+    gen_prims()
+    gen_flow_apply()
+    gen_flow_ops()
+    gen_kats()
+    for grp, store in GROUPS.items():
+        path = os.path.join(HERE, grp + '.npz')
+        np.savez_compressed(path, **store)
+        print(grp, len(store), 'arrays', os.path.getsize(path) // 1024, 'KiB')
+    with open(os.path.join(HERE, 'manifest.json'), 'w') as fh:
+        json.dump({"reference": "oflibpytorch 2.1.1", "torch": torch.__version__, "cases": MANIFEST}, fh, indent=1)
+    print(len(MANIFEST), 'cases')
+
+
+if __name__ == '__main__':
+    main()
