@@ -94,7 +94,9 @@ int ofl_warp_bwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
  *   wmask   = (weight_mask ? weight_mask[n] : 1) && !zero
  *   accum[n,0]       += w_corner * wmask                              (density)
  *   accum[n,1+c]     += w_corner * wmask * data_sign * data[n,c]
- *   accum[n,1+C]     += w_corner * wmask * (chan_mask_a & chan_mask_b)   (only if with_mask_chan)
+ *   accum[n,1+C]     += w_corner * wmask * !(chan_mask_a & chan_mask_b)  (only if with_mask_chan: the
+ *                       INVALID weight; pass 2 forms density - invalid, which is exactly the density --
+ *                       ratio exactly 1 -- when every contributor is valid, in any accumulation order)
  *
  * accum [N, 1 + C + with_mask_chan, H, W] fp32 workspace, zeroed by the caller.
  * Either `flow` (endpoints computed in-kernel, get_flow_endpoints) or `xs`/`ys` (explicit
@@ -114,11 +116,12 @@ int ofl_splat_fwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
  * Forward splat, pass 2: normalise, masks, un-occlude fill.
  *
  *   den        = accum[n,0];  dcl = max(den, 1e-3f)
- *   dst[n,c]   = accum[n,1+c] / dcl ;  mch = accum[n,1+C] / dcl
+ *   dst[n,c]   = accum[n,1+c] / dcl ;  mch = (den - accum[n,1+C]) / dcl
  *   where (weight_mask & zero & den == 0) [occlude only]:  dst[n,c] = data_sign*data[n,c], mch = chan masks
  *   density[n] = den                      (optional)
  *   warped[n]  = den > 0                  (optional; apply_s_flow's returned mask)
  *   valid[n]   = mch > 0.99999f           (optional; requires with_mask_chan)
+ *   mask_chan[n] = mch                    (optional; requires with_mask_chan; valid_target's `== 1` test)
  *   then `round_mode` on dst.
  */
 int ofl_splat_finalize_f32(const float* accum,
@@ -128,7 +131,7 @@ int ofl_splat_finalize_f32(const float* accum,
                            const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
                            const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
                            int32_t with_mask_chan, int32_t occlude,
-                           float* dst, float* density, uint8_t* warped, uint8_t* valid,
+                           float* dst, float* density, uint8_t* warped, uint8_t* valid, float* mask_chan,
                            int32_t n, int32_t c, int32_t h, int32_t w,
                            int32_t round_mode, void* stream);
 

@@ -47,7 +47,7 @@ def load_library(path: str = None):
                                      i32, i32, i32, i32, i32, p]
     lib.ofl_splat_fwd_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p,
                                       i32, i32, i32, i32, p]
-    lib.ofl_splat_finalize_f32.argtypes = [p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p,
+    lib.ofl_splat_finalize_f32.argtypes = [p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                            i32, i32, i32, i32, i32, p]
     lib.ofl_flow_flags_f32.argtypes = [p, i64, p, i64, f32, p, i32, i32, i32, p]
     for name in _SYMBOLS:
@@ -142,11 +142,12 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
               chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False,
-              round_mode=ROUND_NONE):
+              round_mode=ROUND_NONE, want_mask_chan=False):
     """P-family kernels (ofl_splat_fwd_f32 + ofl_splat_finalize_f32).
 
     Either flow [Nf,2,H,W] (endpoints computed in-kernel) or explicit positions xs, ys [N,H,W].
-    Returns (dst [N,C,H,W], valid | None, density | None, warped | None) on the HIP device.
+    Returns (dst [N,C,H,W], valid | None, density | None, warped | None) on the HIP device; with
+    `want_mask_chan` the valid slot holds the warped mask channel itself (fp32) instead of its threshold.
     """
     lib, dev = load_library(), device()
     c, h, w = data.shape[1:]
@@ -163,7 +164,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     wm, wmbs = (None, 0) if weight_mask is None else _planes(weight_mask, dev, torch.bool, n, "mask")
     ca, cabs = (None, 0) if chan_mask_a is None else _planes(chan_mask_a, dev, torch.bool, n, "mask")
     cb, cbbs = (None, 0) if chan_mask_b is None else _planes(chan_mask_b, dev, torch.bool, n, "mask")
-    mch = 1 if want_valid else 0
+    mch = 1 if (want_valid or want_mask_chan) else 0
     occ = 1 if (occlude and f is not None) else 0
     accum = torch.zeros((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
     st = _stream(dev)
@@ -171,11 +172,12 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
                                  float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
                                  _ptr(accum), n, c, h, w, st), "ofl_splat_fwd_f32")
     dst = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
-    valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
+    valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if (want_valid and not want_mask_chan) else None
+    mchan = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_mask_chan else None
     density = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_density else None
     warped = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_warped else None
     _check(lib.ofl_splat_finalize_f32(_ptr(accum), _ptr(f), fbs, _ptr(d), dbs, float(data_sign), _ptr(wm), wmbs,
                                       _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ, _ptr(dst), _ptr(density),
-                                      _ptr(warped), _ptr(valid), n, c, h, w, int(round_mode), st),
+                                      _ptr(warped), _ptr(valid), _ptr(mchan), n, c, h, w, int(round_mode), st),
            "ofl_splat_finalize_f32")
-    return dst, valid, density, warped
+    return dst, (mchan if want_mask_chan else valid), density, warped

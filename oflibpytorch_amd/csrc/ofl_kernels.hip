@@ -213,7 +213,7 @@ struct SplatParams {
     const uint8_t* chan_mask_b; int64_t chan_mask_b_bs;
     int32_t with_mask_chan, occlude;
     float* accum;          // pass 1 out / pass 2 in
-    float* dst; float* density; uint8_t* warped; uint8_t* valid;   // pass 2 out
+    float* dst; float* density; uint8_t* warped; uint8_t* valid; float* mask_chan;   // pass 2 out
     int32_t n, c, h, w;
     int32_t round_mode;
     int32_t tiles_x, tiles_y;
@@ -288,7 +288,10 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
                 for (int ch = 0; ch < (CT ? CT : 1); ++ch)
                     for (int cc = ch; cc < C; cc += (CT ? C : 1))
                         atomicAdd(&acc[(int64_t)(1 + cc) * hw + pos], wgt * (p.data_sign * db[(int64_t)cc * hw + pix]));
-                if (p.with_mask_chan) atomicAdd(&acc[(int64_t)(1 + C) * hw + pos], wgt * mval);
+                // mask channel: the reference accumulates wgt * mval next to the density.  All contributors of a
+                // pixel being valid is the common case and must give ratio == 1 exactly, whatever order the
+                // atomics land in -- so accumulate the INVALID weight instead and form den - inv in pass 2.
+                if (p.with_mask_chan && mval == 0.0f) atomicAdd(&acc[(int64_t)(1 + C) * hw + pos], wgt);
             }
         }
     }
@@ -342,13 +345,14 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
             }
         if (p.density) p.density[(int64_t)n * hw + pix] = den;
         if (p.warped) p.warped[(int64_t)n * hw + pix] = (uint8_t)warped;
-        if (p.valid) {
+        if (p.valid || p.mask_chan) {
             float mch;
             if (fill)
                 mch = ((cma ? cma[pix] != 0 : true) && (cmb ? cmb[pix] != 0 : true)) ? 1.0f : 0.0f;
             else
-                mch = acc[(int64_t)(1 + C) * hw + pix] / dcl;
-            p.valid[(int64_t)n * hw + pix] = (uint8_t)(mch > kValidThr);
+                mch = (den - acc[(int64_t)(1 + C) * hw + pix]) / dcl;
+            if (p.valid) p.valid[(int64_t)n * hw + pix] = (uint8_t)(mch > kValidThr);
+            if (p.mask_chan) p.mask_chan[(int64_t)n * hw + pix] = mch;
         }
     }
 }
@@ -494,10 +498,10 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
     const float* accum, const float* flow, int64_t flow_bs, const float* data, int64_t data_bs, float data_sign,
     const uint8_t* weight_mask, int64_t weight_mask_bs, const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
     const uint8_t* chan_mask_b, int64_t chan_mask_b_bs, int32_t with_mask_chan, int32_t occlude, float* dst,
-    float* density, uint8_t* warped, uint8_t* valid, int32_t n, int32_t c, int32_t h, int32_t w,
+    float* density, uint8_t* warped, uint8_t* valid, float* mask_chan, int32_t n, int32_t c, int32_t h, int32_t w,
     int32_t round_mode, void* stream) {
     if (!accum || !data || !dst) return OFL_E_NULL;
-    if (valid && !with_mask_chan) return OFL_E_ARG;
+    if ((valid || mask_chan) && !with_mask_chan) return OFL_E_ARG;
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
     SplatParams p = {};
     unsigned grid;
@@ -505,7 +509,8 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
                         chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, n, c, h, w, grid);
     if (rc) return rc;
     p.accum = const_cast<float*>(accum);
-    p.dst = dst; p.density = density; p.warped = warped; p.valid = valid; p.round_mode = round_mode;
+    p.dst = dst; p.density = density; p.warped = warped; p.valid = valid; p.mask_chan = mask_chan;
+    p.round_mode = round_mode;
     hipStream_t st = (hipStream_t)stream;
     switch (c) {
         case 1: hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import _native
+from . import _native, distributed
 from .utils import (get_valid_vecs, get_valid_ref, get_valid_mask, get_valid_device, get_valid_padding,
                     get_valid_shape, get_pure_pytorch, move_axis, from_matrix, from_transforms, resize_flow,
                     apply_flow, _flags_to_host, _griddata_unavailable)
@@ -80,12 +80,24 @@ class Flow(object):
             key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
             self._pending_flags = (key, dev_flags)
 
+    def _batch_flags(self) -> int:
+        """OR of the flag words over the whole batch -- over every rank's shard when batch sharding is on
+        (the reference's early exits are batch-global, distributed.py)."""
+        flags = self._flags()
+        if len(self._flag_cache) < 3 or self._flag_cache[2][0] != distributed.is_enabled():
+            local = 0
+            for f in flags:
+                local |= f
+            glob = distributed.reduce_flags(local, self._vecs.device)
+            self._flag_cache = (self._flag_cache[0], self._flag_cache[1], (distributed.is_enabled(), glob))
+        return self._flag_cache[2][1]
+
     def _require_finite(self, error_string: str):
-        if any(f & _native.FLAG_NONFINITE for f in self._flags()):                     # utils.py:98
+        if self._batch_flags() & _native.FLAG_NONFINITE:                              # utils.py:98
             raise ValueError(error_string + "Input contains NaN, Inf or -Inf values")
 
     def _all_zero(self, bit: int) -> bool:
-        return not any(f & bit for f in self._flags())
+        return not (self._batch_flags() & bit)
 
     @property
     def vecs(self) -> torch.Tensor:
@@ -503,9 +515,7 @@ class Flow(object):
         if not isinstance(consider_mask, bool):
             raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
         if self._ref == 's':
-            area = apply_flow(self._vecs, self.mask.unsqueeze(1).to(torch.float), 's',
-                              self.mask if consider_mask else None).squeeze(1)
-            return area == 1
+            return self._splat_mask_is_one(1.0, consider_mask)
         ones = torch.ones((self.shape[0], 1) + self.shape[1:], device=self._device)
         area = apply_flow(self._vecs, ones, 't').squeeze(1)
         return (area > 0.9999) & self.mask
@@ -518,9 +528,22 @@ class Flow(object):
             ones = torch.ones((self.shape[0], 1) + self.shape[1:], device=self._device)
             area = apply_flow(-self._vecs, ones, 't').squeeze(1)
             return (area > 0.9999) & self.mask
-        area = apply_flow(-self._vecs, self.mask.unsqueeze(1).to(torch.float), 's',
-                          self.mask if consider_mask else None).squeeze(1)
-        return area == 1
+        return self._splat_mask_is_one(-1.0, consider_mask)
+
+    def _splat_mask_is_one(self, sign: float, consider_mask: bool) -> torch.Tensor:
+        """apply_flow(sign * vecs, mask.float(), 's', mask if consider_mask else None) == 1 (flow_class.py:1116-1118,
+        1165-1169): the flow mask splatted as data, through the kernels' mask channel so that "every contributor
+        valid" is exactly 1 whatever order the accumulation ran in."""
+        if not get_pure_pytorch():
+            _griddata_unavailable("valid_target / valid_source")
+        self._require_finite("Error applying flow to a target: ")
+        if self._all_zero(_native.FLAG_NZ_THR):                      # apply_flow's early exit: the mask itself
+            return self.mask.clone()
+        dummy = self._vecs[:, :1]
+        _, mch, _, _ = _native.splat_fwd(self._vecs, dummy, flow_sign=sign, chan_mask_a=self._mask,
+                                         weight_mask=self._mask if consider_mask else None, occlude=True,
+                                         want_mask_chan=True)
+        return (mch == 1).to(self._device)
 
     # ------------------------------------------------------------------------------------------
     # zero test (flow_class.py:1226-1244)

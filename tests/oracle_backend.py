@@ -74,14 +74,15 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
-              chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False, round_mode=0):
+              chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False, round_mode=0,
+              want_mask_chan=False):
     d = _np(data, np.float32) * np.float32(data_sign)
     n = max(d.shape[0], 1 if flow is None else flow.shape[0], 1 if xs is None else xs.shape[0],
             1 if weight_mask is None else weight_mask.shape[0], 1 if chan_mask_a is None else chan_mask_a.shape[0],
             1 if chan_mask_b is None else chan_mask_b.shape[0])
     d = _bcast(d, n)
     c, h, w = d.shape[1:]
-    if want_valid:
+    if want_valid or want_mask_chan:
         mc = np.ones((n, h, w), bool)
         for cm in (chan_mask_a, chan_mask_b):
             if cm is not None:
@@ -95,5 +96,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
         out, den = oracle.grid_from_unstructured_data(_bcast(_np(xs, np.float32), n), _bcast(_np(ys, np.float32), n), d, wm)
         warped = den > 0
     valid = torch.tensor(oracle.theta(out[:, c])) if want_valid else None
+    if want_mask_chan:
+        valid = torch.tensor(out[:, c].copy())
     return (torch.tensor(_round(out[:, :c], round_mode)), valid,
             torch.tensor(den) if want_density else None, torch.tensor(warped) if want_warped else None)
