@@ -1,0 +1,2614 @@
+// Microbenchmark: variants of the backward-warp kernel (C=3 image + mask channel + valid mask = Flow.apply 't',
+// 35 algorithmic B/px) against streaming kernels of the same byte mix.  Build & run on the GPU box:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o /tmp/wv tools/microbench/warp_variants.hip && /tmp/wv
+// Every variant is checked bit-for-bit against variant 0 before it is timed.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct P {
+    const float* flow; const float* src; const uint8_t* smask; const uint8_t* fmask;
+    float* dst; uint8_t* valid;
+    int n, h, w;
+    float wm1, hm1, hwm1, hhm1;
+    int tiles_x, tiles_y; long total, per_xcd;
+    unsigned mx_m, mx_s, mi_m, mi_s, tiles_img;   // magic divisors: by tiles_x and by tiles per image
+};
+
+__device__ __forceinline__ float unnorm(float p, float m1, float half) {
+    float g = p * 2.0f; g = g / m1; g = g - 1.0f; return (g + 1.0f) * half;
+}
+
+struct Taps { int o_nw, o_ne, o_sw, o_se; float nw, ne, sw, se; bool k_nw, k_ne, k_sw, k_se; };
+
+__device__ __forceinline__ Taps make_taps(int x, int y, float u, float v, const P& p) {
+    Taps t;
+    const int w = p.w, h = p.h;
+    const float sx = unnorm((float)x - u, p.wm1, p.hwm1), sy = unnorm((float)y - v, p.hm1, p.hhm1);
+    const float x_w = floorf(sx), y_n = floorf(sy);
+    const float ww = sx - x_w, e = 1.0f - ww, nn = sy - y_n, s = 1.0f - nn;
+    t.nw = s * e; t.ne = s * ww; t.sw = nn * e; t.se = nn * ww;
+    const float x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+    const bool x0 = (x_w > -1.0f) && (x_w < (float)w), x1 = (x_e > -1.0f) && (x_e < (float)w);
+    const bool y0 = (y_n > -1.0f) && (y_n < (float)h), y1 = (y_s > -1.0f) && (y_s < (float)h);
+    const int ix0 = x0 ? (int)x_w : 0, ix1 = x1 ? (int)x_e : 0, iy0 = y0 ? (int)y_n : 0, iy1 = y1 ? (int)y_s : 0;
+    t.o_nw = iy0 * w + ix0; t.o_ne = iy0 * w + ix1; t.o_sw = iy1 * w + ix0; t.o_se = iy1 * w + ix1;
+    t.k_nw = x0 && y0; t.k_ne = x1 && y0; t.k_sw = x0 && y1; t.k_se = x1 && y1;
+    return t;
+}
+
+__device__ __forceinline__ float blend(float a, float b, float c, float d, const Taps& t) {
+    float r = a * t.nw; r = __builtin_fmaf(b, t.ne, r); r = __builtin_fmaf(c, t.sw, r); return __builtin_fmaf(d, t.se, r);
+}
+
+__device__ __forceinline__ long logical_block(long per_xcd) { long b = blockIdx.x; return (b % 8) * per_xcd + b / 8; }
+// exact u32 division by an invariant divisor (round-up magic, valid for all n < 2^32): q = (umulhi(m, n) + ((n - umulhi) >> 1)) >> s
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned m, unsigned s) {
+    const unsigned q = __umulhi(m, n);
+    return (((n - q) >> (s >> 16)) + q) >> (s & 0xffffu);   // s = (s1 << 16) | s2, s1 = min(l, 1), s2 = max(l - 1, 0)
+}
+// persistent-grid tile iterator: block b lives on XCD b & 7 (round-robin dispatch); each XCD owns a contiguous range of
+// per_xcd logical tiles and its blocks walk that range with stride gridDim/8 (neighbouring tiles run concurrently)
+__device__ __forceinline__ bool decode_tile_at(const P& p, unsigned it, int& tx, int& ty, int& n) {
+    const unsigned b = blockIdx.x, slots = gridDim.x >> 3;
+    const unsigned k = (b >> 3) + it * slots;
+    if (k >= (unsigned)p.per_xcd) return false;
+    const unsigned tile = (b & 7u) * (unsigned)p.per_xcd + k;
+    if (tile >= (unsigned)p.total) return false;
+    const unsigned nn = fastdiv(tile, p.mi_m, p.mi_s);
+    const unsigned rem = tile - nn * p.tiles_img;
+    const unsigned yy = fastdiv(rem, p.mx_m, p.mx_s);
+    n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (unsigned)p.tiles_x);
+    return true;
+}
+// 32-bit tile decode: XCD-aware logical id, then (n, ty, tx) with two magic divisions and no 64-bit arithmetic
+__device__ __forceinline__ bool decode_tile(const P& p, int& tx, int& ty, int& n) {
+    const unsigned b = blockIdx.x;
+    const unsigned tile = (b & 7u) * (unsigned)p.per_xcd + (b >> 3);
+    if (tile >= (unsigned)p.total) return false;
+    const unsigned nn = fastdiv(tile, p.mi_m, p.mi_s);
+    const unsigned rem = tile - nn * p.tiles_img;
+    const unsigned yy = fastdiv(rem, p.mx_m, p.mx_s);
+    n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (unsigned)p.tiles_x);
+    return true;
+}
+
+
+// streaming (no gather) but in TILE order, 16 B per lane: TWQ threads per row, TH = 256 / TWQ rows per tile
+template <int TWQ>
+__global__ __launch_bounds__(256) void stream_tiled(const P p) {
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    constexpr int TH = 256 / TWQ;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h, hw = h * w;
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    if (x4 >= w || y >= h) return;
+    const int pix = y * w + x4;
+    const float4 u = *reinterpret_cast<const float4*>(p.flow + (long)n * 2 * hw + pix);
+    const float4 v = *reinterpret_cast<const float4*>(p.flow + (long)n * 2 * hw + hw + pix);
+    const uchar4 a = *reinterpret_cast<const uchar4*>(p.smask + (long)n * hw + pix);
+    const uchar4 b = *reinterpret_cast<const uchar4*>(p.fmask + (long)n * hw + pix);
+    *reinterpret_cast<uchar4*>(p.valid + (long)n * hw + pix) = make_uchar4(a.x && b.x && (v.x != 12345.f), a.y && b.y, a.z && b.z, a.w && b.w);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float4 q = *reinterpret_cast<const float4*>(p.src + (long)n * 3 * hw + c * hw + pix);
+        q.x += u.x; q.y += u.y; q.z += u.z; q.w += u.w;
+        *reinterpret_cast<float4*>(p.dst + (long)n * 3 * hw + c * hw + pix) = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// V0: the round-1 first-path kernel (row loop with early `continue`)
+// ---------------------------------------------------------------------------------------------
+template <int ROWS>
+__global__ __launch_bounds__(256) void warp_v0(const P p) {
+    const long tile = logical_block(p.per_xcd);
+    if (tile >= p.total) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / ((long)p.tiles_x * p.tiles_y);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = tx * 64 + lane, w = p.w, h = p.h;
+    const long hw = (long)h * w;
+    const float* fu = p.flow + n * 2 * hw; const float* sb = p.src + n * 3 * hw;
+    const uint8_t* sm = p.smask + n * hw; const uint8_t* fm = p.fmask + n * hw;
+    float* db = p.dst + n * 3 * hw;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = ty * (4 * ROWS) + wave * ROWS + r;
+        if (x >= w || y >= h) continue;
+        const long pix = (long)y * w + x;
+        const Taps t = make_taps(x, y, fu[pix], fu[hw + pix], p);
+        const float m = blend(t.k_nw ? (float)(sm[t.o_nw] != 0) : 0.f, t.k_ne ? (float)(sm[t.o_ne] != 0) : 0.f,
+                              t.k_sw ? (float)(sm[t.o_sw] != 0) : 0.f, t.k_se ? (float)(sm[t.o_se] != 0) : 0.f, t);
+        p.valid[n * hw + pix] = (uint8_t)((m > 0.99999f) && (fm[pix] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* sp = sb + c * hw;
+            db[c * hw + pix] = blend(t.k_nw ? sp[t.o_nw] : 0.f, t.k_ne ? sp[t.o_ne] : 0.f, t.k_sw ? sp[t.o_sw] : 0.f,
+                                     t.k_se ? sp[t.o_se] : 0.f, t);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// V1: branch-free, loads hoisted: all flow loads, then all tap loads (ROWS x 16 in flight), then math + stores
+// ---------------------------------------------------------------------------------------------
+template <int ROWS, int TW_WAVES>   // TW_WAVES: waves side by side in x (tile = 64*TW_WAVES wide, (4/TW_WAVES)*ROWS tall)
+__global__ __launch_bounds__(256) void warp_v1(const P p) {
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wx = wave % TW_WAVES, wy = wave / TW_WAVES;
+    const int w = p.w, h = p.h;
+    const int x = tx * (64 * TW_WAVES) + wx * 64 + lane;
+    const int xc = min(x, w - 1);
+    const long hw = (long)h * w;
+    const float* __restrict__ fu = p.flow + n * 2 * hw; const float* __restrict__ sb = p.src + n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + n * hw; const uint8_t* __restrict__ fm = p.fmask + n * hw;
+    float* __restrict__ db = p.dst + n * 3 * hw;
+    const int y0 = ty * ((4 / TW_WAVES) * ROWS) + wy * ROWS;
+    float u[ROWS], v[ROWS]; uint8_t fmv[ROWS]; int pixc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int yc = min(y0 + r, h - 1);
+        pixc[r] = yc * w + xc;
+        u[r] = fu[pixc[r]]; v[r] = fu[hw + pixc[r]]; fmv[r] = fm[pixc[r]];
+    }
+    Taps t[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) t[r] = make_taps(xc, min(y0 + r, h - 1), u[r], v[r], p);
+    float val[ROWS][3][4]; uint8_t mv[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        mv[r][0] = sm[t[r].o_nw]; mv[r][1] = sm[t[r].o_ne]; mv[r][2] = sm[t[r].o_sw]; mv[r][3] = sm[t[r].o_se];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* __restrict__ sp = sb + c * hw;
+            val[r][c][0] = sp[t[r].o_nw]; val[r][c][1] = sp[t[r].o_ne]; val[r][c][2] = sp[t[r].o_sw]; val[r][c][3] = sp[t[r].o_se];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const bool ok = (x < w) && (y0 + r < h);
+        const Taps& q = t[r];
+        const float m = blend(q.k_nw ? (float)(mv[r][0] != 0) : 0.f, q.k_ne ? (float)(mv[r][1] != 0) : 0.f,
+                              q.k_sw ? (float)(mv[r][2] != 0) : 0.f, q.k_se ? (float)(mv[r][3] != 0) : 0.f, q);
+        if (ok) p.valid[n * hw + pixc[r]] = (uint8_t)((m > 0.99999f) && (fmv[r] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = blend(q.k_nw ? val[r][c][0] : 0.f, q.k_ne ? val[r][c][1] : 0.f, q.k_sw ? val[r][c][2] : 0.f,
+                                  q.k_se ? val[r][c][3] : 0.f, q);
+            if (ok) db[c * hw + pixc[r]] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// V2: 4 consecutive x per thread: 16-byte flow loads / stores, dword taps; tile 256 x ROWS*4? (wave = 256 px of one row)
+// ---------------------------------------------------------------------------------------------
+template <int ROWS>
+__global__ __launch_bounds__(256) void warp_v2(const P p) {   // requires w % 4 == 0
+    const long tile = logical_block(p.per_xcd);
+    if (tile >= p.total) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / ((long)p.tiles_x * p.tiles_y);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = p.w, h = p.h;
+    const int x4 = tx * 256 + lane * 4;
+    const long hw = (long)h * w;
+    const float* __restrict__ fu = p.flow + n * 2 * hw; const float* __restrict__ sb = p.src + n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + n * hw; const uint8_t* __restrict__ fm = p.fmask + n * hw;
+    float* __restrict__ db = p.dst + n * 3 * hw;
+    if (x4 >= w) return;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = ty * (4 * ROWS) + wave * ROWS + r;
+        if (y >= h) break;
+        const long pix = (long)y * w + x4;
+        const float4 u4 = *reinterpret_cast<const float4*>(fu + pix);
+        const float4 v4 = *reinterpret_cast<const float4*>(fu + hw + pix);
+        const uchar4 f4 = *reinterpret_cast<const uchar4*>(fm + pix);
+        const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const uint8_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+        Taps t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = make_taps(x4 + k, y, uu[k], vv[k], p);
+        float val[4][3][4]; uint8_t mv[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mv[k][0] = sm[t[k].o_nw]; mv[k][1] = sm[t[k].o_ne]; mv[k][2] = sm[t[k].o_sw]; mv[k][3] = sm[t[k].o_se];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* __restrict__ sp = sb + c * hw;
+                val[k][c][0] = sp[t[k].o_nw]; val[k][c][1] = sp[t[k].o_ne]; val[k][c][2] = sp[t[k].o_sw]; val[k][c][3] = sp[t[k].o_se];
+            }
+        }
+        float out[3][4]; uint8_t vo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Taps& q = t[k];
+            const float m = blend(q.k_nw ? (float)(mv[k][0] != 0) : 0.f, q.k_ne ? (float)(mv[k][1] != 0) : 0.f,
+                                  q.k_sw ? (float)(mv[k][2] != 0) : 0.f, q.k_se ? (float)(mv[k][3] != 0) : 0.f, q);
+            vo[k] = (uint8_t)((m > 0.99999f) && (ff[k] != 0));
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                out[c][k] = blend(q.k_nw ? val[k][c][0] : 0.f, q.k_ne ? val[k][c][1] : 0.f, q.k_sw ? val[k][c][2] : 0.f,
+                                  q.k_se ? val[k][c][3] : 0.f, q);
+        }
+        *reinterpret_cast<uchar4*>(p.valid + n * hw + pix) = make_uchar4(vo[0], vo[1], vo[2], vo[3]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(db + c * hw + pix) = make_float4(out[c][0], out[c][1], out[c][2], out[c][3]);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V3: V1 + pair loads: (x0, x0+1) of a row fetched by ONE unaligned 8-byte load (2-byte for the mask bytes)
+// ---------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) F2 { float a, b; };
+struct __attribute__((packed, aligned(1))) B2 { uint8_t a, b; };
+
+template <int ROWS, int TW_WAVES>
+__global__ __launch_bounds__(256) void warp_v3(const P p) {   // requires w >= 2
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wx = wave % TW_WAVES, wy = wave / TW_WAVES;
+    const int w = p.w, h = p.h;
+    const int x = tx * (64 * TW_WAVES) + wx * 64 + lane;
+    const int xc = min(x, w - 1);
+    const long hw = (long)h * w;
+    const float* __restrict__ fu = p.flow + n * 2 * hw; const float* __restrict__ sb = p.src + n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + n * hw; const uint8_t* __restrict__ fm = p.fmask + n * hw;
+    float* __restrict__ db = p.dst + n * 3 * hw;
+    const int y0 = ty * ((4 / TW_WAVES) * ROWS) + wy * ROWS;
+    float u[ROWS], v[ROWS]; uint8_t fmv[ROWS]; int pixc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int yc = min(y0 + r, h - 1);
+        pixc[r] = yc * w + xc;
+        u[r] = fu[pixc[r]]; v[r] = fu[hw + pixc[r]]; fmv[r] = fm[pixc[r]];
+    }
+    Taps t[ROWS]; int pn[ROWS], ps[ROWS]; bool lo[ROWS], hi[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        t[r] = make_taps(xc, min(y0 + r, h - 1), u[r], v[r], p);
+        // pair base column: x0 when 0 <= x0 <= w-2; x0 == -1 -> pair at 0 (use .a as east tap); x0 == w-1 -> pair at w-2 (use .b as west tap)
+        const Taps& q = t[r];
+        const int rowN = q.o_nw - (q.k_nw || q.k_sw ? (q.o_nw % w) : 0);   // placeholder, replaced below
+        (void)rowN;
+    }
+    float val[ROWS][3][4]; uint8_t mv[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const Taps& q = t[r];
+        const bool x0ok = q.k_nw || q.k_sw, x1ok = q.k_ne || q.k_se;     // column validity (given some row valid)
+        // column of the west tap if valid else east-1; clamp the pair into [0, w-2]
+        const int row_n = (q.k_nw ? q.o_nw : (q.k_ne ? q.o_ne : 0)) / w, row_s = (q.k_sw ? q.o_sw : (q.k_se ? q.o_se : 0)) / w;
+        const int colw = x0ok ? ((q.k_nw ? q.o_nw : q.o_sw) % w) : (x1ok ? ((q.k_ne ? q.o_ne : q.o_se) % w) - 1 : 0);
+        const int pc = min(max(colw, 0), w - 2);
+        lo[r] = (colw < 0); hi[r] = (colw > w - 2);
+        pn[r] = row_n * w + pc; ps[r] = row_s * w + pc;
+        const B2 mn = *reinterpret_cast<const B2*>(sm + pn[r]); const B2 ms = *reinterpret_cast<const B2*>(sm + ps[r]);
+        mv[r][0] = hi[r] ? mn.b : mn.a; mv[r][1] = lo[r] ? mn.a : mn.b; mv[r][2] = hi[r] ? ms.b : ms.a; mv[r][3] = lo[r] ? ms.a : ms.b;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* __restrict__ sp = sb + c * hw;
+            const F2 a = *reinterpret_cast<const F2*>(sp + pn[r]); const F2 b = *reinterpret_cast<const F2*>(sp + ps[r]);
+            val[r][c][0] = hi[r] ? a.b : a.a; val[r][c][1] = lo[r] ? a.a : a.b; val[r][c][2] = hi[r] ? b.b : b.a; val[r][c][3] = lo[r] ? b.a : b.b;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const bool ok = (x < w) && (y0 + r < h);
+        const Taps& q = t[r];
+        const float m = blend(q.k_nw ? (float)(mv[r][0] != 0) : 0.f, q.k_ne ? (float)(mv[r][1] != 0) : 0.f,
+                              q.k_sw ? (float)(mv[r][2] != 0) : 0.f, q.k_se ? (float)(mv[r][3] != 0) : 0.f, q);
+        if (ok) p.valid[n * hw + pixc[r]] = (uint8_t)((m > 0.99999f) && (fmv[r] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = blend(q.k_nw ? val[r][c][0] : 0.f, q.k_ne ? val[r][c][1] : 0.f, q.k_sw ? val[r][c][2] : 0.f,
+                                  q.k_se ? val[r][c][3] : 0.f, q);
+            if (ok) db[c * hw + pixc[r]] = o;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V4: LDS-staged source tile.  16-byte flow loads / output stores (4 consecutive x per thread); the tile's
+// source bounding box (3 fp32 planes + 1 byte plane) is staged into LDS with 16-byte coalesced loads, the fp32
+// planes de-interleaved by 4 (x -> (x&3)*cw + (x>>2)) so that the stride-4-px gathers are bank-conflict free.
+// Falls back to direct global gathers for a tile whose bounding box does not fit the LDS budget.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+struct Taps2 { int ix0, ix1, iy0, iy1; float nw, ne, sw, se; bool x0, x1, y0, y1; };
+
+__device__ __forceinline__ Taps2 make_taps2(int x, int y, float u, float v, const P& p) {
+    Taps2 t;
+    const int w = p.w, h = p.h;
+    const float sx = unnorm((float)x - u, p.wm1, p.hwm1), sy = unnorm((float)y - v, p.hm1, p.hhm1);
+    const float x_w = floorf(sx), y_n = floorf(sy);
+    const float ww = sx - x_w, e = 1.0f - ww, nn = sy - y_n, s = 1.0f - nn;
+    t.nw = s * e; t.ne = s * ww; t.sw = nn * e; t.se = nn * ww;
+    const float x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+    t.x0 = (x_w > -1.0f) && (x_w < (float)w); t.x1 = (x_e > -1.0f) && (x_e < (float)w);
+    t.y0 = (y_n > -1.0f) && (y_n < (float)h); t.y1 = (y_s > -1.0f) && (y_s < (float)h);
+    t.ix0 = t.x0 ? (int)x_w : 0; t.ix1 = t.x1 ? (int)x_e : 0; t.iy0 = t.y0 ? (int)y_n : 0; t.iy1 = t.y1 ? (int)y_s : 0;
+    return t;
+}
+__device__ __forceinline__ float blend2(float a, float b, float c, float d, const Taps2& t) {
+    float r = a * t.nw; r = __builtin_fmaf(b, t.ne, r); r = __builtin_fmaf(c, t.sw, r); return __builtin_fmaf(d, t.se, r);
+}
+
+__device__ unsigned long long g_fit_count[2];
+
+template <int TWQ, int TH>   // TWQ threads (x4 px) per tile row, TH rows; TWQ*TH == 256
+__global__ __launch_bounds__(256) void warp_v4(const P p, const int lds_budget) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[4][4];
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const long hw = (long)h * w;
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + n * 2 * hw; const float* __restrict__ sb = p.src + n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + n * hw; const uint8_t* __restrict__ fm = p.fmask + n * hw;
+    float* __restrict__ db = p.dst + n * 3 * hw;
+    const int pix = yc * w + xc;
+    const float4 u4 = *reinterpret_cast<const float4*>(fu + pix);
+    const float4 v4 = *reinterpret_cast<const float4*>(fu + hw + pix);
+    const uchar4 f4 = *reinterpret_cast<const uchar4*>(fm + pix);
+    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    const uint8_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    Taps2 t[4];
+    int minx = 0x7fffffff, maxx = -1, miny = 0x7fffffff, maxy = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t[k] = make_taps2(xc + k, yc, uu[k], vv[k], p);
+        const Taps2& q = t[k];
+        const bool anyx = q.x0 || q.x1, anyy = q.y0 || q.y1;
+        if (inb && anyx && anyy) {     // columns / rows touched by at least one valid tap
+            minx = min(minx, q.x0 ? q.ix0 : q.ix1); maxx = max(maxx, q.x1 ? q.ix1 : q.ix0);
+            miny = min(miny, q.y0 ? q.iy0 : q.iy1); maxy = max(maxy, q.y1 ? q.iy1 : q.iy0);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+    __syncthreads();
+    minx = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+    maxx = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+    miny = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+    maxy = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    const bool empty = maxx < 0;
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int plane = bh * bw;                 // elements per plane
+    const bool fits = !empty && (plane * 13 <= lds_budget);
+#ifdef COUNT_FITS
+    if (tid == 0) atomicAdd(&g_fit_count[fits ? 1 : 0], 1ull);
+#endif
+    float* ldsf = reinterpret_cast<float*>(smem);
+    unsigned* ldsm = reinterpret_cast<unsigned*>(smem + (size_t)plane * 12);
+    const uint8_t* ldsb = smem + (size_t)plane * 12;
+    if (fits) {
+        // all staging loads are issued before the first LDS write (ITERS x 4 loads in flight per thread)
+        constexpr int ITERS = 4;               // lds_budget / 13 B / 4 px / 256 threads <= 4 for budgets <= 53 KB
+        const int nchunks = bh * cw;
+        int r[ITERS], c4[ITERS]; float4 q[ITERS][3]; unsigned mq[ITERS];
+        {
+            int rr = 0, cc = tid;
+            while (cc >= cw) { cc -= cw; ++rr; }
+            const int rstep = 256 / cw, cstep = 256 - rstep * cw;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                r[it] = rr; c4[it] = cc;
+                rr += rstep; cc += cstep; if (cc >= cw) { cc -= cw; ++rr; }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const bool on = tid + it * 256 < nchunks;
+            const int g = on ? (miny + r[it]) * w + bx0 + c4[it] * 4 : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const float4*>(sb + c * hw + g);
+            mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (tid + it * 256 < nchunks) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float* row = ldsf + c * plane + r[it] * bw + c4[it];
+                    row[0] = q[it][c].x; row[cw] = q[it][c].y; row[2 * cw] = q[it][c].z; row[3 * cw] = q[it][c].w;
+                }
+                ldsm[r[it] * cw + c4[it]] = mq[it];
+            }
+        }
+    }
+    __syncthreads();
+    float out[3][4]; uint8_t vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const Taps2& q = t[k];
+        float tv[3][4]; uint8_t tm[4];
+        const int cx[4] = {q.ix0, q.ix1, q.ix0, q.ix1}, cy[4] = {q.iy0, q.iy0, q.iy1, q.iy1};
+        const bool ok[4] = {q.x0 && q.y0, q.x1 && q.y0, q.x0 && q.y1, q.x1 && q.y1};
+        if (fits) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xl = ok[j] ? cx[j] - bx0 : 0, yl = ok[j] ? cy[j] - miny : 0;
+                const int fi = yl * bw + (xl & 3) * cw + (xl >> 2);
+                tm[j] = ldsb[yl * bw + xl];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tv[c][j] = ldsf[c * plane + fi];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int og = cy[j] * w + cx[j];
+                tm[j] = sm[og];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tv[c][j] = sb[c * hw + og];
+            }
+        }
+        const float m = blend2(ok[0] ? (float)(tm[0] != 0) : 0.f, ok[1] ? (float)(tm[1] != 0) : 0.f,
+                               ok[2] ? (float)(tm[2] != 0) : 0.f, ok[3] ? (float)(tm[3] != 0) : 0.f, q);
+        vo[k] = (uint8_t)((m > 0.99999f) && (ff[k] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            out[c][k] = blend2(ok[0] ? tv[c][0] : 0.f, ok[1] ? tv[c][1] : 0.f, ok[2] ? tv[c][2] : 0.f, ok[3] ? tv[c][3] : 0.f, q);
+    }
+    if (inb) {
+        *reinterpret_cast<uchar4*>(p.valid + n * hw + pix) = make_uchar4(vo[0], vo[1], vo[2], vo[3]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(db + c * hw + pix) = make_float4(out[c][0], out[c][1], out[c][2], out[c][3]);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V5: LDS-staged, VALU-trimmed: exact reciprocal division (Markstein, 2 refinements), zero slots instead of
+// per-value selects, shared row / column address terms, dense flattened staging without integer division,
+// read-conflict-free row pitch (P == TWQ mod 2*TWQ), blocks of NT = 64 / 128 / 256 threads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float exact_div(float a, float b, float y) {   // y = RN(1/b); == a / b (IEEE RN)
+    const float aa = fabsf(a);
+    if (__builtin_expect(!(aa <= 0x1p100f) || (aa < 0x1p-60f && aa != 0.0f), 0)) return a / b;
+    float q = a * y;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+struct P5 { P p; float rw, rh; };   // rw = RN(1/(w-1)), rh = RN(1/(h-1))
+
+struct Taps5 { int ix0, ix1, iy0, iy1; float nw, ne, sw, se; bool x0, x1, y0, y1; };
+__device__ __forceinline__ Taps5 make_taps5(int x, int y, float u, float v, const P5& q) {
+    Taps5 t; const P& p = q.p;
+    const int w = p.w, h = p.h;
+    float gx = exact_div(((float)x - u) * 2.0f, p.wm1, q.rw) - 1.0f, gy = exact_div(((float)y - v) * 2.0f, p.hm1, q.rh) - 1.0f;
+    const float sx = (gx + 1.0f) * p.hwm1, sy = (gy + 1.0f) * p.hhm1;
+    const float x_w = floorf(sx), y_n = floorf(sy);
+    const float ww = sx - x_w, e = 1.0f - ww, nn = sy - y_n, s = 1.0f - nn;
+    t.nw = s * e; t.ne = s * ww; t.sw = nn * e; t.se = nn * ww;
+    const float x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+    t.x0 = (x_w > -1.0f) && (x_w < (float)w); t.x1 = (x_e > -1.0f) && (x_e < (float)w);
+    t.y0 = (y_n > -1.0f) && (y_n < (float)h); t.y1 = (y_s > -1.0f) && (y_s < (float)h);
+    t.ix0 = t.x0 ? (int)x_w : 0; t.ix1 = t.x1 ? (int)x_e : 0; t.iy0 = t.y0 ? (int)y_n : 0; t.iy1 = t.y1 ? (int)y_s : 0;
+    return t;
+}
+__device__ __forceinline__ float blend5(float a, float b, float c, float d, const Taps5& t) {
+    float r = a * t.nw; r = __builtin_fmaf(b, t.ne, r); r = __builtin_fmaf(c, t.sw, r); return __builtin_fmaf(d, t.se, r);
+}
+__device__ __forceinline__ int pitch_for(int n, int twq) {   // smallest P >= n with P % (2*twq) == twq
+    const int m = 2 * twq; int r = (twq - n) % m; if (r < 0) r += m; return n + r;
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v5(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h, hw = h * w;
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (long)n * 2 * hw; const float* __restrict__ sb = p.src + (long)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (long)n * hw; const uint8_t* __restrict__ fm = p.fmask + (long)n * hw;
+    float* __restrict__ db = p.dst + (long)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (long)n * hw;
+    const int pix = yc * w + xc;
+    const float4 u4 = *reinterpret_cast<const float4*>(fu + pix);
+    const float4 v4 = *reinterpret_cast<const float4*>(fu + hw + pix);
+    const uchar4 f4 = *reinterpret_cast<const uchar4*>(fm + pix);
+    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    const uint8_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    Taps5 t[4];
+    int minx = 0x7fffffff, maxx = -1, miny = 0x7fffffff, maxy = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t[k] = make_taps5(xc + k, yc, uu[k], vv[k], pp);
+        const Taps5& q = t[k];
+        if (inb && (q.x0 || q.x1) && (q.y0 || q.y1)) {
+            minx = min(minx, q.x0 ? q.ix0 : q.ix1); maxx = max(maxx, q.x1 ? q.ix1 : q.ix0);
+            miny = min(miny, q.y0 ? q.iy0 : q.iy1); maxy = max(maxy, q.y1 ? q.iy1 : q.iy0);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx);
+    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
+    const bool empty = maxx < 0;
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pf = pitch_for(bw, TWQ), Pd = pitch_for(cw, TWQ), Pb = Pd * 4;   // fp32 pitch (floats), byte-plane pitch (dwords / bytes)
+    const int planeF = 4 + bh * Pf;
+    const int nch = bh * cw;
+    const bool fits = !empty && (12 * planeF + 4 + bh * Pb <= lds_bytes) && (nch <= ITERS * NT);
+#ifdef COUNT_FITS
+    if (tid == 0) atomicAdd(&g_fit_count[fits ? 1 : 0], 1ull);
+#endif
+    float* ldsf = reinterpret_cast<float*>(smem);
+    unsigned* ldsm = reinterpret_cast<unsigned*>(smem + (size_t)planeF * 12);
+    const uint8_t* ldsb = smem + (size_t)planeF * 12;
+    if (fits) {
+        const int inv = (int)((1048576 + cw - 1) / cw);      // scalar: once per block
+        int r[ITERS], c4[ITERS]; float4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NT;
+            const bool on = i < nch;
+            r[it] = (int)(((unsigned)i * (unsigned)inv) >> 20); c4[it] = i - r[it] * cw;
+            const int g = on ? (miny + r[it]) * w + bx0 + c4[it] * 4 : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const float4*>(sb + c * hw + g);
+            mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+        }
+        if (tid == 0) { ldsf[0] = 0.f; ldsf[planeF] = 0.f; ldsf[2 * planeF] = 0.f; ldsm[0] = 0u; }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (tid + it * NT < nch) {
+                float* row = ldsf + 4 + r[it] * Pf + c4[it];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    row[c * planeF] = q[it][c].x; row[c * planeF + cw] = q[it][c].y;
+                    row[c * planeF + 2 * cw] = q[it][c].z; row[c * planeF + 3 * cw] = q[it][c].w;
+                }
+                ldsm[1 + r[it] * Pd + c4[it]] = mq[it];
+            }
+        }
+    }
+    __syncthreads();
+    float out[3][4]; uint8_t vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const Taps5& q = t[k];
+        float tv[3][4]; uint8_t tm[4];
+        const bool ok[4] = {q.x0 && q.y0, q.x1 && q.y0, q.x0 && q.y1, q.x1 && q.y1};
+        if (fits) {
+            const int xl0 = q.ix0 - bx0, xl1 = q.ix1 - bx0, yl0 = q.iy0 - miny, yl1 = q.iy1 - miny;
+            const int cp0 = (xl0 & 3) * cw + (xl0 >> 2), cp1 = (xl1 & 3) * cw + (xl1 >> 2);
+            const int rf0 = 4 + yl0 * Pf, rf1 = 4 + yl1 * Pf, rb0 = 4 + yl0 * Pb, rb1 = 4 + yl1 * Pb;
+            const int fi[4] = {ok[0] ? rf0 + cp0 : 0, ok[1] ? rf0 + cp1 : 0, ok[2] ? rf1 + cp0 : 0, ok[3] ? rf1 + cp1 : 0};
+            const int bi[4] = {ok[0] ? rb0 + xl0 : 0, ok[1] ? rb0 + xl1 : 0, ok[2] ? rb1 + xl0 : 0, ok[3] ? rb1 + xl1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tm[j] = ldsb[bi[j]];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tv[c][j] = ldsf[c * planeF + fi[j]];
+            }
+        } else {
+            const int cx[4] = {q.ix0, q.ix1, q.ix0, q.ix1}, cy[4] = {q.iy0, q.iy0, q.iy1, q.iy1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int og = cy[j] * w + cx[j];
+                tm[j] = ok[j] ? sm[og] : (uint8_t)0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tv[c][j] = ok[j] ? sb[c * hw + og] : 0.f;
+            }
+        }
+        const float m = blend5((float)(tm[0] != 0), (float)(tm[1] != 0), (float)(tm[2] != 0), (float)(tm[3] != 0), q);
+        vo[k] = (uint8_t)((m > 0.99999f) && (ff[k] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c][k] = blend5(tv[c][0], tv[c][1], tv[c][2], tv[c][3], q);
+    }
+    if (inb) {
+        *reinterpret_cast<uchar4*>(vb + pix) = make_uchar4(vo[0], vo[1], vo[2], vo[3]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(db + c * hw + pix) = make_float4(out[c][0], out[c][1], out[c][2], out[c][3]);
+    }
+}
+
+template <int ROWS, int TW_WAVES>   // TW_WAVES: waves side by side in x (tile = 64*TW_WAVES wide, (4/TW_WAVES)*ROWS tall)
+__global__ __launch_bounds__(256) void warp_v1p(const P p) {
+    for (unsigned tile_it = 0;; ++tile_it) {
+    int tx, ty, n;
+    if (!decode_tile_at(p, tile_it, tx, ty, n)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wx = wave % TW_WAVES, wy = wave / TW_WAVES;
+    const int w = p.w, h = p.h;
+    const int x = tx * (64 * TW_WAVES) + wx * 64 + lane;
+    const int xc = min(x, w - 1);
+    const long hw = (long)h * w;
+    const float* __restrict__ fu = p.flow + n * 2 * hw; const float* __restrict__ sb = p.src + n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + n * hw; const uint8_t* __restrict__ fm = p.fmask + n * hw;
+    float* __restrict__ db = p.dst + n * 3 * hw;
+    const int y0 = ty * ((4 / TW_WAVES) * ROWS) + wy * ROWS;
+    float u[ROWS], v[ROWS]; uint8_t fmv[ROWS]; int pixc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int yc = min(y0 + r, h - 1);
+        pixc[r] = yc * w + xc;
+        u[r] = fu[pixc[r]]; v[r] = fu[hw + pixc[r]]; fmv[r] = fm[pixc[r]];
+    }
+    Taps t[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) t[r] = make_taps(xc, min(y0 + r, h - 1), u[r], v[r], p);
+    float val[ROWS][3][4]; uint8_t mv[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        mv[r][0] = sm[t[r].o_nw]; mv[r][1] = sm[t[r].o_ne]; mv[r][2] = sm[t[r].o_sw]; mv[r][3] = sm[t[r].o_se];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* __restrict__ sp = sb + c * hw;
+            val[r][c][0] = sp[t[r].o_nw]; val[r][c][1] = sp[t[r].o_ne]; val[r][c][2] = sp[t[r].o_sw]; val[r][c][3] = sp[t[r].o_se];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const bool ok = (x < w) && (y0 + r < h);
+        const Taps& q = t[r];
+        const float m = blend(q.k_nw ? (float)(mv[r][0] != 0) : 0.f, q.k_ne ? (float)(mv[r][1] != 0) : 0.f,
+                              q.k_sw ? (float)(mv[r][2] != 0) : 0.f, q.k_se ? (float)(mv[r][3] != 0) : 0.f, q);
+        if (ok) p.valid[n * hw + pixc[r]] = (uint8_t)((m > 0.99999f) && (fmv[r] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = blend(q.k_nw ? val[r][c][0] : 0.f, q.k_ne ? val[r][c][1] : 0.f, q.k_sw ? val[r][c][2] : 0.f,
+                                  q.k_se ? val[r][c][3] : 0.f, q);
+            if (ok) db[c * hw + pixc[r]] = o;
+        }
+    }
+    }
+}
+
+template <int ROWS, int TW_WAVES>
+__global__ __launch_bounds__(256) void warp_v3p(const P p) {   // requires w >= 2
+    for (unsigned tile_it = 0;; ++tile_it) {
+    int tx, ty, n;
+    if (!decode_tile_at(p, tile_it, tx, ty, n)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wx = wave % TW_WAVES, wy = wave / TW_WAVES;
+    const int w = p.w, h = p.h;
+    const int x = tx * (64 * TW_WAVES) + wx * 64 + lane;
+    const int xc = min(x, w - 1);
+    const long hw = (long)h * w;
+    const float* __restrict__ fu = p.flow + n * 2 * hw; const float* __restrict__ sb = p.src + n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + n * hw; const uint8_t* __restrict__ fm = p.fmask + n * hw;
+    float* __restrict__ db = p.dst + n * 3 * hw;
+    const int y0 = ty * ((4 / TW_WAVES) * ROWS) + wy * ROWS;
+    float u[ROWS], v[ROWS]; uint8_t fmv[ROWS]; int pixc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int yc = min(y0 + r, h - 1);
+        pixc[r] = yc * w + xc;
+        u[r] = fu[pixc[r]]; v[r] = fu[hw + pixc[r]]; fmv[r] = fm[pixc[r]];
+    }
+    Taps t[ROWS]; int pn[ROWS], ps[ROWS]; bool lo[ROWS], hi[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        t[r] = make_taps(xc, min(y0 + r, h - 1), u[r], v[r], p);
+        // pair base column: x0 when 0 <= x0 <= w-2; x0 == -1 -> pair at 0 (use .a as east tap); x0 == w-1 -> pair at w-2 (use .b as west tap)
+        const Taps& q = t[r];
+        const int rowN = q.o_nw - (q.k_nw || q.k_sw ? (q.o_nw % w) : 0);   // placeholder, replaced below
+        (void)rowN;
+    }
+    float val[ROWS][3][4]; uint8_t mv[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const Taps& q = t[r];
+        const bool x0ok = q.k_nw || q.k_sw, x1ok = q.k_ne || q.k_se;     // column validity (given some row valid)
+        // column of the west tap if valid else east-1; clamp the pair into [0, w-2]
+        const int row_n = (q.k_nw ? q.o_nw : (q.k_ne ? q.o_ne : 0)) / w, row_s = (q.k_sw ? q.o_sw : (q.k_se ? q.o_se : 0)) / w;
+        const int colw = x0ok ? ((q.k_nw ? q.o_nw : q.o_sw) % w) : (x1ok ? ((q.k_ne ? q.o_ne : q.o_se) % w) - 1 : 0);
+        const int pc = min(max(colw, 0), w - 2);
+        lo[r] = (colw < 0); hi[r] = (colw > w - 2);
+        pn[r] = row_n * w + pc; ps[r] = row_s * w + pc;
+        const B2 mn = *reinterpret_cast<const B2*>(sm + pn[r]); const B2 ms = *reinterpret_cast<const B2*>(sm + ps[r]);
+        mv[r][0] = hi[r] ? mn.b : mn.a; mv[r][1] = lo[r] ? mn.a : mn.b; mv[r][2] = hi[r] ? ms.b : ms.a; mv[r][3] = lo[r] ? ms.a : ms.b;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* __restrict__ sp = sb + c * hw;
+            const F2 a = *reinterpret_cast<const F2*>(sp + pn[r]); const F2 b = *reinterpret_cast<const F2*>(sp + ps[r]);
+            val[r][c][0] = hi[r] ? a.b : a.a; val[r][c][1] = lo[r] ? a.a : a.b; val[r][c][2] = hi[r] ? b.b : b.a; val[r][c][3] = lo[r] ? b.a : b.b;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const bool ok = (x < w) && (y0 + r < h);
+        const Taps& q = t[r];
+        const float m = blend(q.k_nw ? (float)(mv[r][0] != 0) : 0.f, q.k_ne ? (float)(mv[r][1] != 0) : 0.f,
+                              q.k_sw ? (float)(mv[r][2] != 0) : 0.f, q.k_se ? (float)(mv[r][3] != 0) : 0.f, q);
+        if (ok) p.valid[n * hw + pixc[r]] = (uint8_t)((m > 0.99999f) && (fmv[r] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float o = blend(q.k_nw ? val[r][c][0] : 0.f, q.k_ne ? val[r][c][1] : 0.f, q.k_sw ? val[r][c][2] : 0.f,
+                                  q.k_se ? val[r][c][3] : 0.f, q);
+            if (ok) db[c * hw + pixc[r]] = o;
+        }
+    }
+    }
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v5p(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    for (unsigned tile_it = 0;; ++tile_it) {
+    int tx, ty, n;
+    if (!decode_tile_at(p, tile_it, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h, hw = h * w;
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (long)n * 2 * hw; const float* __restrict__ sb = p.src + (long)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (long)n * hw; const uint8_t* __restrict__ fm = p.fmask + (long)n * hw;
+    float* __restrict__ db = p.dst + (long)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (long)n * hw;
+    const int pix = yc * w + xc;
+    const float4 u4 = *reinterpret_cast<const float4*>(fu + pix);
+    const float4 v4 = *reinterpret_cast<const float4*>(fu + hw + pix);
+    const uchar4 f4 = *reinterpret_cast<const uchar4*>(fm + pix);
+    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    const uint8_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    Taps5 t[4];
+    int minx = 0x7fffffff, maxx = -1, miny = 0x7fffffff, maxy = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        t[k] = make_taps5(xc + k, yc, uu[k], vv[k], pp);
+        const Taps5& q = t[k];
+        if (inb && (q.x0 || q.x1) && (q.y0 || q.y1)) {
+            minx = min(minx, q.x0 ? q.ix0 : q.ix1); maxx = max(maxx, q.x1 ? q.ix1 : q.ix0);
+            miny = min(miny, q.y0 ? q.iy0 : q.iy1); maxy = max(maxy, q.y1 ? q.iy1 : q.iy0);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx);
+    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
+    const bool empty = maxx < 0;
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pf = pitch_for(bw, TWQ), Pd = pitch_for(cw, TWQ), Pb = Pd * 4;   // fp32 pitch (floats), byte-plane pitch (dwords / bytes)
+    const int planeF = 4 + bh * Pf;
+    const int nch = bh * cw;
+    const bool fits = !empty && (12 * planeF + 4 + bh * Pb <= lds_bytes) && (nch <= ITERS * NT);
+#ifdef COUNT_FITS
+    if (tid == 0) atomicAdd(&g_fit_count[fits ? 1 : 0], 1ull);
+#endif
+    float* ldsf = reinterpret_cast<float*>(smem);
+    unsigned* ldsm = reinterpret_cast<unsigned*>(smem + (size_t)planeF * 12);
+    const uint8_t* ldsb = smem + (size_t)planeF * 12;
+    if (fits) {
+        const int inv = (int)((1048576 + cw - 1) / cw);      // scalar: once per block
+        int r[ITERS], c4[ITERS]; float4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = tid + it * NT;
+            const bool on = i < nch;
+            r[it] = (int)(((unsigned)i * (unsigned)inv) >> 20); c4[it] = i - r[it] * cw;
+            const int g = on ? (miny + r[it]) * w + bx0 + c4[it] * 4 : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const float4*>(sb + c * hw + g);
+            mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+        }
+        if (tid == 0) { ldsf[0] = 0.f; ldsf[planeF] = 0.f; ldsf[2 * planeF] = 0.f; ldsm[0] = 0u; }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (tid + it * NT < nch) {
+                float* row = ldsf + 4 + r[it] * Pf + c4[it];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    row[c * planeF] = q[it][c].x; row[c * planeF + cw] = q[it][c].y;
+                    row[c * planeF + 2 * cw] = q[it][c].z; row[c * planeF + 3 * cw] = q[it][c].w;
+                }
+                ldsm[1 + r[it] * Pd + c4[it]] = mq[it];
+            }
+        }
+    }
+    __syncthreads();
+    float out[3][4]; uint8_t vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const Taps5& q = t[k];
+        float tv[3][4]; uint8_t tm[4];
+        const bool ok[4] = {q.x0 && q.y0, q.x1 && q.y0, q.x0 && q.y1, q.x1 && q.y1};
+        if (fits) {
+            const int xl0 = q.ix0 - bx0, xl1 = q.ix1 - bx0, yl0 = q.iy0 - miny, yl1 = q.iy1 - miny;
+            const int cp0 = (xl0 & 3) * cw + (xl0 >> 2), cp1 = (xl1 & 3) * cw + (xl1 >> 2);
+            const int rf0 = 4 + yl0 * Pf, rf1 = 4 + yl1 * Pf, rb0 = 4 + yl0 * Pb, rb1 = 4 + yl1 * Pb;
+            const int fi[4] = {ok[0] ? rf0 + cp0 : 0, ok[1] ? rf0 + cp1 : 0, ok[2] ? rf1 + cp0 : 0, ok[3] ? rf1 + cp1 : 0};
+            const int bi[4] = {ok[0] ? rb0 + xl0 : 0, ok[1] ? rb0 + xl1 : 0, ok[2] ? rb1 + xl0 : 0, ok[3] ? rb1 + xl1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tm[j] = ldsb[bi[j]];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tv[c][j] = ldsf[c * planeF + fi[j]];
+            }
+        } else {
+            const int cx[4] = {q.ix0, q.ix1, q.ix0, q.ix1}, cy[4] = {q.iy0, q.iy0, q.iy1, q.iy1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int og = cy[j] * w + cx[j];
+                tm[j] = ok[j] ? sm[og] : (uint8_t)0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tv[c][j] = ok[j] ? sb[c * hw + og] : 0.f;
+            }
+        }
+        const float m = blend5((float)(tm[0] != 0), (float)(tm[1] != 0), (float)(tm[2] != 0), (float)(tm[3] != 0), q);
+        vo[k] = (uint8_t)((m > 0.99999f) && (ff[k] != 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c][k] = blend5(tv[c][0], tv[c][1], tv[c][2], tv[c][3], q);
+    }
+    __syncthreads();   // LDS is reused by the next tile
+    if (inb) {
+        *reinterpret_cast<uchar4*>(vb + pix) = make_uchar4(vo[0], vo[1], vo[2], vo[3]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(db + c * hw + pix) = make_float4(out[c][0], out[c][1], out[c][2], out[c][3]);
+    }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V6: LDS-staged with the 3 image channels + mask INTERLEAVED per pixel in 16-byte LDS slots:
+//   slot(xl, yl) = 1 + yl * P + (xl & 3) * cw + (xl >> 2)      (slot 0 = zeros: every invalid tap points there)
+// one ds_write_b128 per staged pixel, ONE ds_read_b128 per tap (all 4 channels), packed-fp32 coordinate math.
+// ---------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only: global loads / stores stay in flight across it
+// (__syncthreads() carries a workgroup fence = s_waitcnt vmcnt(0), which would drain prefetches and stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f2 exact_div2(f2 a, float b, float y) {
+    const float a0 = fabsf(a.x), a1 = fabsf(a.y);
+    if (__builtin_expect(!(a0 <= 0x1p100f) || (a0 < 0x1p-60f && a0 != 0.0f) || !(a1 <= 0x1p100f) || (a1 < 0x1p-60f && a1 != 0.0f), 0))
+        return (f2){a.x / b, a.y / b};
+    const f2 yy = {y, y}, nb = {-b, -b};
+    f2 q = a * yy;
+    f2 r = __builtin_elementwise_fma(nb, q, a);
+    q = __builtin_elementwise_fma(r, yy, q);
+    r = __builtin_elementwise_fma(nb, q, a);
+    return __builtin_elementwise_fma(r, yy, q);
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v6(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + pix);
+
+    // ---- sample coordinates, two pixels per packed op (reference op order: (x - u)*2 / (w-1) - 1 ; (g + 1) * (w-1)/2)
+    const float xf = (float)xc, yf = (float)yc;
+    const f2 wm1 = {p.wm1, p.wm1}, hwm1 = {p.hwm1, p.hwm1}, hhm1 = {p.hhm1, p.hhm1};
+    f2 sx[2], sy[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        const f2 uu = {u4[2 * j], u4[2 * j + 1]}, vv = {v4[2 * j], v4[2 * j + 1]};
+        f2 gx = exact_div2((xx - uu) * 2.0f, p.wm1, pp.rw) - 1.0f;
+        f2 gy = exact_div2((yy - vv) * 2.0f, p.hm1, pp.rh) - 1.0f;
+        sx[j] = (gx + 1.0f) * hwm1; sy[j] = (gy + 1.0f) * hhm1;
+    }
+    float wgt[4][4]; int ix0[4], iy0[4]; bool x0[4], x1[4], y0[4], y1[4];
+    float fminx = 1e30f, fmaxx = -1e30f, fminy = 1e30f, fmaxy = -1e30f;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sxx = sx[k >> 1][k & 1], syy = sy[k >> 1][k & 1];
+        const float x_w = floorf(sxx), y_n = floorf(syy);
+        const float ww = sxx - x_w, e = 1.0f - ww, nn = syy - y_n, s = 1.0f - nn;
+        wgt[k][0] = s * e; wgt[k][1] = s * ww; wgt[k][2] = nn * e; wgt[k][3] = nn * ww;
+        const float x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+        x0[k] = (x_w > -1.0f) && (x_w < wf); x1[k] = (x_e > -1.0f) && (x_e < wf);
+        y0[k] = (y_n > -1.0f) && (y_n < hf); y1[k] = (y_s > -1.0f) && (y_s < hf);
+        // clamp to [-1, size] BEFORE the int conversion (anything beyond is out of range anyway)
+        const float xcl = fminf(fmaxf(x_w, -1.0f), wf), ycl = fminf(fmaxf(y_n, -1.0f), hf);
+        ix0[k] = (int)xcl; iy0[k] = (int)ycl;
+        if (inb && (x0[k] || x1[k]) && (y0[k] || y1[k])) {
+            // touched columns: [max(x_w,0), min(x_w+1, w-1)], rows likewise
+            fminx = fminf(fminx, fmaxf(xcl, 0.0f)); fmaxx = fmaxf(fmaxx, fminf(xcl + 1.0f, wf - 1.0f));
+            fminy = fminf(fminy, fmaxf(ycl, 0.0f)); fmaxy = fmaxf(fmaxy, fminf(ycl + 1.0f, hf - 1.0f));
+        }
+    }
+    int minx = fminx > 1e29f ? 0x7fffffff : (int)fminx, maxx = fmaxx < -1e29f ? -1 : (int)fmaxx;
+    int miny = fminy > 1e29f ? 0x7fffffff : (int)fminy, maxy = fmaxy < -1e29f ? -1 : (int)fmaxy;
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx);
+    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
+    const bool empty = maxx < 0;
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const unsigned i = (unsigned)tid + it * NT;
+            const bool on = i < (unsigned)nch;
+            const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+            const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+            slot[it] = 1 + (int)(r * (unsigned)Pp + c4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+            mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if ((unsigned)tid + it * NT < (unsigned)nch) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    __syncthreads();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok[4] = {x0[k] && y0[k], x1[k] && y0[k], x0[k] && y1[k], x1[k] && y1[k]};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = ix0[k] - bx0, xl1 = xl0 + 1, yl0 = iy0[k] - miny;
+            const int cp0 = (xl0 & 3) * cw + (xl0 >> 2), cp1 = (xl1 & 3) * cw + (xl1 >> 2);
+            const int r0 = 1 + yl0 * Pp, r1 = r0 + Pp;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = lds[si[j]];
+        } else {
+            const int cx[4] = {ix0[k], ix0[k] + 1, ix0[k], ix0[k] + 1}, cy[4] = {iy0[k], iy0[k], iy0[k] + 1, iy0[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // blend: r = v_nw*nw; r = fma(v_ne, ne, r); r = fma(v_sw, sw, r); r = fma(v_se, se, r)   (per channel)
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v6t(const P5 pp, const int lds_bytes, unsigned long long* stamps) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    unsigned long long ts[8];
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[0] = t_; }
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + pix);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[1] = t_; }
+    // ---- sample coordinates, two pixels per packed op (reference op order: (x - u)*2 / (w-1) - 1 ; (g + 1) * (w-1)/2)
+    const float xf = (float)xc, yf = (float)yc;
+    const f2 wm1 = {p.wm1, p.wm1}, hwm1 = {p.hwm1, p.hwm1}, hhm1 = {p.hhm1, p.hhm1};
+    f2 sx[2], sy[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        const f2 uu = {u4[2 * j], u4[2 * j + 1]}, vv = {v4[2 * j], v4[2 * j + 1]};
+        f2 gx = exact_div2((xx - uu) * 2.0f, p.wm1, pp.rw) - 1.0f;
+        f2 gy = exact_div2((yy - vv) * 2.0f, p.hm1, pp.rh) - 1.0f;
+        sx[j] = (gx + 1.0f) * hwm1; sy[j] = (gy + 1.0f) * hhm1;
+    }
+    float wgt[4][4]; int ix0[4], iy0[4]; bool x0[4], x1[4], y0[4], y1[4];
+    float fminx = 1e30f, fmaxx = -1e30f, fminy = 1e30f, fmaxy = -1e30f;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sxx = sx[k >> 1][k & 1], syy = sy[k >> 1][k & 1];
+        const float x_w = floorf(sxx), y_n = floorf(syy);
+        const float ww = sxx - x_w, e = 1.0f - ww, nn = syy - y_n, s = 1.0f - nn;
+        wgt[k][0] = s * e; wgt[k][1] = s * ww; wgt[k][2] = nn * e; wgt[k][3] = nn * ww;
+        const float x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+        x0[k] = (x_w > -1.0f) && (x_w < wf); x1[k] = (x_e > -1.0f) && (x_e < wf);
+        y0[k] = (y_n > -1.0f) && (y_n < hf); y1[k] = (y_s > -1.0f) && (y_s < hf);
+        // clamp to [-1, size] BEFORE the int conversion (anything beyond is out of range anyway)
+        const float xcl = fminf(fmaxf(x_w, -1.0f), wf), ycl = fminf(fmaxf(y_n, -1.0f), hf);
+        ix0[k] = (int)xcl; iy0[k] = (int)ycl;
+        if (inb && (x0[k] || x1[k]) && (y0[k] || y1[k])) {
+            // touched columns: [max(x_w,0), min(x_w+1, w-1)], rows likewise
+            fminx = fminf(fminx, fmaxf(xcl, 0.0f)); fmaxx = fmaxf(fmaxx, fminf(xcl + 1.0f, wf - 1.0f));
+            fminy = fminf(fminy, fmaxf(ycl, 0.0f)); fmaxy = fmaxf(fmaxy, fminf(ycl + 1.0f, hf - 1.0f));
+        }
+    }
+    int minx = fminx > 1e29f ? 0x7fffffff : (int)fminx, maxx = fmaxx < -1e29f ? -1 : (int)fmaxx;
+    int miny = fminy > 1e29f ? 0x7fffffff : (int)fminy, maxy = fmaxy < -1e29f ? -1 : (int)fmaxy;
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[2] = t_; }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx);
+    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[3] = t_; }
+    const bool empty = maxx < 0;
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const unsigned i = (unsigned)tid + it * NT;
+            const bool on = i < (unsigned)nch;
+            const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+            const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+            slot[it] = 1 + (int)(r * (unsigned)Pp + c4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+            mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[4] = t_; }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if ((unsigned)tid + it * NT < (unsigned)nch) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[5] = t_; }
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok[4] = {x0[k] && y0[k], x1[k] && y0[k], x0[k] && y1[k], x1[k] && y1[k]};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = ix0[k] - bx0, xl1 = xl0 + 1, yl0 = iy0[k] - miny;
+            const int cp0 = (xl0 & 3) * cw + (xl0 >> 2), cp1 = (xl1 & 3) * cw + (xl1 >> 2);
+            const int r0 = 1 + yl0 * Pp, r1 = r0 + Pp;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = lds[si[j]];
+        } else {
+            const int cx[4] = {ix0[k], ix0[k] + 1, ix0[k], ix0[k] + 1}, cy[4] = {iy0[k], iy0[k], iy0[k] + 1, iy0[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // blend: r = v_nw*nw; r = fma(v_ne, ne, r); r = fma(v_sw, sw, r); r = fma(v_se, se, r)   (per channel)
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[6] = t_; }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[7] = t_; }
+    if (tid == 0) { for (int i = 1; i < 8; ++i) atomicAdd(&stamps[(blockIdx.x & 63) * 8 + i], ts[i] - ts[i - 1]); atomicAdd(&stamps[(blockIdx.x & 63) * 8], 1ull); }
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v7(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    // ---- software pipeline: the flow of tile i+1 is loaded while tile i is staged / gathered
+    int ntx, nty, nn;
+    bool have = decode_tile_at(p, 0, ntx, nty, nn);
+    f4 nu4, nv4; unsigned nfm4 = 0;
+    if (have) {
+        const int xq = min(ntx * (TWQ * 4) + lx * 4, w - 4), yq = min(nty * TH + ly, h - 1);
+        const unsigned pq = (unsigned)(yq * w + xq);
+        nu4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + pq);
+        nv4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + hw + pq);
+        nfm4 = *reinterpret_cast<const unsigned*>(p.fmask + (size_t)nn * hw + pq);
+    }
+    for (unsigned tile_it = 1; have; ++tile_it) {
+    const int tx = ntx, ty = nty, n = nn;
+    const f4 u4 = nu4, v4 = nv4; const unsigned fmask4 = nfm4;
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    have = decode_tile_at(p, tile_it, ntx, nty, nn);
+    if (have) {
+        const int xq = min(ntx * (TWQ * 4) + lx * 4, w - 4), yq = min(nty * TH + ly, h - 1);
+        const unsigned pq = (unsigned)(yq * w + xq);
+        nu4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + pq);
+        nv4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + hw + pq);
+        nfm4 = *reinterpret_cast<const unsigned*>(p.fmask + (size_t)nn * hw + pq);
+    }
+
+    // ---- sample coordinates, two pixels per packed op (reference op order: (x - u)*2 / (w-1) - 1 ; (g + 1) * (w-1)/2)
+    const float xf = (float)xc, yf = (float)yc;
+    const f2 wm1 = {p.wm1, p.wm1}, hwm1 = {p.hwm1, p.hwm1}, hhm1 = {p.hhm1, p.hhm1};
+    f2 sx[2], sy[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        const f2 uu = {u4[2 * j], u4[2 * j + 1]}, vv = {v4[2 * j], v4[2 * j + 1]};
+        f2 gx = exact_div2((xx - uu) * 2.0f, p.wm1, pp.rw) - 1.0f;
+        f2 gy = exact_div2((yy - vv) * 2.0f, p.hm1, pp.rh) - 1.0f;
+        sx[j] = (gx + 1.0f) * hwm1; sy[j] = (gy + 1.0f) * hhm1;
+    }
+    float wgt[4][4]; int ix0[4], iy0[4]; bool x0[4], x1[4], y0[4], y1[4];
+    float fminx = 1e30f, fmaxx = -1e30f, fminy = 1e30f, fmaxy = -1e30f;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sxx = sx[k >> 1][k & 1], syy = sy[k >> 1][k & 1];
+        const float x_w = floorf(sxx), y_n = floorf(syy);
+        const float ww = sxx - x_w, e = 1.0f - ww, nn = syy - y_n, s = 1.0f - nn;
+        wgt[k][0] = s * e; wgt[k][1] = s * ww; wgt[k][2] = nn * e; wgt[k][3] = nn * ww;
+        const float x_e = x_w + 1.0f, y_s = y_n + 1.0f;
+        x0[k] = (x_w > -1.0f) && (x_w < wf); x1[k] = (x_e > -1.0f) && (x_e < wf);
+        y0[k] = (y_n > -1.0f) && (y_n < hf); y1[k] = (y_s > -1.0f) && (y_s < hf);
+        // clamp to [-1, size] BEFORE the int conversion (anything beyond is out of range anyway)
+        const float xcl = fminf(fmaxf(x_w, -1.0f), wf), ycl = fminf(fmaxf(y_n, -1.0f), hf);
+        ix0[k] = (int)xcl; iy0[k] = (int)ycl;
+        if (inb && (x0[k] || x1[k]) && (y0[k] || y1[k])) {
+            // touched columns: [max(x_w,0), min(x_w+1, w-1)], rows likewise
+            fminx = fminf(fminx, fmaxf(xcl, 0.0f)); fmaxx = fmaxf(fmaxx, fminf(xcl + 1.0f, wf - 1.0f));
+            fminy = fminf(fminy, fmaxf(ycl, 0.0f)); fmaxy = fmaxf(fmaxy, fminf(ycl + 1.0f, hf - 1.0f));
+        }
+    }
+    int minx = fminx > 1e29f ? 0x7fffffff : (int)fminx, maxx = fmaxx < -1e29f ? -1 : (int)fmaxx;
+    int miny = fminy > 1e29f ? 0x7fffffff : (int)fminy, maxy = fmaxy < -1e29f ? -1 : (int)fmaxy;
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx);
+    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
+    const bool empty = maxx < 0;
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const unsigned i = (unsigned)tid + it * NT;
+            const bool on = i < (unsigned)nch;
+            const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+            const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+            slot[it] = 1 + (int)(r * (unsigned)Pp + c4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+            mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if ((unsigned)tid + it * NT < (unsigned)nch) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    lds_barrier();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok[4] = {x0[k] && y0[k], x1[k] && y0[k], x0[k] && y1[k], x1[k] && y1[k]};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = ix0[k] - bx0, xl1 = xl0 + 1, yl0 = iy0[k] - miny;
+            const int cp0 = (xl0 & 3) * cw + (xl0 >> 2), cp1 = (xl1 & 3) * cw + (xl1 >> 2);
+            const int r0 = 1 + yl0 * Pp, r1 = r0 + Pp;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = lds[si[j]];
+        } else {
+            const int cx[4] = {ix0[k], ix0[k] + 1, ix0[k], ix0[k] + 1}, cy[4] = {iy0[k], iy0[k], iy0[k] + 1, iy0[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // blend: r = v_nw*nw; r = fma(v_ne, ne, r); r = fma(v_sw, sw, r); r = fma(v_se, se, r)   (per channel)
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    lds_barrier();   // LDS (and `red`) are reused by the next tile
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V8: V6 with the VALU trimmed by hand: one wave-uniform slow-path branch for the exact division, integer
+// bounds tests on a clamped int coordinate, bbox over the clamped coordinates (clipped to the image afterwards),
+// byte-offset LDS addressing, only the staging rounds a tile needs.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v8(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + pix);
+
+    // ---- (x - u) * 2 / (w - 1): packed, exact via two Newton refinements on RN(1/(w-1)); operands outside
+    //      [2^-60, 2^100] (never in practice) send the whole wave through the IEEE divide instead
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        // range guard: big operands anywhere, or a tiny non-zero operand (only possible in column 0 / row 0)
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            // integer coordinate of the west / north tap, clamped to [-2, size]: everything beyond is out of range anyway
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]); miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    // touched columns [minx, maxx + 1] and rows [miny, maxy + 1], clipped to the image (all wave-uniform -> SALU)
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    const bool empty = (maxx < minx) || (maxy < miny);
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        const int rounds = (nch + NT - 1) / NT;        // wave-uniform: only the rounds this tile needs are issued
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+                const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+            }
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds && slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    __syncthreads();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+    const int cw16 = cw * 16, P16 = Pp * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // x0 valid <=> 0 <= xi <= w-1 ; x1 valid <=> -1 <= xi <= w-2   (same for y)
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+            // byte offset of slot (xl, yl): 16 + yl*P16 + (xl & 3)*cw16 + (xl >> 2)*16
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+}
+
+template <int NT, int TWQ, int ITERS, int ABL>
+__global__ __launch_bounds__(NT) void warp_v8a(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + pix);
+
+    // ---- (x - u) * 2 / (w - 1): packed, exact via two Newton refinements on RN(1/(w-1)); operands outside
+    //      [2^-60, 2^100] (never in practice) send the whole wave through the IEEE divide instead
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        // range guard: big operands anywhere, or a tiny non-zero operand (only possible in column 0 / row 0)
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            // integer coordinate of the west / north tap, clamped to [-2, size]: everything beyond is out of range anyway
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]); miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+        }
+    }
+    if (ABL == 5) { minx = tx * (TWQ * 4) - 8; maxx = tx * (TWQ * 4) + TWQ * 4 + 8; miny = ty * TH - 8; maxy = ty * TH + TH + 8; }
+    else { minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy); }
+    if (NW > 1 && ABL != 5) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    // touched columns [minx, maxx + 1] and rows [miny, maxy + 1], clipped to the image (all wave-uniform -> SALU)
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    const bool empty = (maxx < minx) || (maxy < miny);
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        const int rounds = (nch + NT - 1) / NT;        // wave-uniform: only the rounds this tile needs are issued
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+                const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)Pp + c4) : -1;
+                if (ABL == 1) { for (int c = 0; c < 3; ++c) q[it][c] = (f4){(float)g, 1.f, 2.f, 3.f}; mq[it] = g; } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g); }
+            }
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (ABL != 2 && it < rounds && slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    __syncthreads();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+    const int cw16 = cw * 16, P16 = Pp * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // x0 valid <=> 0 <= xi <= w-1 ; x1 valid <=> -1 <= xi <= w-2   (same for y)
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+            // byte offset of slot (xl, yl): 16 + yl*P16 + (xl & 3)*cw16 + (xl >> 2)*16
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = ABL == 3 ? (f4){(float)si[j], 1.f, 2.f, 1.f} : *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        if (ABL != 4 || vo == 0x12345678u) {
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V9: direct gather with pair loads (V3) but the streaming traffic vectorised: a wave owns a 64 x ROWS patch, loads the
+// flow with 16-byte loads (lane j <-> row j/16, columns 4*(j%16)..+3), transposes it through LDS so that in round k lane i
+// handles pixel (column i, row k) -- tap addresses are then lane-consecutive -- and transposes the results back for
+// 16-byte stores.  LDS is only a 5 KB/wave transposition buffer: no bounding box, no fallback, full occupancy.
+// ---------------------------------------------------------------------------------------------
+template <int NWAVES>   // waves per block, each wave an independent 64 x 4 patch; block tile = 64 x (4 * NWAVES)
+__global__ __launch_bounds__(64 * NWAVES) void warp_v9(const P5 pp) {
+    __shared__ __attribute__((aligned(16))) float xbuf[NWAVES][4][4 * 64];   // per wave: u, v in; reused for c0..c2 + mask out
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const int xbase = tx * 64, ybase = ty * (4 * NWAVES) + wave * 4;
+    // ---- vector phase mapping: lane j -> (row j >> 4, columns 4 * (j & 15) .. + 3)
+    const int vr = lane >> 4, vx = xbase + (lane & 15) * 4;
+    const bool vin = (vx < w) && (ybase + vr < h);
+    const unsigned vpix = (unsigned)(min(ybase + vr, h - 1) * w + min(vx, w - 4));
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + vpix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + vpix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + vpix);
+    float (*xb)[4 * 64] = xbuf[wave];
+    *reinterpret_cast<f4*>(&xb[0][lane * 4]) = u4;
+    *reinterpret_cast<f4*>(&xb[1][lane * 4]) = v4;
+    // (single wave reads what it wrote: LDS ops of one wave complete in order; the compiler inserts the lgkmcnt wait)
+    // ---- gather phase: round k = row k, lane i = column xbase + i
+    const int gx = min(xbase + lane, w - 1);
+    float outc[4][3]; float outm[4];
+    const float wf = (float)w, hf = (float)h;
+    const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float y0f = (float)min(ybase + 2 * j, h - 1), y1f = (float)min(ybase + 2 * j + 1, h - 1);
+        const f2 uu = {xb[0][(2 * j) * 64 + lane], xb[0][(2 * j + 1) * 64 + lane]};
+        const f2 vv = {xb[1][(2 * j) * 64 + lane], xb[1][(2 * j + 1) * 64 + lane]};
+        ax[j] = ((f2){(float)gx, (float)gx} - uu) * 2.0f;
+        ay[j] = ((f2){y0f, y1f} - vv) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+        r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+        q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+        r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+    }
+    {
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (gx == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ax[k >> 1][k & 1]) < 0x1p-60f) && (ax[k >> 1][k & 1] != 0.0f);
+        }
+        if (ybase == 0) bad |= (fabsf(ay[0].x) < 0x1p-60f) && (ay[0].x != 0.0f);
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+        }
+    }
+    // all pair loads of the 4 rounds are issued before the first use
+    F2 pa[4][3], pb[4][3]; B2 ma[4], mb[4]; bool lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pc = min(max(xi[k], 0), w - 2);
+        lo[k] = xi[k] < 0; hi[k] = xi[k] > w - 2;
+        const unsigned on = (unsigned)(min(max(yi[k], 0), h - 1) * w + pc), os = (unsigned)(min(max(yi[k] + 1, 0), h - 1) * w + pc);
+        ma[k] = *reinterpret_cast<const B2*>(sm + on); mb[k] = *reinterpret_cast<const B2*>(sm + os);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pa[k][c] = *reinterpret_cast<const F2*>(sb + c * hw + on); pb[k][c] = *reinterpret_cast<const F2*>(sb + c * hw + os);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool k_nw = x0 && y0, k_ne = x1 && y0, k_sw = x0 && y1, k_se = x1 && y1;
+        const float m_nw = k_nw ? (float)((hi[k] ? ma[k].b : ma[k].a) != 0) : 0.f, m_ne = k_ne ? (float)((lo[k] ? ma[k].a : ma[k].b) != 0) : 0.f;
+        const float m_sw = k_sw ? (float)((hi[k] ? mb[k].b : mb[k].a) != 0) : 0.f, m_se = k_se ? (float)((lo[k] ? mb[k].a : mb[k].b) != 0) : 0.f;
+        float m = m_nw * wgt[k][0]; m = __builtin_fmaf(m_ne, wgt[k][1], m); m = __builtin_fmaf(m_sw, wgt[k][2], m); m = __builtin_fmaf(m_se, wgt[k][3], m);
+        outm[k] = m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v_nw = k_nw ? (hi[k] ? pa[k][c].b : pa[k][c].a) : 0.f, v_ne = k_ne ? (lo[k] ? pa[k][c].a : pa[k][c].b) : 0.f;
+            const float v_sw = k_sw ? (hi[k] ? pb[k][c].b : pb[k][c].a) : 0.f, v_se = k_se ? (lo[k] ? pb[k][c].a : pb[k][c].b) : 0.f;
+            float r = v_nw * wgt[k][0]; r = __builtin_fmaf(v_ne, wgt[k][1], r); r = __builtin_fmaf(v_sw, wgt[k][2], r); r = __builtin_fmaf(v_se, wgt[k][3], r);
+            outc[k][c] = r;
+        }
+    }
+    // ---- transpose back: round-k results of lane i -> xb[c][k*64 + i]; vector lane j reads 4 consecutive columns of its row
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xb[c][k * 64 + lane] = outc[k][c];
+        xb[3][k * 64 + lane] = outm[k];
+    }
+    if (vin) {
+        const f4 mm = *reinterpret_cast<const f4*>(&xb[3][lane * 4]);
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo |= (unsigned)((mm[k] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + vpix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4*>(db + c * hw + vpix) = *reinterpret_cast<const f4*>(&xb[c][lane * 4]);
+    }
+}
+
+template <int NWAVES, int ABL>   // ablation build; waves per block, each wave an independent 64 x 4 patch; block tile = 64 x (4 * NWAVES)
+__global__ __launch_bounds__(64 * NWAVES) void warp_v9a(const P5 pp) {
+    __shared__ __attribute__((aligned(16))) float xbuf[NWAVES][4][4 * 64];   // per wave: u, v in; reused for c0..c2 + mask out
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const int xbase = tx * 64, ybase = ty * (4 * NWAVES) + wave * 4;
+    // ---- vector phase mapping: lane j -> (row j >> 4, columns 4 * (j & 15) .. + 3)
+    const int vr = lane >> 4, vx = xbase + (lane & 15) * 4;
+    const bool vin = (vx < w) && (ybase + vr < h);
+    const unsigned vpix = (unsigned)(min(ybase + vr, h - 1) * w + min(vx, w - 4));
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + vpix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + vpix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + vpix);
+    float (*xb)[4 * 64] = xbuf[wave];
+    *reinterpret_cast<f4*>(&xb[0][lane * 4]) = u4;
+    *reinterpret_cast<f4*>(&xb[1][lane * 4]) = v4;
+    // (single wave reads what it wrote: LDS ops of one wave complete in order; the compiler inserts the lgkmcnt wait)
+    // ---- gather phase: round k = row k, lane i = column xbase + i
+    const int gx = min(xbase + lane, w - 1);
+    float outc[4][3]; float outm[4];
+    const float wf = (float)w, hf = (float)h;
+    const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float y0f = (float)min(ybase + 2 * j, h - 1), y1f = (float)min(ybase + 2 * j + 1, h - 1);
+        const f2 uu = {xb[0][(2 * j) * 64 + lane], xb[0][(2 * j + 1) * 64 + lane]};
+        const f2 vv = {xb[1][(2 * j) * 64 + lane], xb[1][(2 * j + 1) * 64 + lane]};
+        ax[j] = ((f2){(float)gx, (float)gx} - uu) * 2.0f;
+        ay[j] = ((f2){y0f, y1f} - vv) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+        r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+        q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+        r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+    }
+    {
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (gx == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ax[k >> 1][k & 1]) < 0x1p-60f) && (ax[k >> 1][k & 1] != 0.0f);
+        }
+        if (ybase == 0) bad |= (fabsf(ay[0].x) < 0x1p-60f) && (ay[0].x != 0.0f);
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+        }
+    }
+    // all pair loads of the 4 rounds are issued before the first use
+    F2 pa[4][3], pb[4][3]; B2 ma[4], mb[4]; bool lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pc = min(max(xi[k], 0), w - 2);
+        lo[k] = xi[k] < 0; hi[k] = xi[k] > w - 2;
+        const unsigned on = (unsigned)(min(max(yi[k], 0), h - 1) * w + pc), os = (unsigned)(min(max(yi[k] + 1, 0), h - 1) * w + pc);
+        if (ABL == 1) {
+            ma[k].a = ma[k].b = mb[k].a = mb[k].b = 1;
+            for (int c = 0; c < 3; ++c) { pa[k][c].a = pa[k][c].b = pb[k][c].a = pb[k][c].b = (float)on; }
+        } else {
+            const unsigned on_ = ABL == 3 ? ((unsigned)(min(ybase + k, h - 1) * w + gx) & ~1u) : on;
+            const unsigned os_ = ABL == 3 ? on_ : os;
+            ma[k] = *reinterpret_cast<const B2*>(sm + on_); mb[k] = *reinterpret_cast<const B2*>(sm + os_);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pa[k][c] = *reinterpret_cast<const F2*>(sb + c * hw + on_); pb[k][c] = *reinterpret_cast<const F2*>(sb + c * hw + os_);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool k_nw = x0 && y0, k_ne = x1 && y0, k_sw = x0 && y1, k_se = x1 && y1;
+        const float m_nw = k_nw ? (float)((hi[k] ? ma[k].b : ma[k].a) != 0) : 0.f, m_ne = k_ne ? (float)((lo[k] ? ma[k].a : ma[k].b) != 0) : 0.f;
+        const float m_sw = k_sw ? (float)((hi[k] ? mb[k].b : mb[k].a) != 0) : 0.f, m_se = k_se ? (float)((lo[k] ? mb[k].a : mb[k].b) != 0) : 0.f;
+        float m = m_nw * wgt[k][0]; m = __builtin_fmaf(m_ne, wgt[k][1], m); m = __builtin_fmaf(m_sw, wgt[k][2], m); m = __builtin_fmaf(m_se, wgt[k][3], m);
+        outm[k] = m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v_nw = k_nw ? (hi[k] ? pa[k][c].b : pa[k][c].a) : 0.f, v_ne = k_ne ? (lo[k] ? pa[k][c].a : pa[k][c].b) : 0.f;
+            const float v_sw = k_sw ? (hi[k] ? pb[k][c].b : pb[k][c].a) : 0.f, v_se = k_se ? (lo[k] ? pb[k][c].a : pb[k][c].b) : 0.f;
+            float r = v_nw * wgt[k][0]; r = __builtin_fmaf(v_ne, wgt[k][1], r); r = __builtin_fmaf(v_sw, wgt[k][2], r); r = __builtin_fmaf(v_se, wgt[k][3], r);
+            outc[k][c] = r;
+        }
+    }
+    // ---- transpose back: round-k results of lane i -> xb[c][k*64 + i]; vector lane j reads 4 consecutive columns of its row
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xb[c][k * 64 + lane] = outc[k][c];
+        xb[3][k * 64 + lane] = outm[k];
+    }
+    if (vin) {
+        const f4 mm = *reinterpret_cast<const f4*>(&xb[3][lane * 4]);
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo |= (unsigned)((mm[k] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        if (ABL != 2 || vo == 0x12345678u) {
+        *reinterpret_cast<unsigned*>(vb + vpix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4*>(db + c * hw + vpix) = *reinterpret_cast<const f4*>(&xb[c][lane * 4]);
+        }
+    }
+}
+
+template <int NWAVES>   // waves per block, each wave an independent 64 x 4 patch; block tile = 64 x (4 * NWAVES)
+__global__ __launch_bounds__(64 * NWAVES) void warp_v10(const P5 pp) {
+    __shared__ __attribute__((aligned(16))) float xbuf[NWAVES][4][4 * 64];   // per wave: u, v in; reused for c0..c2 + mask out
+    const P& p = pp.p;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int vr = lane >> 4;
+    float (*xb)[4 * 64] = xbuf[wave];
+    // ---- software pipeline over the tiles of this (persistent) block: the flow of tile i+1 is in flight while the
+    //      taps of tile i are gathered, so every wave always has both kinds of load outstanding
+    int ntx, nty, nn;
+    bool have = decode_tile_at(p, 0, ntx, nty, nn);
+    f4 nu4, nv4; unsigned nfm4 = 0, nvpix = 0;
+    if (have) {
+        const int vx_ = ntx * 64 + (lane & 15) * 4, yb_ = nty * (4 * NWAVES) + wave * 4;
+        nvpix = (unsigned)(min(yb_ + vr, h - 1) * w + min(vx_, w - 4));
+        nu4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + nvpix);
+        nv4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + hw + nvpix);
+        nfm4 = *reinterpret_cast<const unsigned*>(p.fmask + (size_t)nn * hw + nvpix);
+    }
+    for (unsigned tile_it = 1; have; ++tile_it) {
+    const int tx = ntx, ty = nty, n = nn;
+    const f4 u4 = nu4, v4 = nv4; const unsigned fmask4 = nfm4, vpix = nvpix;
+    const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const int xbase = tx * 64, ybase = ty * (4 * NWAVES) + wave * 4;
+    const int vx = xbase + (lane & 15) * 4;
+    const bool vin = (vx < w) && (ybase + vr < h);
+    *reinterpret_cast<f4*>(&xb[0][lane * 4]) = u4;
+    *reinterpret_cast<f4*>(&xb[1][lane * 4]) = v4;
+    // (single wave reads what it wrote: LDS ops of one wave complete in order; the compiler inserts the lgkmcnt wait)
+    // ---- gather phase: round k = row k, lane i = column xbase + i
+    const int gx = min(xbase + lane, w - 1);
+    float outc[4][3]; float outm[4];
+    const float wf = (float)w, hf = (float)h;
+    const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float y0f = (float)min(ybase + 2 * j, h - 1), y1f = (float)min(ybase + 2 * j + 1, h - 1);
+        const f2 uu = {xb[0][(2 * j) * 64 + lane], xb[0][(2 * j + 1) * 64 + lane]};
+        const f2 vv = {xb[1][(2 * j) * 64 + lane], xb[1][(2 * j + 1) * 64 + lane]};
+        ax[j] = ((f2){(float)gx, (float)gx} - uu) * 2.0f;
+        ay[j] = ((f2){y0f, y1f} - vv) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+        r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+        q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+        r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+    }
+    {
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (gx == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ax[k >> 1][k & 1]) < 0x1p-60f) && (ax[k >> 1][k & 1] != 0.0f);
+        }
+        if (ybase == 0) bad |= (fabsf(ay[0].x) < 0x1p-60f) && (ay[0].x != 0.0f);
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+        }
+    }
+    // all pair loads of the 4 rounds are issued before the first use
+    F2 pa[4][3], pb[4][3]; B2 ma[4], mb[4]; bool lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pc = min(max(xi[k], 0), w - 2);
+        lo[k] = xi[k] < 0; hi[k] = xi[k] > w - 2;
+        const unsigned on = (unsigned)(min(max(yi[k], 0), h - 1) * w + pc), os = (unsigned)(min(max(yi[k] + 1, 0), h - 1) * w + pc);
+        ma[k] = *reinterpret_cast<const B2*>(sm + on); mb[k] = *reinterpret_cast<const B2*>(sm + os);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pa[k][c] = *reinterpret_cast<const F2*>(sb + c * hw + on); pb[k][c] = *reinterpret_cast<const F2*>(sb + c * hw + os);
+        }
+    }
+    have = decode_tile_at(p, tile_it, ntx, nty, nn);
+    if (have) {
+        const int vx_ = ntx * 64 + (lane & 15) * 4, yb_ = nty * (4 * NWAVES) + wave * 4;
+        nvpix = (unsigned)(min(yb_ + vr, h - 1) * w + min(vx_, w - 4));
+        nu4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + nvpix);
+        nv4 = *reinterpret_cast<const f4*>(p.flow + (size_t)nn * 2 * hw + hw + nvpix);
+        nfm4 = *reinterpret_cast<const unsigned*>(p.fmask + (size_t)nn * hw + nvpix);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool k_nw = x0 && y0, k_ne = x1 && y0, k_sw = x0 && y1, k_se = x1 && y1;
+        const float m_nw = k_nw ? (float)((hi[k] ? ma[k].b : ma[k].a) != 0) : 0.f, m_ne = k_ne ? (float)((lo[k] ? ma[k].a : ma[k].b) != 0) : 0.f;
+        const float m_sw = k_sw ? (float)((hi[k] ? mb[k].b : mb[k].a) != 0) : 0.f, m_se = k_se ? (float)((lo[k] ? mb[k].a : mb[k].b) != 0) : 0.f;
+        float m = m_nw * wgt[k][0]; m = __builtin_fmaf(m_ne, wgt[k][1], m); m = __builtin_fmaf(m_sw, wgt[k][2], m); m = __builtin_fmaf(m_se, wgt[k][3], m);
+        outm[k] = m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v_nw = k_nw ? (hi[k] ? pa[k][c].b : pa[k][c].a) : 0.f, v_ne = k_ne ? (lo[k] ? pa[k][c].a : pa[k][c].b) : 0.f;
+            const float v_sw = k_sw ? (hi[k] ? pb[k][c].b : pb[k][c].a) : 0.f, v_se = k_se ? (lo[k] ? pb[k][c].a : pb[k][c].b) : 0.f;
+            float r = v_nw * wgt[k][0]; r = __builtin_fmaf(v_ne, wgt[k][1], r); r = __builtin_fmaf(v_sw, wgt[k][2], r); r = __builtin_fmaf(v_se, wgt[k][3], r);
+            outc[k][c] = r;
+        }
+    }
+    // ---- transpose back: round-k results of lane i -> xb[c][k*64 + i]; vector lane j reads 4 consecutive columns of its row
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xb[c][k * 64 + lane] = outc[k][c];
+        xb[3][k * 64 + lane] = outm[k];
+    }
+    if (vin) {
+        const f4 mm = *reinterpret_cast<const f4*>(&xb[3][lane * 4]);
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo |= (unsigned)((mm[k] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + vpix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4*>(db + c * hw + vpix) = *reinterpret_cast<const f4*>(&xb[c][lane * 4]);
+    }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V11: V8 as a persistent, software-pipelined block: while tile i is gathered from LDS, the staging loads of tile
+// i+1 (registers) and the flow of tile i+2 are in flight and the stores of tile i-1 drain.  LDS-only barriers.
+// ---------------------------------------------------------------------------------------------
+struct TileTaps { float wgt[4][4]; int xi[4], yi[4]; };
+struct TileBox { int bx0, miny, cw, Pp, bh, nch; bool fits, empty; };   // wave-uniform
+struct TileId { int tx, ty, n; bool have; };
+
+template <int NT, int TWQ>
+__device__ __forceinline__ void v11_load_flow(const P& p, const TileId& t, unsigned hw, f4& u4, f4& v4, unsigned& fm4, unsigned& pix, bool& inb) {
+    constexpr int TH = NT / TWQ;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int x4 = t.tx * (TWQ * 4) + lx * 4, y = t.ty * TH + ly;
+    inb = (x4 < p.w) && (y < p.h);
+    pix = (unsigned)(min(y, p.h - 1) * p.w + min(x4, p.w - 4));
+    u4 = *reinterpret_cast<const f4*>(p.flow + (size_t)t.n * 2 * hw + pix);
+    v4 = *reinterpret_cast<const f4*>(p.flow + (size_t)t.n * 2 * hw + hw + pix);
+    fm4 = *reinterpret_cast<const unsigned*>(p.fmask + (size_t)t.n * hw + pix);
+}
+
+template <int NT, int TWQ, int ITERS>
+__device__ __forceinline__ void v11_taps(const P5& pp, const TileId& t, const f4& u4, const f4& v4, TileTaps& T, TileBox& B,
+                                         int (*red)[4], const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    const P& p = pp.p;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const int xc = min(t.tx * (TWQ * 4) + lx * 4, w - 4), yc = min(t.ty * TH + ly, h - 1);
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            T.wgt[k][0] = wnw[i]; T.wgt[k][1] = wne[i]; T.wgt[k][2] = wsw[i]; T.wgt[k][3] = wse[i];
+            T.xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            T.yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, T.xi[k]); maxx = max(maxx, T.xi[k]); miny = min(miny, T.yi[k]); maxy = max(maxy, T.yi[k]);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    B.empty = (maxx < minx) || (maxy < miny);
+    B.bx0 = minx & ~3; B.miny = miny;
+    const int bw = B.empty ? 4 : (((maxx + 4) & ~3) - B.bx0);
+    B.bh = B.empty ? 1 : (maxy - miny + 1); B.cw = bw >> 2; B.Pp = pitch_for(bw, TWQ); B.nch = B.bh * B.cw;
+    B.fits = !B.empty && (16 * (1 + B.bh * B.Pp) <= lds_bytes) && (B.nch <= ITERS * NT);
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v11(const P5 pp, const int lds_bytes) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[2][NW][4];
+    const P& p = pp.p;
+    const int tid = threadIdx.x;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    f4* lds = reinterpret_cast<f4*>(smem);
+
+    TileId tc, tn, tnn;                    // current, next, next-next
+    tc.have = decode_tile_at(p, 0, tc.tx, tc.ty, tc.n);
+    if (!tc.have) return;
+    f4 u4, v4; unsigned fm_c, pix_c; bool inb_c;
+    v11_load_flow<NT, TWQ>(p, tc, hw, u4, v4, fm_c, pix_c, inb_c);
+    TileTaps Tc; TileBox Bc;
+    v11_taps<NT, TWQ, ITERS>(pp, tc, u4, v4, Tc, Bc, red[0], lds_bytes);
+    // staging registers of the CURRENT tile (loaded one iteration ahead)
+    int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+    auto issue_staging = [&](const TileId& t, const TileBox& B) {
+        const float* __restrict__ sb = p.src + (size_t)t.n * 3 * hw; const uint8_t* __restrict__ sm = p.smask + (size_t)t.n * hw;
+        const unsigned inv = (1048576u + (unsigned)B.cw - 1u) / (unsigned)B.cw;
+        const int rounds = B.fits ? (B.nch + NT - 1) / NT : 0;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            slot[it] = -1;
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)B.nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)B.cw;
+                const unsigned g = on ? (unsigned)((B.miny + (int)r) * w + B.bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)B.Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+            }
+        }
+    };
+    issue_staging(tc, Bc);
+    tn.have = decode_tile_at(p, 1, tn.tx, tn.ty, tn.n);
+    f4 nu4, nv4; unsigned fm_n = 0, pix_n = 0; bool inb_n = false;
+    if (tn.have) v11_load_flow<NT, TWQ>(p, tn, hw, nu4, nv4, fm_n, pix_n, inb_n);
+
+    for (unsigned it_tile = 2;; ++it_tile) {
+        // ---- (1) staged registers of the current tile -> LDS
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * Bc.cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+        lds_barrier();
+        // ---- (2) next tile: taps + bbox from its (prefetched) flow, issue its staging loads, prefetch the flow after it
+        TileTaps Tn; TileBox Bn; f4 nnu4, nnv4; unsigned fm_nn = 0, pix_nn = 0; bool inb_nn = false;
+        if (tn.have) {
+            v11_taps<NT, TWQ, ITERS>(pp, tn, nu4, nv4, Tn, Bn, red[it_tile & 1], lds_bytes);
+            issue_staging(tn, Bn);
+            tnn.have = decode_tile_at(p, it_tile, tnn.tx, tnn.ty, tnn.n);
+            if (tnn.have) v11_load_flow<NT, TWQ>(p, tnn, hw, nnu4, nnv4, fm_nn, pix_nn, inb_nn);
+        } else {
+            tnn.have = false;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) slot[it] = -1;
+        }
+        // ---- (3) gather the current tile from LDS, blend, store
+        {
+            const float* __restrict__ sb = p.src + (size_t)tc.n * 3 * hw; const uint8_t* __restrict__ sm = p.smask + (size_t)tc.n * hw;
+            float* __restrict__ db = p.dst + (size_t)tc.n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)tc.n * hw;
+            const int cw16 = Bc.cw * 16, P16 = Bc.Pp * 16;
+            f4 outv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool x0 = (unsigned)Tc.xi[k] < (unsigned)w, x1 = (unsigned)(Tc.xi[k] + 1) < (unsigned)w;
+                const bool y0 = (unsigned)Tc.yi[k] < (unsigned)h, y1 = (unsigned)(Tc.yi[k] + 1) < (unsigned)h;
+                const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+                f4 tv[4];
+                if (Bc.fits) {
+                    const int xl0 = Tc.xi[k] - Bc.bx0, xl1 = xl0 + 1;
+                    const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+                    const int r0 = 16 + (Tc.yi[k] - Bc.miny) * P16, r1 = r0 + P16;
+                    const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+                } else {
+                    const int cx[4] = {Tc.xi[k], Tc.xi[k] + 1, Tc.xi[k], Tc.xi[k] + 1}, cy[4] = {Tc.yi[k], Tc.yi[k], Tc.yi[k] + 1, Tc.yi[k] + 1};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                        tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                f4 r = tv[0] * Tc.wgt[k][0];
+                r = __builtin_elementwise_fma(tv[1], (f4){Tc.wgt[k][1], Tc.wgt[k][1], Tc.wgt[k][1], Tc.wgt[k][1]}, r);
+                r = __builtin_elementwise_fma(tv[2], (f4){Tc.wgt[k][2], Tc.wgt[k][2], Tc.wgt[k][2], Tc.wgt[k][2]}, r);
+                r = __builtin_elementwise_fma(tv[3], (f4){Tc.wgt[k][3], Tc.wgt[k][3], Tc.wgt[k][3], Tc.wgt[k][3]}, r);
+                outv[k] = r;
+            }
+            if (inb_c) {
+                unsigned vo = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fm_c >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+                *reinterpret_cast<unsigned*>(vb + pix_c) = vo;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<f4*>(db + c * hw + pix_c) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+            }
+        }
+        if (!tn.have) break;
+        lds_barrier();       // every wave is done reading LDS before the next tile overwrites it
+        // ---- rotate
+        tc = tn; Tc = Tn; Bc = Bn; fm_c = fm_n; pix_c = pix_n; inb_c = inb_n;
+        tn = tnn; nu4 = nnu4; nv4 = nnv4; fm_n = fm_nn; pix_n = pix_nn; inb_n = inb_nn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming ceilings with the same byte mix (no gather): dword-per-lane and 16-byte-per-lane
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_dword(const P p) {
+    const long hw = (long)p.h * p.w, tot = (long)p.n * hw;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+        const long n = i / hw, pix = i - n * hw;
+        const float u = p.flow[n * 2 * hw + pix], v = p.flow[n * 2 * hw + hw + pix];
+        const uint8_t a = p.smask[i], b = p.fmask[i];
+        p.valid[i] = (uint8_t)((a != 0) && (b != 0) && (u + v != 12345.f));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p.dst[n * 3 * hw + c * hw + pix] = p.src[n * 3 * hw + c * hw + pix] + u;
+    }
+}
+
+__global__ __launch_bounds__(256) void stream_vec4(const P p) {
+    const long hw = (long)p.h * p.w, tot4 = (long)p.n * hw / 4, hw4 = hw / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot4; i += (long)gridDim.x * 256) {
+        const long n = i / hw4, pix = (i - n * hw4) * 4;
+        const float4 u = *reinterpret_cast<const float4*>(p.flow + n * 2 * hw + pix);
+        const float4 v = *reinterpret_cast<const float4*>(p.flow + n * 2 * hw + hw + pix);
+        const uchar4 a = *reinterpret_cast<const uchar4*>(p.smask + n * hw + pix);
+        const uchar4 b = *reinterpret_cast<const uchar4*>(p.fmask + n * hw + pix);
+        *reinterpret_cast<uchar4*>(p.valid + n * hw + pix) =
+            make_uchar4(a.x && b.x && (v.x != 12345.f), a.y && b.y, a.z && b.z, a.w && b.w);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float4 s = *reinterpret_cast<const float4*>(p.src + n * 3 * hw + c * hw + pix);
+            s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+            *reinterpret_cast<float4*>(p.dst + n * 3 * hw + c * hw + pix) = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static void fill_smooth(std::vector<float>& f, int n, int h, int w, float sigma, unsigned seed) {
+    // low-res gaussian-ish noise (sum of uniforms) on a 40-px lattice, bilinear up-sampled
+    const int lh = h / 40 + 2, lw = w / 40 + 2;
+    srand(seed);
+    std::vector<float> lo((size_t)n * 2 * lh * lw);
+    for (auto& x : lo) { float s = 0; for (int k = 0; k < 12; ++k) s += rand() / (float)RAND_MAX; x = (s - 6.f) * sigma; }
+    for (int b = 0; b < n; ++b) for (int c = 0; c < 2; ++c) for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        const float fy = y / 40.f, fx = x / 40.f; const int iy = (int)fy, ix = (int)fx; const float ay = fy - iy, ax = fx - ix;
+        const float* L = &lo[((size_t)(b * 2 + c) * lh) * lw];
+        f[((size_t)(b * 2 + c) * h + y) * w + x] = (1 - ay) * ((1 - ax) * L[iy * lw + ix] + ax * L[iy * lw + ix + 1]) +
+                                                   ay * ((1 - ax) * L[(iy + 1) * lw + ix] + ax * L[(iy + 1) * lw + ix + 1]);
+    }
+}
+
+template <typename F>
+static float time_it(F launch, int iters) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 16, h = 1080, w = 1920;
+    const float sigma = argc > 2 ? atof(argv[2]) : 8.f;
+    const char* only = argc > 3 ? argv[3] : "";
+    const size_t hw = (size_t)h * w, px = (size_t)n * hw;
+    std::vector<float> flow(px * 2), src(px * 3);
+    std::vector<uint8_t> sm(px), fm(px);
+    fill_smooth(flow, n, h, w, sigma, 1);
+    for (size_t i = 0; i < src.size(); ++i) src[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 256.f;
+    for (size_t i = 0; i < px; ++i) { sm[i] = ((i / w) % 200) > 10; fm[i] = ((i % w) % 300) > 20; }
+    P p; memset(&p, 0, sizeof(p));
+    float *dflow, *dsrc, *ddst, *dref; uint8_t *dsm, *dfm, *dval, *dvref;
+    CK(hipMalloc(&dflow, px * 8)); CK(hipMalloc(&dsrc, px * 12)); CK(hipMalloc(&ddst, px * 12)); CK(hipMalloc(&dref, px * 12));
+    CK(hipMalloc(&dsm, px)); CK(hipMalloc(&dfm, px)); CK(hipMalloc(&dval, px)); CK(hipMalloc(&dvref, px));
+    CK(hipMemcpy(dflow, flow.data(), px * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dsrc, src.data(), px * 12, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsm, sm.data(), px, hipMemcpyHostToDevice)); CK(hipMemcpy(dfm, fm.data(), px, hipMemcpyHostToDevice));
+    p.flow = dflow; p.src = dsrc; p.smask = dsm; p.fmask = dfm; p.n = n; p.h = h; p.w = w;
+    p.wm1 = w - 1; p.hm1 = h - 1; p.hwm1 = p.wm1 / 2.f; p.hhm1 = p.hm1 / 2.f;
+    const double bytes = 35.0 * px;
+    auto magic = [](unsigned d, unsigned& m, unsigned& s) {   // d >= 1
+        unsigned l = 0; while ((1ull << l) < d) ++l;
+        m = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1); s = ((l ? 1u : 0u) << 16) | (l ? l - 1 : 0);
+    };
+    auto grid_for = [&](int tw, int th) {
+        p.tiles_x = (w + tw - 1) / tw; p.tiles_y = (h + th - 1) / th; p.total = (long)p.tiles_x * p.tiles_y * n;
+        p.per_xcd = (p.total + 7) / 8; p.tiles_img = p.tiles_x * p.tiles_y;
+        magic(p.tiles_x, p.mx_m, p.mx_s); magic(p.tiles_img, p.mi_m, p.mi_s);
+        return (unsigned)(p.per_xcd * 8);
+    };
+    // reference result: V0
+    p.dst = dref; p.valid = dvref;
+    { unsigned g = grid_for(64, 16); hipLaunchKernelGGL(warp_v0<4>, dim3(g), dim3(256), 0, 0, p); CK(hipDeviceSynchronize()); }
+    std::vector<float> ref(px * 3), got(px * 3); std::vector<uint8_t> vref(px), vgot(px);
+    CK(hipMemcpy(ref.data(), dref, px * 12, hipMemcpyDeviceToHost)); CK(hipMemcpy(vref.data(), dvref, px, hipMemcpyDeviceToHost));
+    p.dst = ddst; p.valid = dval;
+    auto check = [&](const char* name) {
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), ddst, px * 12, hipMemcpyDeviceToHost)); CK(hipMemcpy(vgot.data(), dval, px, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < got.size(); ++i) bad += memcmp(&got[i], &ref[i], 4) != 0;
+        size_t badm = 0; for (size_t i = 0; i < px; ++i) badm += vgot[i] != vref[i];
+        if (bad || badm) printf("  !! %s MISMATCH values %zu masks %zu\n", name, bad, badm);
+        CK(hipMemset(ddst, 0, px * 12)); CK(hipMemset(dval, 0, px));
+    };
+    auto report = [&](const char* name, float ms) {
+        printf("%-34s %8.3f ms  %7.1f GB/s  (%.1f%% of 8 TB/s)  %7.1f Gpix/s\n", name, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 80.0, px / ms / 1e6);
+    };
+    printf("N=%d %dx%d sigma=%.1f  algorithmic bytes/launch = %.1f MB\n", n, h, w, sigma, bytes / 1e6);
+    const int it = 20;
+    if (strstr("stream_dword", only)) { unsigned g = 2048 * 4; report("stream_dword (no gather)", time_it([&] { hipLaunchKernelGGL(stream_dword, dim3(g), dim3(256), 0, 0, p); }, it)); }
+    if (strstr("stream_vec4", only)) { unsigned g = 2048 * 4; report("stream_vec4 (no gather)", time_it([&] { hipLaunchKernelGGL(stream_vec4, dim3(g), dim3(256), 0, 0, p); }, it)); }
+#define RUNS(name, TWQ) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, 256 / TWQ); \
+        report(name, time_it([&] { hipLaunchKernelGGL(stream_tiled<TWQ>, dim3(g), dim3(256), 0, 0, p); }, it)); }
+    RUNS("stream_tiled 32x32", 8)
+    RUNS("stream_tiled 64x16", 16)
+    RUNS("stream_tiled 128x8", 32)
+    RUNS("stream_tiled 256x4", 64)
+    RUNS("stream_tiled 512x2", 128)
+#define RUN(name, kern, tw, th) if (strstr(name, only)) { unsigned g = grid_for(tw, th); hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, p); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, p); }, it)); }
+    RUN("v0 rows=4 (64x16, current)", warp_v0<4>, 64, 16)
+    RUN("v0 rows=1 (64x4)", warp_v0<1>, 64, 4)
+    RUN("v1 hoisted rows=1 64x4", (warp_v1<1, 1>), 64, 4)
+    RUN("v1 hoisted rows=2 64x8", (warp_v1<2, 1>), 64, 8)
+    RUN("v1 hoisted rows=4 64x16", (warp_v1<4, 1>), 64, 16)
+    RUN("v1 hoisted rows=8 64x32", (warp_v1<8, 1>), 64, 32)
+    RUN("v1 hoisted rows=2 128x4", (warp_v1<2, 2>), 128, 4)
+    RUN("v1 hoisted rows=4 128x8", (warp_v1<4, 2>), 128, 8)
+    RUN("v1 hoisted rows=4 256x4", (warp_v1<4, 4>), 256, 4)
+    RUN("v1 hoisted rows=2 256x2", (warp_v1<2, 4>), 256, 2)
+    RUN("v3 pair rows=1 64x4", (warp_v3<1, 1>), 64, 4)
+    RUN("v3 pair rows=2 64x8", (warp_v3<2, 1>), 64, 8)
+    RUN("v3 pair rows=4 64x16", (warp_v3<4, 1>), 64, 16)
+    RUN("v3 pair rows=2 128x4", (warp_v3<2, 2>), 128, 4)
+#define RUN4(name, TWQ, TH, LDSB) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, TH); \
+        CK(hipFuncSetAttribute((const void*)warp_v4<TWQ, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        { unsigned long long z[2] = {0, 0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_fit_count), z, sizeof(z))); } \
+        hipLaunchKernelGGL((warp_v4<TWQ, TH>), dim3(g), dim3(256), LDSB, 0, p, LDSB); check(name); \
+        { unsigned long long z[2]; CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fit_count), sizeof(z))); printf("  [%s] tiles fit LDS: %llu, fallback: %llu\n", name, z[1], z[0]); } \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v4<TWQ, TH>), dim3(g), dim3(256), LDSB, 0, p, LDSB); }, it)); }
+    RUN4("v4 lds 64x16 40K", 16, 16, 40960)
+    RUN4("v4 lds 64x16 52K", 16, 16, 53248)
+    RUN4("v4 lds 64x16 32K", 16, 16, 32768)
+    RUN4("v4 lds 128x8 40K", 32, 8, 40960)
+    RUN4("v4 lds 128x8 52K", 32, 8, 53248)
+    RUN4("v4 lds 32x32 40K", 8, 32, 40960)
+    RUN4("v4 lds 32x32 52K", 8, 32, 53248)
+    RUN4("v4 lds 64x16 0K (all fallback)", 16, 16, 16)
+#define RUN5(name, NT, TWQ, ITERS, LDSB) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, NT / TWQ); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v5<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        { unsigned long long z[2] = {0, 0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_fit_count), z, sizeof(z))); } \
+        hipLaunchKernelGGL((warp_v5<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        { unsigned long long z[2]; CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fit_count), sizeof(z))); printf("  [%s] tiles fit LDS: %llu, fallback: %llu\n", name, z[1], z[0]); } \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v5<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN5("v5 256t 32x32 40K", 256, 8, 4, 40960)
+    RUN5("v5 256t 64x16 40K", 256, 16, 4, 40960)
+    RUN5("v5 256t 32x32 32K", 256, 8, 3, 32768)
+    RUN5("v5 128t 32x16 20K", 128, 8, 4, 20480)
+    RUN5("v5 128t 32x16 16K", 128, 8, 3, 16384)
+    RUN5("v5 128t 16x32 20K", 128, 4, 4, 20480)
+    RUN5("v5 64t 16x16 10K", 64, 4, 4, 10240)
+    RUN5("v5 64t 16x16 12K", 64, 4, 4, 12288)
+    RUN5("v5 64t 32x8 12K", 64, 8, 4, 12288)
+#define RUNP(name, kern, tw, th, G) if (strstr(name, only)) { grid_for(tw, th); unsigned g = G; \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, p); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, 0, p); }, it)); }
+    RUNP("p1 hoisted rows=2 64x8 g2048", (warp_v1p<2, 1>), 64, 8, 2048)
+    RUNP("p1 hoisted rows=2 64x8 g4096", (warp_v1p<2, 1>), 64, 8, 4096)
+    RUNP("p3 pair rows=2 64x8 g1024", (warp_v3p<2, 1>), 64, 8, 1024)
+    RUNP("p3 pair rows=2 64x8 g2048", (warp_v3p<2, 1>), 64, 8, 2048)
+    RUNP("p3 pair rows=2 64x8 g4096", (warp_v3p<2, 1>), 64, 8, 4096)
+    RUNP("p3 pair rows=1 64x4 g2048", (warp_v3p<1, 1>), 64, 4, 2048)
+    RUNP("p3 pair rows=4 64x16 g2048", (warp_v3p<4, 1>), 64, 16, 2048)
+#define RUN5P(name, NT, TWQ, ITERS, LDSB, G) if (strstr(name, only)) { grid_for(TWQ * 4, NT / TWQ); unsigned g = G; \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v5p<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v5p<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v5p<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN5P("p5 256t 32x32 40K g768", 256, 8, 4, 40960, 768)
+    RUN5P("p5 256t 32x32 40K g1024", 256, 8, 4, 40960, 1024)
+    RUN5P("p5 256t 64x16 40K g1024", 256, 16, 4, 40960, 1024)
+    RUN5P("p5 256t 32x32 32K g1024", 256, 8, 3, 32768, 1024)
+    RUN5P("p5 128t 32x16 20K g2048", 128, 8, 4, 20480, 2048)
+    RUN5P("p5 128t 16x32 20K g2048", 128, 4, 4, 20480, 2048)
+    RUN5P("p5 64t 16x16 10K g4096", 64, 4, 4, 10240, 4096)
+    RUN5P("p5 64t 16x16 12K g3072", 64, 4, 4, 12288, 3072)
+#define RUN6(name, NT, TWQ, ITERS, LDSB) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, NT / TWQ); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v6<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v6<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v6<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN6("v6 256t 32x32 48K", 256, 8, 4, 49152)
+    RUN6("v6 256t 32x32 40K", 256, 8, 3, 40960)
+    RUN6("v6 256t 64x16 48K", 256, 16, 4, 49152)
+    RUN6("v6 128t 32x16 26K", 128, 8, 4, 26624)
+    RUN6("v6 128t 32x16 32K", 128, 8, 4, 32768)
+    RUN6("v6 128t 16x32 26K", 128, 4, 4, 26624)
+    RUN6("v6 64t 16x16 13K", 64, 4, 4, 13312)
+    RUN6("v6 64t 16x16 16K", 64, 4, 4, 16384)
+#define RUN7(name, NT, TWQ, ITERS, LDSB, G) if (strstr(name, only)) { grid_for(TWQ * 4, NT / TWQ); unsigned g = G; \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v7<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v7<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v7<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN7("v7 256t 32x32 48K g768", 256, 8, 4, 49152, 768)
+    RUN7("v7 256t 32x32 40K g768", 256, 8, 3, 40960, 768)
+    RUN7("v7 256t 32x32 40K g1024", 256, 8, 3, 40960, 1024)
+    RUN7("v7 128t 32x16 26K g1536", 128, 8, 4, 26624, 1536)
+    RUN7("v7 128t 32x16 26K g2048", 128, 8, 4, 26624, 2048)
+    RUN7("v7 64t 16x16 13K g3072", 64, 4, 4, 13312, 3072)
+    RUN7("v7 64t 16x16 13K g4096", 64, 4, 4, 13312, 4096)
+#define RUN8(name, NT, TWQ, ITERS, LDSB) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, NT / TWQ); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v8<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v8<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v8<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN8("v8 256t 32x32 48K", 256, 8, 4, 49152)
+    RUN8("v8 256t 32x32 40K", 256, 8, 3, 40960)
+    RUN8("v8 256t 64x16 48K", 256, 16, 4, 49152)
+    RUN8("v8 128t 32x16 26K", 128, 8, 4, 26624)
+    RUN8("v8 128t 16x32 26K", 128, 4, 4, 26624)
+    RUN8("v8 64t 16x16 13K", 64, 4, 4, 13312)
+#define RUN9(name, NWAVES) if (strstr(name, only)) { unsigned g = grid_for(64, 4 * NWAVES); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        hipLaunchKernelGGL((warp_v9<NWAVES>), dim3(g), dim3(64 * NWAVES), 0, 0, pp); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v9<NWAVES>), dim3(g), dim3(64 * NWAVES), 0, 0, pp); }, it)); }
+    RUN9("v9 hybrid 1 wave 64x4", 1)
+    RUN9("v9 hybrid 2 waves 64x8", 2)
+    RUN9("v9 hybrid 4 waves 64x16", 4)
+#define RUN10(name, NWAVES, G) if (strstr(name, only)) { grid_for(64, 4 * NWAVES); unsigned g = G; \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        hipLaunchKernelGGL((warp_v10<NWAVES>), dim3(g), dim3(64 * NWAVES), 0, 0, pp); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v10<NWAVES>), dim3(g), dim3(64 * NWAVES), 0, 0, pp); }, it)); }
+    RUN10("v10 pipelined 4 waves g1024", 4, 1024)
+    RUN10("v10 pipelined 4 waves g2048", 4, 2048)
+    RUN10("v10 pipelined 2 waves g2048", 2, 2048)
+    RUN10("v10 pipelined 1 wave g4096", 1, 4096)
+    RUN10("v10 pipelined 1 wave g8192", 1, 8192)
+#define RUN9A(name, ABL) if (strstr(name, only)) { unsigned g = grid_for(64, 16); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v9a<4, ABL>), dim3(g), dim3(256), 0, 0, pp); }, it)); }
+    RUN9A("abl v9 full", 0)
+    RUN9A("abl v9 no tap loads", 1)
+    RUN9A("abl v9 no stores", 2)
+    RUN9A("abl v9 taps at own pixel (coalesced)", 3)
+#define RUN8A(name, ABL) if (strstr(name, only)) { unsigned g = grid_for(32, 16); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v8a<128, 8, 4, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 26624)); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v8a<128, 8, 4, ABL>), dim3(g), dim3(128), 26624, 0, pp, 26624); }, it)); }
+    RUN8A("abl v8 full (128t 32x16 26K)", 0)
+    RUN8A("abl v8 no staging global loads", 1)
+    RUN8A("abl v8 no LDS writes", 2)
+    RUN8A("abl v8 no LDS gather reads", 3)
+    RUN8A("abl v8 no stores", 4)
+    RUN8A("abl v8 no bbox reduction (fixed halo 8)", 5)
+#define RUN11(name, NT, TWQ, ITERS, LDSB, G) if (strstr(name, only)) { grid_for(TWQ * 4, NT / TWQ); unsigned g = G; \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v11<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v11<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v11<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN11("v11 128t 32x16 26K g1536", 128, 8, 4, 26624, 1536)
+    RUN11("v11 128t 32x16 26K it3 g1536", 128, 8, 3, 26624, 1536)
+    RUN11("v11 128t 32x16 32K g1280", 128, 8, 4, 32768, 1280)
+    RUN11("v11 256t 32x32 48K g768", 256, 8, 4, 49152, 768)
+    RUN11("v11 64t 16x16 13K g3072", 64, 4, 4, 13312, 3072)
+    RUN11("v11 64t 16x16 13K g2048", 64, 4, 4, 13312, 2048)
+    if (strstr("stamps", only)) {
+        unsigned g = grid_for(32, 32); P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1;
+        unsigned long long* dst_; CK(hipMalloc(&dst_, 64 * 8 * 8)); CK(hipMemset(dst_, 0, 64 * 8 * 8));
+        CK(hipFuncSetAttribute((const void*)warp_v6t<256, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152));
+        hipLaunchKernelGGL((warp_v6t<256, 8, 4>), dim3(g), dim3(256), 49152, 0, pp, 49152, dst_); CK(hipDeviceSynchronize());
+        unsigned long long hst[64 * 8]; CK(hipMemcpy(hst, dst_, sizeof(hst), hipMemcpyDeviceToHost));
+        double tot[8] = {0}; for (int i = 0; i < 64; ++i) for (int j = 0; j < 8; ++j) tot[j] += hst[i * 8 + j];
+        const char* nm[8] = {"tiles", "flow-load wait", "coords+taps", "bbox reduce+barrier", "staging issue+wait", "lds write+barrier", "gather+blend", "stores drain"};
+        printf("v6 phase stamps (s_memtime ticks), 256t 32x32 48K, per tile:\n");
+        for (int j = 1; j < 8; ++j) printf("   %-22s %9.1f ticks\n", nm[j], tot[j] / tot[0]);
+    }
+    RUN("v2 vec4 rows=1 256x4", warp_v2<1>, 256, 4)
+    RUN("v2 vec4 rows=2 256x8", warp_v2<2>, 256, 8)
+    RUN("v2 vec4 rows=4 256x16", warp_v2<4>, 256, 16)
+    return 0;
+}
