@@ -47,8 +47,15 @@ extern "C" {
 #define OFL_E_SHAPE -2     /* n, c, h or w out of range (all must be >= 1; h*w < 2^24, utils.py:1118) */
 #define OFL_E_ARG -3       /* inconsistent optional arguments */
 
-/* library / build identification: returns e.g. 10 for 0.1.0 */
+/* library / build identification: returns e.g. 11 for 0.1.1 */
 int ofl_version(void);
+
+/* Process-wide options (testing / benchmarking aids; defaults are what production uses).
+ *   OFL_OPT_WARP_PATH: 0 = auto (LDS-staged kernel when the launch is eligible: C <= 3, W % 4 == 0, 16-byte aligned
+ *                          planes; generic direct-gather kernel otherwise -- both restate the same arithmetic),
+ *                      1 = generic direct-gather kernel only. */
+#define OFL_OPT_WARP_PATH 1
+int ofl_set_option(int32_t key, int32_t value);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,
  * Flow.apply flow_class.py:943-946): 0 none, 1 round-half-even, 2 round then clamp to [0,255] */

@@ -18,7 +18,7 @@ FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2,
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
-_SYMBOLS = ("ofl_version", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_flow_flags_f32")
+_SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_flow_flags_f32")
 _lib = None
 
 
@@ -43,6 +43,7 @@ def load_library(path: str = None):
         raise NativeUnavailable("oflibpytorch_amd: cannot load %s: %s" % (path, exc))
     p, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
     lib.ofl_version.argtypes = []
+    lib.ofl_set_option.argtypes = [i32, i32]
     lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p,
                                      i32, i32, i32, i32, i32, p]
     lib.ofl_splat_fwd_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p,
@@ -54,6 +55,11 @@ def load_library(path: str = None):
         getattr(lib, name).restype = ctypes.c_int
     _lib = lib
     return lib
+
+
+def set_warp_path(mode: int):
+    """0 = auto (LDS-staged kernel when eligible), 1 = generic direct-gather kernel only (tests compare the two)."""
+    _check(load_library().ofl_set_option(1, int(mode)), "ofl_set_option")
 
 
 def exported_symbols():

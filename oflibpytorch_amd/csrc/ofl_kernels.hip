@@ -85,22 +85,297 @@ struct WarpParams {
     float flow_sign, a_sign, g_sign;
     int32_t round_mode;
     float wm1, hm1, half_wm1, half_hm1;
+    float rcp_wm1, rcp_hm1;          // RN(1/(w-1)), RN(1/(h-1)) for the exact reciprocal division
     int32_t tiles_x, tiles_y;
     int64_t total_tiles, per_xcd;
+    uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;   // magic divisors by tiles_x and by tiles per image
+    int32_t lds_bytes;
 };
 
 constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
 constexpr int kRows = 4;     // rows per thread (independent pixels in flight per lane)
 constexpr int kTileH = 4 * kRows;  // 4 wavefronts per 256-thread block
 
+
+// exact u32 division by an invariant divisor: q = (((n - t) >> s1) + t) >> s2 with t = umulhi(m, n); s = (s1 << 16) | s2
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s) {
+    const uint32_t t = __umulhi(m, n);
+    return (((n - t) >> (s >> 16)) + t) >> (s & 0xffffu);
+}
+
+// XCD-aware 32-bit tile decode (no 64-bit integer division in the kernel prologue)
+__device__ __forceinline__ bool decode_tile(const WarpParams& p, int& tx, int& ty, int& n) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t tile = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
+    if (tile >= (uint32_t)p.total_tiles) return false;
+    const uint32_t nn = fastdiv(tile, p.mi_m, p.mi_s);
+    const uint32_t rem = tile - nn * p.tiles_img;
+    const uint32_t yy = fastdiv(rem, p.mx_m, p.mx_s);
+    n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (uint32_t)p.tiles_x);
+    return true;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// backward warp, LDS-staged fast path (C <= 3, W % 4 == 0, 16-byte aligned planes)
+//
+// A 128-thread block owns a 32 x 16 output tile, 4 consecutive x per thread:
+//   1. flow (u, v) + flow mask of the tile: 16-byte loads; sample coordinates in the reference's fp32 op order
+//      (packed fp32; the divide by (W-1) is an exact reciprocal division, see exact_div2);
+//   2. bounding box of the source pixels the tile touches (wave shuffles + one LDS exchange);
+//   3. the box is staged into LDS with 16-byte row-coalesced loads, channels + mask INTERLEAVED per pixel in
+//      16-byte slots, de-interleaved by 4 along x:  slot(xl, yl) = 1 + yl*P + (xl & 3)*cw + (xl >> 2), so the
+//      stride-4-pixel gathers of the 64 lanes are bank-conflict free; slot 0 holds zeros and every out-of-image
+//      tap points there (zero padding without per-value selects);
+//   4. one ds_read_b128 per tap fetches all channels; FMA chain in the reference's order; 16-byte stores.
+// A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLdsNT = 128, kLdsTWQ = 8, kLdsTH = kLdsNT / kLdsTWQ, kLdsIters = 4;
+constexpr int kLdsBytes = 26624;   // 6 blocks per CU
+
+// a / b for two values at once, bit-identical to the IEEE divide: y = RN(1/b), two Newton refinements through exact
+// FMA residuals (Markstein); valid for a == 0 or 2^-60 <= |a| <= 2^100 -- the caller routes anything else (never
+// seen in practice) through the hardware divide.
+__device__ __forceinline__ f2 exact_div2(f2 a, float nb, float y) {
+    const f2 yy = {y, y}, nbb = {nb, nb};
+    f2 q = a * yy;
+    f2 r = __builtin_elementwise_fma(nbb, q, a);
+    q = __builtin_elementwise_fma(r, yy, q);
+    r = __builtin_elementwise_fma(nbb, q, a);
+    return __builtin_elementwise_fma(r, yy, q);
+}
+
+__device__ __forceinline__ int lds_pitch(int n) {   // smallest P >= n with P % 16 == 8 (read-conflict-free rows, TWQ = 8)
+    int r = (kLdsTWQ - n) % (2 * kLdsTWQ);
+    if (r < 0) r += 2 * kLdsTWQ;
+    return n + r;
+}
+
+template <int NC, bool VALID, bool ADD>
+__global__ __launch_bounds__(kLdsNT) void warp_bwd_lds_kernel(const WarpParams p) {
+    constexpr int NW = kLdsNT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const float* __restrict__ sb = p.src + n * p.src_bs;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
+    float* __restrict__ db = p.dst + (int64_t)n * NC * hw;
+    const uint32_t pix = (uint32_t)(yc * w + xc);
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
+    uint32_t fmask4 = 0x01010101u;
+    if ((VALID || p.flow_flags) && fm) fmask4 = *reinterpret_cast<const uint32_t*>(fm + pix);
+
+    if (p.flow_flags) {   // wave-uniform: finiteness / zero tests of the flow operand as a by-product
+        int f = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f |= flag_bits(u4[k], v4[k], ((fmask4 >> (8 * k)) & 0xffu) != 0u);
+        if (!inb) f = 0;
+        f = wave_or_flags(f);
+        if ((tid & 63) == 0 && f) atomicOr(&p.flow_flags[n], f);
+    }
+
+    // ---- sample coordinates: ((x - s*u) * 2) / (w - 1) - 1, then (g + 1) * ((w - 1) / 2)   (utils.py:462-465, 549)
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        const f2 su = (f2){u4[2 * j], u4[2 * j + 1]} * p.flow_sign, sv = (f2){v4[2 * j], v4[2 * j + 1]} * p.flow_sign;
+        ax[j] = (xx - su) * 2.0f;
+        ay[j] = (yy - sv) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        qx[j] = exact_div2(ax[j], -p.wm1, p.rcp_wm1);
+        qy[j] = exact_div2(ay[j], -p.hm1, p.rcp_hm1);
+    }
+    {
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        // a tiny non-zero operand needs |x - u| < 2^-61 with integer x >= 0: only column 0 / row 0 can produce one
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1};
+                qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4];
+    int xi[4], yi[4];
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.half_wm1, p.half_wm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.half_hm1, p.half_hm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            // west / north tap as an int, clamped to [-2, size] (beyond that every tap is out of range anyway; a NaN
+            // coordinate lands on 0 through the conversion and is blended with NaN weights like the reference's)
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]);
+            miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+        }
+    }
+    minx = wave_min_i32(minx); maxx = wave_max_i32(maxx); miny = wave_min_i32(miny); maxy = wave_max_i32(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]);
+            miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
+        }
+    }
+    // touched columns [minx, maxx + 1] / rows [miny, maxy + 1], clipped to the image (wave-uniform)
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    const bool empty = (maxx < minx) || (maxy < miny);
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = lds_pitch(bw);
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= p.lds_bytes) && (nch <= kLdsIters * kLdsNT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const uint32_t inv = (1048576u + (uint32_t)cw - 1u) / (uint32_t)cw;
+        const int rounds = (nch + kLdsNT - 1) / kLdsNT;
+        int slot[kLdsIters];
+        f4 q[kLdsIters][NC];
+        uint32_t mq[kLdsIters];
+#pragma unroll
+        for (int it = 0; it < kLdsIters; ++it) {
+            if (it < rounds) {
+                const uint32_t i = (uint32_t)tid + it * kLdsNT;
+                const bool on = i < (uint32_t)nch;
+                const uint32_t r = (i * inv) >> 20, c4 = i - r * (uint32_t)cw;
+                const uint32_t g = on ? (uint32_t)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (uint32_t)Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = (VALID && sm) ? *reinterpret_cast<const uint32_t*>(sm + g) : 0x01010101u;
+            }
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < kLdsIters; ++it) {
+            if (it < rounds && slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f4 sl = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) sl[c] = q[it][c][k];
+                    if (VALID) sl[3] = (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u);
+                    lds[slot[it] + k * cw] = sl;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask channel)
+    const int cw16 = cw * 16, P16 = Pp * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // west column valid <=> 0 <= xi <= w-1 ; east <=> -1 <= xi <= w-2   (rows alike)
+        const bool x0 = (uint32_t)xi[k] < (uint32_t)w, x1 = (uint32_t)(xi[k] + 1) < (uint32_t)w;
+        const bool y0 = (uint32_t)yi[k] < (uint32_t)h, y1 = (uint32_t)(yi[k] + 1) < (uint32_t)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t og = ok[j] ? (uint32_t)(cy[j] * w + cx[j]) : 0u;
+                f4 t = {0.f, 0.f, 0.f, 0.f};
+                if (ok[j]) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) t[c] = sb[c * hw + og];
+                    if (VALID) t[3] = sm ? (float)(sm[og] != 0) : 1.0f;
+                }
+                tv[j] = t;
+            }
+        }
+        // v_nw*nw, then fma(v_ne, ne, .), fma(v_sw, sw, .), fma(v_se, se, .): the reference's contraction order
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (inb) {
+        if (VALID) {
+            uint32_t vo = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+            *reinterpret_cast<uint32_t*>(p.valid + (int64_t)n * hw + pix) = vo;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+            if (ADD) {
+                f4 a;
+                if (p.addend == p.flow && p.addend_bs == p.flow_bs && c < 2) a = c == 0 ? u4 : v4;   // wave-uniform
+                else a = *reinterpret_cast<const f4*>(p.addend + n * p.addend_bs + c * hw + pix);
+                o = a * p.a_sign + o * p.g_sign;
+            }
+            if (p.round_mode != OFL_ROUND_NONE) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], p.round_mode);
+            }
+            *reinterpret_cast<f4*>(db + c * hw + pix) = o;
+        }
+    }
+}
+
 // CT = compile-time channel count (0: run-time p.c)
 template <int CT, bool VALID, bool ADD, bool FLAGS>
 __global__ __launch_bounds__(256) void warp_bwd_kernel(const WarpParams p) {
-    const int64_t tile = logical_block(p.per_xcd);
-    if (tile >= p.total_tiles) return;
-    const int tx = (int)(tile % p.tiles_x);
-    const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
-    const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -391,6 +666,41 @@ inline void tile_grid(int32_t n, int32_t h, int32_t w, int32_t& tiles_x, int32_t
     grid = (unsigned)(per_xcd * kXcds);
 }
 
+inline void magic_u32(uint32_t d, uint32_t& m, uint32_t& s) {   // d >= 1; see fastdiv()
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    s = ((l ? 1u : 0u) << 16) | (l ? l - 1 : 0);
+}
+
+inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
+    p.tiles_x = (p.w + tile_w - 1) / tile_w;
+    p.tiles_y = (p.h + tile_h - 1) / tile_h;
+    p.tiles_img = (uint32_t)(p.tiles_x * p.tiles_y);
+    p.total_tiles = (int64_t)p.tiles_img * p.n;
+    p.per_xcd = (p.total_tiles + kXcds - 1) / kXcds;
+    magic_u32((uint32_t)p.tiles_x, p.mx_m, p.mx_s);
+    magic_u32(p.tiles_img, p.mi_m, p.mi_s);
+    return (unsigned)(p.per_xcd * kXcds);
+}
+
+int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
+
+template <int NC>
+int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
+    const bool valid = p.valid != nullptr, add = p.addend != nullptr;
+#define OFL_LAUNCH_L(V, A)                                                                                       \
+    if (valid == V && add == A) {                                                                                \
+        hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, V, A>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);          \
+        return (int)hipGetLastError();                                                                           \
+    }
+    OFL_LAUNCH_L(false, false) OFL_LAUNCH_L(true, false) OFL_LAUNCH_L(false, true) OFL_LAUNCH_L(true, true)
+#undef OFL_LAUNCH_L
+    return OFL_E_ARG;
+}
+
+inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+
 template <int CT>
 int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
     const bool valid = p.valid != nullptr, add = p.addend != nullptr, flags = p.flow_flags != nullptr;
@@ -414,7 +724,12 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 10; }
+__attribute__((visibility("default"))) int ofl_version(void) { return 11; }
+
+__attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
+    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
+    return OFL_E_ARG;
+}
 
 __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
@@ -437,9 +752,34 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.flow_sign = flow_sign; p.a_sign = a_sign; p.g_sign = g_sign; p.round_mode = round_mode;
     p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
     p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
-    unsigned grid;
-    tile_grid(n, h, w, p.tiles_x, p.tiles_y, p.total_tiles, p.per_xcd, grid);
+    p.rcp_wm1 = 1.0f / p.wm1; p.rcp_hm1 = 1.0f / p.hm1;
+    p.lds_bytes = kLdsBytes;
     hipStream_t st = (hipStream_t)stream;
+    if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
+    // LDS-staged fast path: <= 3 channels, rows that are whole 16-byte groups, 16-byte aligned planes
+    const bool lds_ok = g_warp_path != 1 && c <= 3 && w >= 4 && (w % 4) == 0 && h >= 2 &&
+                        aligned_to(flow, 16) && aligned_to(src, 16) && aligned_to(dst, 16) && (flow_bs % 4) == 0 &&
+                        (src_bs % 4) == 0 && (!addend || (aligned_to(addend, 16) && (addend_bs % 4) == 0)) &&
+                        (!src_mask || (aligned_to(src_mask, 4) && (src_mask_bs % 4) == 0)) &&
+                        (!flow_mask || (aligned_to(flow_mask, 4) && (flow_mask_bs % 4) == 0)) &&
+                        (!valid || aligned_to(valid, 4));
+    if (lds_ok) {
+        if (src_flags) {   // the staged path never reads `src` at its own pixel: a separate reduction supplies its flags
+            const int64_t hw = (int64_t)h * w;
+            int64_t bx = (hw + 255) / 256;
+            if (bx > 512) bx = 512;
+            hipLaunchKernelGGL(flow_flags_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, src, src_bs, src_mask,
+                               src_mask_bs, src_flags, hw);
+            p.src_flags = nullptr;
+        }
+        const unsigned g = warp_geometry(p, kLdsTWQ * 4, kLdsTH);
+        switch (c) {
+            case 1: return launch_warp_lds<1>(p, g, st);
+            case 2: return launch_warp_lds<2>(p, g, st);
+            default: return launch_warp_lds<3>(p, g, st);
+        }
+    }
+    const unsigned grid = warp_geometry(p, kTileW, kTileH);
     switch (c) {
         case 1: return launch_warp<1>(p, grid, st);
         case 2: return launch_warp<2>(p, grid, st);

@@ -1,0 +1,62 @@
+"""CPU tier: the C-ABI library builds, loads, exports every symbol include/oflib_hip.h declares, and rejects bad
+arguments before touching a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from oflibpytorch_amd import _build, _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_loads():
+    path = _build.build()
+    assert os.path.exists(path)
+    lib = _native.load_library()
+    assert lib.ofl_version() >= 10
+
+
+def test_header_and_library_agree_on_symbols():
+    header = open(os.path.join(ROOT, 'include', 'oflib_hip.h')).read()
+    declared = set(re.findall(r'^int (ofl_\w+)\(', header, flags=re.M))
+    assert declared == set(_native.exported_symbols())
+    lib = ctypes.CDLL(_build.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _native.load_library()
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)      # never dereferenced: rejected on shape / argument checks first
+    # NULL required pointers
+    assert lib.ofl_warp_bwd_f32(null, 0, 1.0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, null, null, null, null,
+                                1, 1, 4, 4, 0, null) == -1
+    # bad dims / h*w >= 2^24 (utils.py:1118 fp32 index limit)
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null,
+                                0, 1, 4, 4, 0, null) == -2
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null,
+                                1, 1, 4096, 4096, 0, null) == -2
+    # flow_sign must be +-1, round mode 0..2
+    assert lib.ofl_warp_bwd_f32(one, 0, 0.5, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null,
+                                1, 1, 4, 4, 0, null) == -3
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null,
+                                1, 1, 4, 4, 7, null) == -3
+    assert lib.ofl_flow_flags_f32(null, 0, null, 0, 1e-3, null, 1, 4, 4, null) == -1
+    assert lib.ofl_splat_fwd_f32(null, 0, 1.0, null, null, 0, null, 0, 1.0, null, 0, null, 0, null, 0, 0, 0, null,
+                                 1, 1, 4, 4, null) == -1
+    assert lib.ofl_set_option(1, 5) == -3 and lib.ofl_set_option(1, 0) == 0
+
+
+def test_no_gpu_means_loud_failure(monkeypatch):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(_native.NativeUnavailable):
+        _native.device()
+    import oflibpytorch_amd as ofl
+    f = ofl.Flow(torch.zeros(1, 2, 8, 8) + 1.0)
+    with pytest.raises(_native.NativeUnavailable):
+        f.apply(torch.zeros(1, 1, 8, 8))

@@ -81,3 +81,88 @@ def test_cpu_tensors_are_staged_through_the_gpu(dev):
     w_cpu = ofl.Flow(f, 't').apply(img)
     w_gpu = ofl.Flow(f.to(dev), 't').apply(img.to(dev))
     assert w_cpu.device.type == 'cpu' and torch.equal(w_cpu, w_gpu.cpu())
+
+
+# ------------------------------------------------------------------------------------------------
+# the LDS-staged fast path and the generic direct-gather kernel must agree bit for bit, and both with the oracle
+# ------------------------------------------------------------------------------------------------
+def _smooth(n, h, w, sigma, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.randn(n, 2, max(h // 12, 2), max(w // 12, 2), generator=g) * sigma
+    return torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous().to(dev)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260)])
+@pytest.mark.parametrize("sigma", [0.0005, 3.0, 40.0])
+def test_lds_and_generic_paths_agree(shape, sigma, dev):
+    import sys
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    n, c, h, w = shape
+    flow = _smooth(n, h, w, sigma, 11, dev)
+    if sigma > 10:
+        flow[0, :, : h // 2] *= 20            # huge displacements: bounding boxes that cannot fit LDS -> per-tile fallback
+    g = torch.Generator().manual_seed(5)
+    src = (torch.rand(n, c, h, w, generator=g) * 200 - 50).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    fmk = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    add = torch.randn(n, c, h, w, generator=g).to(dev)
+    for kw in (dict(), dict(src_mask=sm, flow_mask=fmk, want_valid=True), dict(want_valid=True),
+               dict(flow_sign=-1.0, src_mask=sm, want_valid=True, addend=add, a_sign=1.0, g_sign=-1.0),
+               dict(round_mode=2), dict(flow_mask=fmk, want_valid=True, want_flags=True, want_src_flags=(c == 2))):
+        outs = []
+        for path in (0, 1):
+            _native.set_warp_path(path)
+            try:
+                outs.append(_native.warp_bwd(flow, src, **kw))
+            finally:
+                _native.set_warp_path(0)
+        for a, b in zip(*outs):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), "LDS path and generic path differ for %s" % (kw,)
+        # and against the oracle (values bit-exact, masks bit-exact)
+        f = flow.cpu().numpy() * np.float32(kw.get("flow_sign", 1.0))
+        s = src.cpu().numpy()
+        if kw.get("want_valid"):
+            m = sm.cpu().numpy().astype(np.float32) if "src_mask" in kw else np.ones((n, h, w), np.float32)
+            s = np.concatenate([s, m[:, None]], 1)
+        gref = oracle.G(f, s)
+        exp = gref[:, :c]
+        if "addend" in kw:
+            exp = np.float32(kw["a_sign"]) * add.cpu().numpy() + np.float32(kw["g_sign"]) * exp
+        if kw.get("round_mode"):
+            exp = np.clip(np.rint(exp), 0, 255).astype(np.float32)
+        assert np.array_equal(outs[0][0].cpu().numpy(), exp, equal_nan=True)
+        if kw.get("want_valid"):
+            v = oracle.theta(gref[:, c])
+            if "flow_mask" in kw:
+                v = v & fmk.cpu().numpy()
+            assert np.array_equal(outs[0][1].cpu().numpy(), v)
+        if kw.get("want_flags"):
+            assert np.array_equal(outs[0][2].cpu().numpy(), oracle.flow_flags(flow.cpu().numpy(), fmk.cpu().numpy()))
+            if c == 2:
+                assert np.array_equal(outs[0][3].cpu().numpy(), oracle.flow_flags(src.cpu().numpy(), None))
+
+
+def test_exact_division_corner_cases(dev):
+    """Operands the reciprocal division cannot take (huge, and tiny non-zero in column / row 0) go through the IEEE divide."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    h, w = 16, 32
+    flow = torch.zeros(1, 2, h, w)
+    flow[0, 0, :, 0] = 1e-30          # x - u tiny but non-zero in column 0
+    flow[0, 1, 0, :] = -3e-33         # y - v tiny in row 0
+    flow[0, 0, 5, 7] = 3e37           # overflow when doubled
+    flow[0, 1, 9, 3] = -2.5e31
+    flow[0, 0, 3, 3] = 1.7
+    src = torch.rand(1, 3, h, w) * 10
+    for path in (0, 1):
+        _native.set_warp_path(path)
+        try:
+            out, valid, _, _ = _native.warp_bwd(flow.to(dev), src.to(dev), want_valid=True)
+        finally:
+            _native.set_warp_path(0)
+        ref = oracle.G(flow.numpy(), np.concatenate([src.numpy(), np.ones((1, 1, h, w), np.float32)], 1))
+        assert np.array_equal(out.cpu().numpy(), ref[:, :3], equal_nan=True)
+        assert np.array_equal(valid.cpu().numpy(), oracle.theta(ref[:, 3]))
