@@ -57,6 +57,8 @@ def test_no_gpu_means_loud_failure(monkeypatch):
     with pytest.raises(_native.NativeUnavailable):
         _native.device()
     import oflibpytorch_amd as ofl
-    f = ofl.Flow(torch.zeros(1, 2, 8, 8) + 1.0)
-    with pytest.raises(_native.NativeUnavailable):
+    with pytest.raises(_native.NativeUnavailable):      # validation itself is a HIP reduction: no silent CPU path
+        f = ofl.Flow(torch.zeros(1, 2, 8, 8) + 1.0)
         f.apply(torch.zeros(1, 1, 8, 8))
+    with pytest.raises(_native.NativeUnavailable):
+        ofl.apply_flow(torch.ones(1, 2, 8, 8), torch.zeros(1, 1, 8, 8), 't')
