@@ -161,6 +161,11 @@ def main():
     el2 = time.perf_counter() - t1
 
     if rank == 0:
+        if args.traffic_bytes is None and (n, h, w) == (64, 1080, 1920):
+            tj = os.path.join(ROOT, "profiles", "r1_traffic.json")      # PMC passes are separate runs (tools/profile_bench.sh)
+            if os.path.exists(tj):
+                with open(tj) as fh:
+                    args.traffic_bytes = json.load(fh).get("traffic_bytes_per_launch")
         px = n * h * w
         ms_step = elapsed / args.steps * 1e3
         ach = BYTES_APPLY * px / (t_apply * 1e-3) / 1e9
@@ -177,7 +182,7 @@ def main():
                        "batch_per_gpu": n, "global_batch": n * world, "height": h, "width": w,
                        "parallelism": "batch-sharded x%d (no data-path collective)" % world,
                        "bytes_per_px": BYTES_APPLY + BYTES_COMBINE},
-            "roofline": {"bound": "hbm", "kernel": "warp_bwd_kernel<C=3,valid> (Flow.apply 't')",
+            "roofline": {"bound": "hbm", "kernel": "warp_bwd_lds_kernel<3,valid> (Flow.apply 't')",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": args.traffic_bytes,
