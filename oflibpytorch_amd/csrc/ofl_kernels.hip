@@ -132,19 +132,56 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // backward warp, LDS-staged fast path (C <= 3, W % 4 == 0, 16-byte aligned planes)
 //
-// A 128-thread block owns a 32 x 16 output tile, 4 consecutive x per thread:
-//   1. flow (u, v) + flow mask of the tile: 16-byte loads; sample coordinates in the reference's fp32 op order
-//      (packed fp32; the divide by (W-1) is an exact reciprocal division, see exact_div2);
-//   2. bounding box of the source pixels the tile touches (wave shuffles + one LDS exchange);
+// A 128-thread block owns TWO vertically adjacent 32 x 16 output tiles (A above B), 4 consecutive x per thread, and
+// runs them as a straight-line software pipeline so that memory phases overlap compute:
+//
+//   flow(A), flow(B) loads  ->  coords + bbox(A)  ->  staging loads(A) issued  ->  coords + bbox(B) while they fly
+//   -> LDS(A)  ->  staging loads(B) issued  ->  gather / blend / store A while they fly  ->  LDS(B)  ->  gather / store B
+//
+// Per tile:
+//   1. flow (u, v) + flow mask: 16-byte loads; sample coordinates in the reference's fp32 op order (packed fp32;
+//      the divide by (W-1) is an exact reciprocal division, see exact_div2);
+//   2. bounding box of the source pixels the tile touches (DPP butterflies + one LDS exchange between the two waves);
 //   3. the box is staged into LDS with 16-byte row-coalesced loads, channels + mask INTERLEAVED per pixel in
 //      16-byte slots, de-interleaved by 4 along x:  slot(xl, yl) = 1 + yl*P + (xl & 3)*cw + (xl >> 2), so the
 //      stride-4-pixel gathers of the 64 lanes are bank-conflict free; slot 0 holds zeros and every out-of-image
 //      tap points there (zero padding without per-value selects);
 //   4. one ds_read_b128 per tap fetches all channels; FMA chain in the reference's order; 16-byte stores.
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
+// Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
-constexpr int kLdsNT = 128, kLdsTWQ = 8, kLdsTH = kLdsNT / kLdsTWQ, kLdsIters = 4;
-constexpr int kLdsBytes = 26624;   // 6 blocks per CU
+constexpr int kLdsNT = 128, kLdsTWQ = 8, kLdsTH = kLdsNT / kLdsTWQ, kLdsIters = 3;
+constexpr int kLdsBytes = 26624;   // 6 blocks (12 waves) per CU
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wave-wide min / max without LDS: four DPP butterfly steps inside each row of 16 lanes, then the four row results are
+// combined on the scalar unit (v_readlane + s_min / s_max)
+#define OFL_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    v = min(v, OFL_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
+    v = min(v, OFL_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
+    v = min(v, OFL_DPP(v, 0x141));   // row_half_mirror
+    v = min(v, OFL_DPP(v, 0x140));   // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_dpp(int v) {
+    v = max(v, OFL_DPP(v, 0xB1));
+    v = max(v, OFL_DPP(v, 0x4E));
+    v = max(v, OFL_DPP(v, 0x141));
+    v = max(v, OFL_DPP(v, 0x140));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// ceil(2^20 / cw), cw = 1..127, without an integer division (float reciprocal + correction)
+__device__ __forceinline__ uint32_t inv20(uint32_t cw) {
+    uint32_t q = (uint32_t)(1048576.0f / (float)cw);
+    while (q * cw > 1048576u) --q;
+    while ((q + 1) * cw <= 1048576u) ++q;
+    return q * cw == 1048576u ? q : q + 1;
+}
 
 // a / b for two values at once, bit-identical to the IEEE divide: y = RN(1/b), two Newton refinements through exact
 // FMA residuals (Markstein); valid for a == 0 or 2^-60 <= |a| <= 2^100 -- the caller routes anything else (never
@@ -164,40 +201,18 @@ __device__ __forceinline__ int lds_pitch(int n) {   // smallest P >= n with P % 
     return n + r;
 }
 
-template <int NC, bool VALID, bool ADD>
-__global__ __launch_bounds__(kLdsNT) void warp_bwd_lds_kernel(const WarpParams p) {
+struct LdsCoords { float sx[4], sy[4]; };                              // un-normalised sample positions of 4 pixels
+struct LdsBox { int bx0, miny, cw, Pp, bh, nch; bool fits; };          // wave-uniform staging geometry
+template <int NC> struct LdsStage { int slot[kLdsIters]; f4 q[kLdsIters][NC]; uint32_t mq[kLdsIters]; };
+
+// steps 1-2 for one tile
+__device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int ty, const f4& u4, const f4& v4,
+                                               LdsCoords& T, LdsBox& B, int (*red)[4]) {
     constexpr int NW = kLdsNT / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int red[NW][4];
-    int tx, ty, n;
-    if (!decode_tile(p, tx, ty, n)) return;
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const int w = p.w, h = p.h;
-    const uint32_t hw = (uint32_t)(h * w);
-    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
-    const bool inb = (x4 < w) && (y < h);
-    const int xc = min(x4, w - 4), yc = min(y, h - 1);
-    const float* __restrict__ fu = p.flow + n * p.flow_bs;
-    const float* __restrict__ sb = p.src + n * p.src_bs;
-    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
-    const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
-    float* __restrict__ db = p.dst + (int64_t)n * NC * hw;
-    const uint32_t pix = (uint32_t)(yc * w + xc);
-    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
-    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
-    uint32_t fmask4 = 0x01010101u;
-    if ((VALID || p.flow_flags) && fm) fmask4 = *reinterpret_cast<const uint32_t*>(fm + pix);
-
-    if (p.flow_flags) {   // wave-uniform: finiteness / zero tests of the flow operand as a by-product
-        int f = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f |= flag_bits(u4[k], v4[k], ((fmask4 >> (8 * k)) & 0xffu) != 0u);
-        if (!inb) f = 0;
-        f = wave_or_flags(f);
-        if ((tid & 63) == 0 && f) atomicOr(&p.flow_flags[n], f);
-    }
-
-    // ---- sample coordinates: ((x - s*u) * 2) / (w - 1) - 1, then (g + 1) * ((w - 1) / 2)   (utils.py:462-465, 549)
+    const int xc = min(tx * (kLdsTWQ * 4) + lx * 4, w - 4), yc = min(ty * kLdsTH + ly, h - 1);
+    // ((x - s*u) * 2) / (w - 1) - 1, then (g + 1) * ((w - 1) / 2)   (utils.py:462-465, 549)
     const float xf = (float)xc, yf = (float)yc;
     f2 ax[2], ay[2];
 #pragma unroll
@@ -231,33 +246,27 @@ __global__ __launch_bounds__(kLdsNT) void warp_bwd_lds_kernel(const WarpParams p
             }
         }
     }
-    float wgt[4][4];
-    int xi[4], yi[4];
     int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
     const float wf = (float)w, hf = (float)h;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.half_wm1, p.half_wm1};
         const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.half_hm1, p.half_hm1};
-        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
-        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
-        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = 2 * j + i;
-            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            T.sx[k] = sx[i]; T.sy[k] = sy[i];
             // west / north tap as an int, clamped to [-2, size] (beyond that every tap is out of range anyway; a NaN
             // coordinate lands on 0 through the conversion and is blended with NaN weights like the reference's)
-            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
-            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
-            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]);
-            miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+            const int xi = (int)__builtin_amdgcn_fmed3f(floorf(sx[i]), -2.0f, wf);
+            const int yi = (int)__builtin_amdgcn_fmed3f(floorf(sy[i]), -2.0f, hf);
+            minx = min(minx, xi); maxx = max(maxx, xi); miny = min(miny, yi); maxy = max(maxy, yi);
         }
     }
-    minx = wave_min_i32(minx); maxx = wave_max_i32(maxx); miny = wave_min_i32(miny); maxy = wave_max_i32(maxy);
+    minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
     if (NW > 1) {
         if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]);
@@ -268,64 +277,88 @@ __global__ __launch_bounds__(kLdsNT) void warp_bwd_lds_kernel(const WarpParams p
     minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
     miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
     const bool empty = (maxx < minx) || (maxy < miny);
-    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
-    const int Pp = lds_pitch(bw);
-    const int nch = bh * cw;
-    const bool fits = !empty && (16 * (1 + bh * Pp) <= p.lds_bytes) && (nch <= kLdsIters * kLdsNT);
-    f4* lds = reinterpret_cast<f4*>(smem);
-    if (fits) {
-        const uint32_t inv = (1048576u + (uint32_t)cw - 1u) / (uint32_t)cw;
-        const int rounds = (nch + kLdsNT - 1) / kLdsNT;
-        int slot[kLdsIters];
-        f4 q[kLdsIters][NC];
-        uint32_t mq[kLdsIters];
+    B.bx0 = minx & ~3; B.miny = miny;
+    const int bw = empty ? 4 : (((maxx + 4) & ~3) - B.bx0);
+    B.bh = empty ? 1 : (maxy - miny + 1); B.cw = bw >> 2; B.Pp = lds_pitch(bw); B.nch = B.bh * B.cw;
+    B.fits = !empty && (16 * (1 + B.bh * B.Pp) <= p.lds_bytes) && (B.nch <= kLdsIters * kLdsNT);
+}
+
+// step 3a: issue the staging loads of a tile into registers (nothing waits here)
+template <int NC, bool VALID>
+__device__ __forceinline__ void lds_issue(const WarpParams& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+                                          uint32_t hw, const LdsBox& B, LdsStage<NC>& S) {
+    const int tid = threadIdx.x;
+    const uint32_t inv = inv20((uint32_t)B.cw);
+    const int rounds = B.fits ? (B.nch + kLdsNT - 1) / kLdsNT : 0;
 #pragma unroll
-        for (int it = 0; it < kLdsIters; ++it) {
-            if (it < rounds) {
-                const uint32_t i = (uint32_t)tid + it * kLdsNT;
-                const bool on = i < (uint32_t)nch;
-                const uint32_t r = (i * inv) >> 20, c4 = i - r * (uint32_t)cw;
-                const uint32_t g = on ? (uint32_t)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
-                slot[it] = on ? 1 + (int)(r * (uint32_t)Pp + c4) : -1;
+    for (int it = 0; it < kLdsIters; ++it) {
+        S.slot[it] = -1;
+        if (it < rounds) {
+            const uint32_t i = (uint32_t)tid + it * kLdsNT;
+            const bool on = i < (uint32_t)B.nch;
+            const uint32_t r = (i * inv) >> 20, c4 = i - r * (uint32_t)B.cw;
+            const uint32_t g = on ? (uint32_t)((B.miny + (int)r) * p.w + B.bx0) + c4 * 4u : 0u;
+            S.slot[it] = on ? 1 + (int)(r * (uint32_t)B.Pp + c4) : -1;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
-                mq[it] = (VALID && sm) ? *reinterpret_cast<const uint32_t*>(sm + g) : 0x01010101u;
-            }
+            for (int c = 0; c < NC; ++c) S.q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+            S.mq[it] = (VALID && sm) ? *reinterpret_cast<const uint32_t*>(sm + g) : 0x01010101u;
         }
-        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// step 3b: registers -> interleaved LDS slots
+template <int NC, bool VALID>
+__device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsStage<NC>& S) {
+    if (threadIdx.x == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int it = 0; it < kLdsIters; ++it) {
-            if (it < rounds && slot[it] >= 0) {
+    for (int it = 0; it < kLdsIters; ++it) {
+        if (S.slot[it] >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f4 sl = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 4; ++k) {
+                f4 sl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) sl[c] = q[it][c][k];
-                    if (VALID) sl[3] = (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u);
-                    lds[slot[it] + k * cw] = sl;
-                }
+                for (int c = 0; c < NC; ++c) sl[c] = S.q[it][c][k];
+                if (VALID) sl[3] = (float)(((S.mq[it] >> (8 * k)) & 0xffu) != 0u);
+                lds[S.slot[it] + k * B.cw] = sl;
             }
         }
     }
-    __syncthreads();
+}
+
+// step 4: gather from LDS (or from global memory when the box did not fit), blend, epilogue, store
+template <int NC, bool VALID, bool ADD>
+__device__ __forceinline__ void lds_gather_store(const WarpParams& p, int tx, int ty, int n, uint32_t hw,
+                                                 const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+                                                 const LdsCoords& T, const LdsBox& B, uint32_t fmask4,
+                                                 const unsigned char* smem) {
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h;
+    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const uint32_t pix = (uint32_t)(min(y, h - 1) * w + min(x4, w - 4));
+    const int cw16 = B.cw * 16, P16 = B.Pp * 16;
+    const float wf = (float)w, hf = (float)h;
     f4 outv[4];   // per pixel: (c0, c1, c2, mask channel)
-    const int cw16 = cw * 16, P16 = Pp * 16;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        const float fx = floorf(T.sx[k]), fy = floorf(T.sy[k]);
+        const float ww = T.sx[k] - fx, e = 1.0f - ww, nn = T.sy[k] - fy, s = 1.0f - nn;
+        const float wg[4] = {s * e, s * ww, nn * e, nn * ww};
+        const int xi = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, wf), yi = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, hf);
         // west column valid <=> 0 <= xi <= w-1 ; east <=> -1 <= xi <= w-2   (rows alike)
-        const bool x0 = (uint32_t)xi[k] < (uint32_t)w, x1 = (uint32_t)(xi[k] + 1) < (uint32_t)w;
-        const bool y0 = (uint32_t)yi[k] < (uint32_t)h, y1 = (uint32_t)(yi[k] + 1) < (uint32_t)h;
+        const bool x0 = (uint32_t)xi < (uint32_t)w, x1 = (uint32_t)(xi + 1) < (uint32_t)w;
+        const bool y0 = (uint32_t)yi < (uint32_t)h, y1 = (uint32_t)(yi + 1) < (uint32_t)h;
         const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
         f4 tv[4];
-        if (fits) {
-            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+        if (B.fits) {
+            const int xl0 = xi - B.bx0, xl1 = xl0 + 1;
             const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
-            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int r0 = 16 + (yi - B.miny) * P16, r1 = r0 + P16;
             const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
         } else {
-            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+            const int cx[4] = {xi, xi + 1, xi, xi + 1}, cy[4] = {yi, yi, yi + 1, yi + 1};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t og = ok[j] ? (uint32_t)(cy[j] * w + cx[j]) : 0u;
@@ -339,10 +372,10 @@ __global__ __launch_bounds__(kLdsNT) void warp_bwd_lds_kernel(const WarpParams p
             }
         }
         // v_nw*nw, then fma(v_ne, ne, .), fma(v_sw, sw, .), fma(v_se, se, .): the reference's contraction order
-        f4 r = tv[0] * wgt[k][0];
-        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
-        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
-        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        f4 r = tv[0] * wg[0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wg[1], wg[1], wg[1], wg[1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wg[2], wg[2], wg[2], wg[2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wg[3], wg[3], wg[3], wg[3]}, r);
         outv[k] = r;
     }
     if (inb) {
@@ -353,13 +386,12 @@ __global__ __launch_bounds__(kLdsNT) void warp_bwd_lds_kernel(const WarpParams p
                 vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
             *reinterpret_cast<uint32_t*>(p.valid + (int64_t)n * hw + pix) = vo;
         }
+        float* __restrict__ db = p.dst + (int64_t)n * NC * hw;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
-            if (ADD) {
-                f4 a;
-                if (p.addend == p.flow && p.addend_bs == p.flow_bs && c < 2) a = c == 0 ? u4 : v4;   // wave-uniform
-                else a = *reinterpret_cast<const f4*>(p.addend + n * p.addend_bs + c * hw + pix);
+            if (ADD) {   // re-read rather than kept in registers across the pipeline (an L2 hit when it aliases the flow)
+                const f4 a = *reinterpret_cast<const f4*>(p.addend + n * p.addend_bs + c * hw + pix);
                 o = a * p.a_sign + o * p.g_sign;
             }
             if (p.round_mode != OFL_ROUND_NONE) {
@@ -369,6 +401,61 @@ __global__ __launch_bounds__(kLdsNT) void warp_bwd_lds_kernel(const WarpParams p
             *reinterpret_cast<f4*>(db + c * hw + pix) = o;
         }
     }
+}
+
+template <int NC, bool VALID, bool ADD>
+__global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParams p) {
+    constexpr int NW = kLdsNT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[2][NW][4];
+    int tx, ty2, n;                      // the grid counts tile PAIRS: tiles_y = ceil(h / (2 * kLdsTH))
+    if (!decode_tile(p, tx, ty2, n)) return;
+    const int tyA = 2 * ty2, tyB = tyA + 1;
+    const bool haveB = tyB * kLdsTH < p.h;
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const float* __restrict__ sb = p.src + n * p.src_bs;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
+    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
+    const uint32_t pixA = (uint32_t)(min(tyA * kLdsTH + ly, h - 1) * w + xq);
+    const uint32_t pixB = (uint32_t)(min(tyB * kLdsTH + ly, h - 1) * w + xq);
+    const f4 uA = *reinterpret_cast<const f4*>(fu + pixA), vA = *reinterpret_cast<const f4*>(fu + hw + pixA);
+    const f4 uB = *reinterpret_cast<const f4*>(fu + pixB), vB = *reinterpret_cast<const f4*>(fu + hw + pixB);
+    uint32_t fmA = 0x01010101u, fmB = 0x01010101u;
+    if ((VALID || p.flow_flags) && fm) {
+        fmA = *reinterpret_cast<const uint32_t*>(fm + pixA);
+        fmB = *reinterpret_cast<const uint32_t*>(fm + pixB);
+    }
+    if (p.flow_flags) {   // wave-uniform: finiteness / zero tests of the flow operand as a by-product
+        int f = 0;
+        const bool inA = (x4 < w) && (tyA * kLdsTH + ly < h), inB = (x4 < w) && (tyB * kLdsTH + ly < h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (inA) f |= flag_bits(uA[k], vA[k], ((fmA >> (8 * k)) & 0xffu) != 0u);
+            if (inB) f |= flag_bits(uB[k], vB[k], ((fmB >> (8 * k)) & 0xffu) != 0u);
+        }
+        f = wave_or_flags(f);
+        if ((tid & 63) == 0 && f) atomicOr(&p.flow_flags[n], f);
+    }
+    f4* lds = reinterpret_cast<f4*>(smem);
+    LdsCoords TA, TB;
+    LdsBox BA, BB;
+    LdsStage<NC> S;
+    lds_coords_box(p, tx, tyA, uA, vA, TA, BA, red[0]);
+    lds_issue<NC, VALID>(p, sb, sm, hw, BA, S);                 // staging loads of A fly ...
+    lds_coords_box(p, tx, tyB, uB, vB, TB, BB, red[1]);         // ... while B's coordinates are computed
+    lds_write<NC, VALID>(lds, BA, S);
+    lds_barrier();
+    if (haveB) lds_issue<NC, VALID>(p, sb, sm, hw, BB, S);      // staging loads of B fly while A is gathered and stored
+    lds_gather_store<NC, VALID, ADD>(p, tx, tyA, n, hw, sb, sm, TA, BA, fmA, smem);
+    if (!haveB) return;
+    lds_barrier();
+    lds_write<NC, VALID>(lds, BB, S);
+    lds_barrier();
+    lds_gather_store<NC, VALID, ADD>(p, tx, tyB, n, hw, sb, sm, TB, BB, fmB, smem);
 }
 
 // CT = compile-time channel count (0: run-time p.c)
@@ -772,7 +859,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
                                src_mask_bs, src_flags, hw);
             p.src_flags = nullptr;
         }
-        const unsigned g = warp_geometry(p, kLdsTWQ * 4, kLdsTH);
+        const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
         switch (c) {
             case 1: return launch_warp_lds<1>(p, g, st);
             case 2: return launch_warp_lds<2>(p, g, st);

@@ -1531,6 +1531,742 @@ __global__ __launch_bounds__(NT) void warp_v8(const P5 pp, const int lds_bytes) 
     }
 }
 
+
+// wave-wide min / max without LDS: four DPP butterfly steps inside each row of 16 lanes, then the four row results are
+// combined on the scalar unit (v_readlane + s_min / s_max).  ~12 instructions, ~100 cycles (ds_bpermute chain: ~600+).
+#define OFL_DPP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xf, 0xf, false)
+__device__ __forceinline__ int wave_min_dpp(int v) {
+    v = min(v, OFL_DPP(v, 0xB1));    // quad_perm [1,0,3,2]
+    v = min(v, OFL_DPP(v, 0x4E));    // quad_perm [2,3,0,1]
+    v = min(v, OFL_DPP(v, 0x141));   // row_half_mirror
+    v = min(v, OFL_DPP(v, 0x140));   // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_dpp(int v) {
+    v = max(v, OFL_DPP(v, 0xB1));
+    v = max(v, OFL_DPP(v, 0x4E));
+    v = max(v, OFL_DPP(v, 0x141));
+    v = max(v, OFL_DPP(v, 0x140));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// ceil(2^20 / cw) for cw = 1..127 without an integer division: float reciprocal + one correction step
+__device__ __forceinline__ unsigned inv20(unsigned cw) {
+    unsigned q = (unsigned)(1048576.0f / (float)cw);       // within 1 of floor
+    while (q * cw > 1048576u) --q;
+    while ((q + 1) * cw <= 1048576u) ++q;                   // q = floor(2^20 / cw)
+    return q * cw == 1048576u ? q : q + 1;
+}
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v14(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + pix);
+
+    // ---- (x - u) * 2 / (w - 1): packed, exact via two Newton refinements on RN(1/(w-1)); operands outside
+    //      [2^-60, 2^100] (never in practice) send the whole wave through the IEEE divide instead
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        // range guard: big operands anywhere, or a tiny non-zero operand (only possible in column 0 / row 0)
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            // integer coordinate of the west / north tap, clamped to [-2, size]: everything beyond is out of range anyway
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]); miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+        }
+    }
+    minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    // touched columns [minx, maxx + 1] and rows [miny, maxy + 1], clipped to the image (all wave-uniform -> SALU)
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    const bool empty = (maxx < minx) || (maxy < miny);
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = inv20((unsigned)cw);
+        const int rounds = (nch + NT - 1) / NT;        // wave-uniform: only the rounds this tile needs are issued
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+                const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+            }
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds && slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    __syncthreads();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+    const int cw16 = cw * 16, P16 = Pp * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // x0 valid <=> 0 <= xi <= w-1 ; x1 valid <=> -1 <= xi <= w-2   (same for y)
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+            // byte offset of slot (xl, yl): 16 + yl*P16 + (xl & 3)*cw16 + (xl >> 2)*16
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v8t(const P5 pp, const int lds_bytes, unsigned long long* stamps) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    unsigned long long ts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[0] = t_; }
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = *reinterpret_cast<const f4*>(fu + hw + pix);
+    const unsigned fmask4 = *reinterpret_cast<const unsigned*>(fm + pix);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[1] = t_; }
+    // ---- (x - u) * 2 / (w - 1): packed, exact via two Newton refinements on RN(1/(w-1)); operands outside
+    //      [2^-60, 2^100] (never in practice) send the whole wave through the IEEE divide instead
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        // range guard: big operands anywhere, or a tiny non-zero operand (only possible in column 0 / row 0)
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            // integer coordinate of the west / north tap, clamped to [-2, size]: everything beyond is out of range anyway
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]); miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+        }
+    }
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[2] = t_; }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    // touched columns [minx, maxx + 1] and rows [miny, maxy + 1], clipped to the image (all wave-uniform -> SALU)
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[3] = t_; }
+    const bool empty = (maxx < minx) || (maxy < miny);
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        const int rounds = (nch + NT - 1) / NT;        // wave-uniform: only the rounds this tile needs are issued
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+                const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+            }
+        }
+        if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[4] = t_; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[5] = t_; }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds && slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[6] = t_; }
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+    const int cw16 = cw * 16, P16 = Pp * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // x0 valid <=> 0 <= xi <= w-1 ; x1 valid <=> -1 <= xi <= w-2   (same for y)
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+            // byte offset of slot (xl, yl): 16 + yl*P16 + (xl & 3)*cw16 + (xl >> 2)*16
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[7] = t_; }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[8] = t_; }
+    if (tid == 0 && ts[4] != 0) { for (int i = 1; i < 9; ++i) atomicAdd(&stamps[(blockIdx.x & 63) * 16 + i], ts[i] - ts[i - 1]); atomicAdd(&stamps[(blockIdx.x & 63) * 16], 1ull); }
+}
+
+struct Pre13 { f4 u4, v4; unsigned fm4; int tx, ty, n; bool have; };
+
+template <int NT, int TWQ>
+__device__ __forceinline__ void v13_prefetch(const P& p, unsigned it, Pre13& q) {
+    constexpr int TH = NT / TWQ;
+    q.have = decode_tile_at(p, it, q.tx, q.ty, q.n);
+    if (q.have) {
+        const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+        const unsigned hw = (unsigned)(p.h * p.w);
+        const unsigned pix = (unsigned)(min(q.ty * TH + ly, p.h - 1) * p.w + min(q.tx * (TWQ * 4) + lx * 4, p.w - 4));
+        q.u4 = *reinterpret_cast<const f4*>(p.flow + (size_t)q.n * 2 * hw + pix);
+        q.v4 = *reinterpret_cast<const f4*>(p.flow + (size_t)q.n * 2 * hw + hw + pix);
+        q.fm4 = *reinterpret_cast<const unsigned*>(p.fmask + (size_t)q.n * hw + pix);
+    }
+}
+
+template <int NT, int TWQ, int ITERS>
+__device__ __forceinline__ void v13_process(const P5& pp, const int lds_bytes, const Pre13& cur, unsigned char* smem, int (*red)[4]) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    const P& p = pp.p;
+    const int tx = cur.tx, ty = cur.ty, n = cur.n;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = cur.u4, v4 = cur.v4;
+    const unsigned fmask4 = cur.fm4;
+
+    // ---- (x - u) * 2 / (w - 1): packed, exact via two Newton refinements on RN(1/(w-1)); operands outside
+    //      [2^-60, 2^100] (never in practice) send the whole wave through the IEEE divide instead
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        // range guard: big operands anywhere, or a tiny non-zero operand (only possible in column 0 / row 0)
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            // integer coordinate of the west / north tap, clamped to [-2, size]: everything beyond is out of range anyway
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]); miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    // touched columns [minx, maxx + 1] and rows [miny, maxy + 1], clipped to the image (all wave-uniform -> SALU)
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    const bool empty = (maxx < minx) || (maxy < miny);
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        const int rounds = (nch + NT - 1) / NT;        // wave-uniform: only the rounds this tile needs are issued
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+                const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+            }
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds && slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    lds_barrier();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+    const int cw16 = cw * 16, P16 = Pp * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // x0 valid <=> 0 <= xi <= w-1 ; x1 valid <=> -1 <= xi <= w-2   (same for y)
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+            // byte offset of slot (xl, yl): 16 + yl*P16 + (xl & 3)*cw16 + (xl >> 2)*16
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    lds_barrier();   // every wave is done reading LDS / red: the next tile may overwrite them
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT) void warp_v13(const P5 pp, const int lds_bytes) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    Pre13 A, B;
+    v13_prefetch<NT, TWQ>(p, 0, A);
+    for (unsigned it = 1;; it += 2) {
+        if (!A.have) break;
+        v13_prefetch<NT, TWQ>(p, it, B);            // flow of the next tile in flight while this one is processed
+        v13_process<NT, TWQ, ITERS>(pp, lds_bytes, A, smem, red);
+        if (!B.have) break;
+        v13_prefetch<NT, TWQ>(p, it + 1, A);
+        v13_process<NT, TWQ, ITERS>(pp, lds_bytes, B, smem, red);
+    }
+}
+
+template <int NT, int TWQ, int ITERS, int NTMODE>
+__global__ __launch_bounds__(NT) void warp_v8n(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    const P& p = pp.p;
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const int xc = min(x4, w - 4), yc = min(y, h - 1);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const float* __restrict__ sb = p.src + (size_t)n * 3 * hw;
+    const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const unsigned pix = (unsigned)(yc * w + xc);
+    const f4 u4 = (NTMODE & 2) ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(fu + pix)) : *reinterpret_cast<const f4*>(fu + pix);
+    const f4 v4 = (NTMODE & 2) ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(fu + hw + pix)) : *reinterpret_cast<const f4*>(fu + hw + pix);
+    const unsigned fmask4 = (NTMODE & 2) ? __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(fm + pix)) : *reinterpret_cast<const unsigned*>(fm + pix);
+
+    // ---- (x - u) * 2 / (w - 1): packed, exact via two Newton refinements on RN(1/(w-1)); operands outside
+    //      [2^-60, 2^100] (never in practice) send the whole wave through the IEEE divide instead
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        // range guard: big operands anywhere, or a tiny non-zero operand (only possible in column 0 / row 0)
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    float wgt[4][4]; int xi[4], yi[4];
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+        const f2 fx = {floorf(sx.x), floorf(sx.y)}, fy = {floorf(sy.x), floorf(sy.y)};
+        const f2 ww = sx - fx, e = 1.0f - ww, nn = sy - fy, s = 1.0f - nn;
+        const f2 wnw = s * e, wne = s * ww, wsw = nn * e, wse = nn * ww;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            wgt[k][0] = wnw[i]; wgt[k][1] = wne[i]; wgt[k][2] = wsw[i]; wgt[k][3] = wse[i];
+            // integer coordinate of the west / north tap, clamped to [-2, size]: everything beyond is out of range anyway
+            xi[k] = (int)__builtin_amdgcn_fmed3f(fx[i], -2.0f, wf);
+            yi[k] = (int)__builtin_amdgcn_fmed3f(fy[i], -2.0f, hf);
+            minx = min(minx, xi[k]); maxx = max(maxx, xi[k]); miny = min(miny, yi[k]); maxy = max(maxy, yi[k]);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    // touched columns [minx, maxx + 1] and rows [miny, maxy + 1], clipped to the image (all wave-uniform -> SALU)
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    const bool empty = (maxx < minx) || (maxy < miny);
+    const int bx0 = minx & ~3, bw = empty ? 4 : (((maxx + 4) & ~3) - bx0), bh = empty ? 1 : (maxy - miny + 1), cw = bw >> 2;
+    const int Pp = pitch_for(bw, TWQ);                 // row pitch in 16-byte slots
+    const int nch = bh * cw;
+    const bool fits = !empty && (16 * (1 + bh * Pp) <= lds_bytes) && (nch <= ITERS * NT);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    if (fits) {
+        const unsigned inv = (1048576u + (unsigned)cw - 1u) / (unsigned)cw;
+        const int rounds = (nch + NT - 1) / NT;        // wave-uniform: only the rounds this tile needs are issued
+        int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)cw;
+                const unsigned g = on ? (unsigned)((miny + (int)r) * w + bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+            }
+        }
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (it < rounds && slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+    }
+    __syncthreads();
+    f4 outv[4];   // per pixel: (c0, c1, c2, mask)
+    const int cw16 = cw * 16, P16 = Pp * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // x0 valid <=> 0 <= xi <= w-1 ; x1 valid <=> -1 <= xi <= w-2   (same for y)
+        const bool x0 = (unsigned)xi[k] < (unsigned)w, x1 = (unsigned)(xi[k] + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi[k] < (unsigned)h, y1 = (unsigned)(yi[k] + 1) < (unsigned)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (fits) {
+            const int xl0 = xi[k] - bx0, xl1 = xl0 + 1;
+            // byte offset of slot (xl, yl): 16 + yl*P16 + (xl & 3)*cw16 + (xl >> 2)*16
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi[k] - miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi[k], xi[k] + 1, xi[k], xi[k] + 1}, cy[4] = {yi[k], yi[k], yi[k] + 1, yi[k] + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 r = tv[0] * wgt[k][0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wgt[k][1], wgt[k][1], wgt[k][1], wgt[k][1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wgt[k][2], wgt[k][2], wgt[k][2], wgt[k][2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wgt[k][3], wgt[k][3], wgt[k][3], wgt[k][3]}, r);
+        outv[k] = r;
+    }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        if (NTMODE & 1) __builtin_nontemporal_store(vo, reinterpret_cast<unsigned*>(vb + pix));
+        else *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f4 o = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+            if (NTMODE & 1) __builtin_nontemporal_store(o, reinterpret_cast<f4*>(db + c * hw + pix));
+            else *reinterpret_cast<f4*>(db + c * hw + pix) = o;
+        }
+    }
+}
+
 template <int NT, int TWQ, int ITERS, int ABL>
 __global__ __launch_bounds__(NT) void warp_v8a(const P5 pp, const int lds_bytes) {
     constexpr int TH = NT / TWQ, NW = NT / 64;
@@ -1695,6 +2431,7 @@ __global__ __launch_bounds__(NT) void warp_v8a(const P5 pp, const int lds_bytes)
         *reinterpret_cast<unsigned*>(vb + pix) = vo;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
+            if ((ABL != 6 && ABL != 7) || (ABL == 7 && c == 0) || outv[0][c] == 1.2345e-30f)
             *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
         }
     }
@@ -2328,6 +3065,429 @@ __global__ __launch_bounds__(NT) void warp_v11(const P5 pp, const int lds_bytes)
     }
 }
 
+struct TileTaps12 { float sx[4], sy[4]; };
+struct TileBox12 { int bx0, miny, cw, Pp, bh, nch; bool fits, empty; };   // wave-uniform
+struct TileId12 { int tx, ty, n; bool have; };
+
+template <int NT, int TWQ>
+__device__ __forceinline__ void v12_load_flow(const P& p, const TileId12& t, unsigned hw, f4& u4, f4& v4, unsigned& fm4, unsigned& pix, bool& inb) {
+    constexpr int TH = NT / TWQ;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int x4 = t.tx * (TWQ * 4) + lx * 4, y = t.ty * TH + ly;
+    inb = (x4 < p.w) && (y < p.h);
+    pix = (unsigned)(min(y, p.h - 1) * p.w + min(x4, p.w - 4));
+    u4 = *reinterpret_cast<const f4*>(p.flow + (size_t)t.n * 2 * hw + pix);
+    v4 = *reinterpret_cast<const f4*>(p.flow + (size_t)t.n * 2 * hw + hw + pix);
+    fm4 = *reinterpret_cast<const unsigned*>(p.fmask + (size_t)t.n * hw + pix);
+}
+
+template <int NT, int TWQ, int ITERS>
+__device__ __forceinline__ void v12_taps(const P5& pp, const TileId12& t, const f4& u4, const f4& v4, TileTaps12& T, TileBox12& B,
+                                         int (*red)[4], const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    const P& p = pp.p;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const int xc = min(t.tx * (TWQ * 4) + lx * 4, w - 4), yc = min(t.ty * TH + ly, h - 1);
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            T.sx[k] = sx[i]; T.sy[k] = sy[i];
+            const int xi = (int)__builtin_amdgcn_fmed3f(floorf(sx[i]), -2.0f, wf), yi = (int)__builtin_amdgcn_fmed3f(floorf(sy[i]), -2.0f, hf);
+            minx = min(minx, xi); maxx = max(maxx, xi); miny = min(miny, yi); maxy = max(maxy, yi);
+        }
+    }
+    minx = wave_min(minx); maxx = wave_max(maxx); miny = wave_min(miny); maxy = wave_max(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    B.empty = (maxx < minx) || (maxy < miny);
+    B.bx0 = minx & ~3; B.miny = miny;
+    const int bw = B.empty ? 4 : (((maxx + 4) & ~3) - B.bx0);
+    B.bh = B.empty ? 1 : (maxy - miny + 1); B.cw = bw >> 2; B.Pp = pitch_for(bw, TWQ); B.nch = B.bh * B.cw;
+    B.fits = !B.empty && (16 * (1 + B.bh * B.Pp) <= lds_bytes) && (B.nch <= ITERS * NT);
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT, (6 * NT) / 256 > 0 ? 3 : 1) void warp_v12(const P5 pp, const int lds_bytes) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[2][NW][4];
+    const P& p = pp.p;
+    const int tid = threadIdx.x;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    f4* lds = reinterpret_cast<f4*>(smem);
+
+    TileId12 tc, tn, tnn;                    // current, next, next-next
+    tc.have = decode_tile_at(p, 0, tc.tx, tc.ty, tc.n);
+    if (!tc.have) return;
+    f4 u4, v4; unsigned fm_c, pix_c; bool inb_c;
+    v12_load_flow<NT, TWQ>(p, tc, hw, u4, v4, fm_c, pix_c, inb_c);
+    TileTaps12 Tc; TileBox12 Bc;
+    v12_taps<NT, TWQ, ITERS>(pp, tc, u4, v4, Tc, Bc, red[0], lds_bytes);
+    // staging registers of the CURRENT tile (loaded one iteration ahead)
+    int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS];
+    auto issue_staging = [&](const TileId12& t, const TileBox12& B) {
+        const float* __restrict__ sb = p.src + (size_t)t.n * 3 * hw; const uint8_t* __restrict__ sm = p.smask + (size_t)t.n * hw;
+        const unsigned inv = (1048576u + (unsigned)B.cw - 1u) / (unsigned)B.cw;
+        const int rounds = B.fits ? (B.nch + NT - 1) / NT : 0;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            slot[it] = -1;
+            if (it < rounds) {
+                const unsigned i = (unsigned)tid + it * NT;
+                const bool on = i < (unsigned)B.nch;
+                const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)B.cw;
+                const unsigned g = on ? (unsigned)((B.miny + (int)r) * w + B.bx0) + c4 * 4u : 0u;
+                slot[it] = on ? 1 + (int)(r * (unsigned)B.Pp + c4) : -1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+                mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+            }
+        }
+    };
+    issue_staging(tc, Bc);
+    tn.have = decode_tile_at(p, 1, tn.tx, tn.ty, tn.n);
+    f4 nu4, nv4; unsigned fm_n = 0, pix_n = 0; bool inb_n = false;
+    if (tn.have) v12_load_flow<NT, TWQ>(p, tn, hw, nu4, nv4, fm_n, pix_n, inb_n);
+
+    for (unsigned it_tile = 2;; ++it_tile) {
+        // ---- (1) staged registers of the current tile -> LDS
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    lds[slot[it] + k * Bc.cw] = (f4){q[it][0][k], q[it][1][k], q[it][2][k], (float)(((mq[it] >> (8 * k)) & 0xffu) != 0u)};
+            }
+        }
+        lds_barrier();
+        // ---- (2) next tile: taps + bbox from its (prefetched) flow, issue its staging loads, prefetch the flow after it
+        TileTaps12 Tn; TileBox12 Bn; f4 nnu4, nnv4; unsigned fm_nn = 0, pix_nn = 0; bool inb_nn = false;
+        if (tn.have) {
+            v12_taps<NT, TWQ, ITERS>(pp, tn, nu4, nv4, Tn, Bn, red[it_tile & 1], lds_bytes);
+            issue_staging(tn, Bn);
+            tnn.have = decode_tile_at(p, it_tile, tnn.tx, tnn.ty, tnn.n);
+            if (tnn.have) v12_load_flow<NT, TWQ>(p, tnn, hw, nnu4, nnv4, fm_nn, pix_nn, inb_nn);
+        } else {
+            tnn.have = false;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) slot[it] = -1;
+        }
+        // ---- (3) gather the current tile from LDS, blend, store
+        {
+            const float* __restrict__ sb = p.src + (size_t)tc.n * 3 * hw; const uint8_t* __restrict__ sm = p.smask + (size_t)tc.n * hw;
+            float* __restrict__ db = p.dst + (size_t)tc.n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)tc.n * hw;
+            const int cw16 = Bc.cw * 16, P16 = Bc.Pp * 16;
+            f4 outv[4];
+            const float wf_ = (float)w, hf_ = (float)h;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float fx = floorf(Tc.sx[k]), fy = floorf(Tc.sy[k]);
+                const float ww = Tc.sx[k] - fx, e_ = 1.0f - ww, nn = Tc.sy[k] - fy, s_ = 1.0f - nn;
+                const float wg[4] = {s_ * e_, s_ * ww, nn * e_, nn * ww};
+                const int xi_ = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, wf_), yi_ = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, hf_);
+                const bool x0 = (unsigned)xi_ < (unsigned)w, x1 = (unsigned)(xi_ + 1) < (unsigned)w;
+                const bool y0 = (unsigned)yi_ < (unsigned)h, y1 = (unsigned)(yi_ + 1) < (unsigned)h;
+                const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+                f4 tv[4];
+                if (Bc.fits) {
+                    const int xl0 = xi_ - Bc.bx0, xl1 = xl0 + 1;
+                    const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+                    const int r0 = 16 + (yi_ - Bc.miny) * P16, r1 = r0 + P16;
+                    const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+                } else {
+                    const int cx[4] = {xi_, xi_ + 1, xi_, xi_ + 1}, cy[4] = {yi_, yi_, yi_ + 1, yi_ + 1};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                        tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                f4 r = tv[0] * wg[0];
+                r = __builtin_elementwise_fma(tv[1], (f4){wg[1], wg[1], wg[1], wg[1]}, r);
+                r = __builtin_elementwise_fma(tv[2], (f4){wg[2], wg[2], wg[2], wg[2]}, r);
+                r = __builtin_elementwise_fma(tv[3], (f4){wg[3], wg[3], wg[3], wg[3]}, r);
+                outv[k] = r;
+            }
+            if (inb_c) {
+                unsigned vo = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fm_c >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+                *reinterpret_cast<unsigned*>(vb + pix_c) = vo;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<f4*>(db + c * hw + pix_c) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+            }
+        }
+        if (!tn.have) break;
+        lds_barrier();       // every wave is done reading LDS before the next tile overwrites it
+        // ---- rotate
+        tc = tn; Tc = Tn; Bc = Bn; fm_c = fm_n; pix_c = pix_n; inb_c = inb_n;
+        tn = tnn; nu4 = nnu4; nv4 = nnv4; fm_n = fm_nn; pix_n = pix_nn; inb_n = inb_nn;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V15: two vertically adjacent 32x16 tiles per (non-persistent) block, straight-line software pipeline:
+//   flow(A), flow(B) loads -> taps/bbox(A) -> staging loads(A) -> taps/bbox(B) -> LDS(A) -> staging loads(B) in flight
+//   while A is gathered / blended / stored -> LDS(B) -> gather / store B.   One LDS buffer, LDS-only barriers.
+// ---------------------------------------------------------------------------------------------
+struct T15 { float sx[4], sy[4]; };
+struct B15 { int bx0, miny, cw, Pp, bh, nch; bool fits; };
+
+template <int NT, int TWQ, int ITERS>
+__device__ __forceinline__ void v15_taps(const P5& pp, int tx, int ty, const f4& u4, const f4& v4, T15& T, B15& B, int (*red)[4], const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    const P& p = pp.p;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const int xc = min(tx * (TWQ * 4) + lx * 4, w - 4), yc = min(ty * TH + ly, h - 1);
+    const float xf = (float)xc, yf = (float)yc;
+    f2 ax[2], ay[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 xx = {xf + (float)(2 * j), xf + (float)(2 * j + 1)}, yy = {yf, yf};
+        ax[j] = (xx - (f2){u4[2 * j], u4[2 * j + 1]}) * 2.0f;
+        ay[j] = (yy - (f2){v4[2 * j], v4[2 * j + 1]}) * 2.0f;
+    }
+    f2 qx[2], qy[2];
+    {
+        const f2 rw = {pp.rw, pp.rw}, rh = {pp.rh, pp.rh}, nbw = {-p.wm1, -p.wm1}, nbh = {-p.hm1, -p.hm1};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f2 q = ax[j] * rw; f2 r = __builtin_elementwise_fma(nbw, q, ax[j]); q = __builtin_elementwise_fma(r, rw, q);
+            r = __builtin_elementwise_fma(nbw, q, ax[j]); qx[j] = __builtin_elementwise_fma(r, rw, q);
+            q = ay[j] * rh; r = __builtin_elementwise_fma(nbh, q, ay[j]); q = __builtin_elementwise_fma(r, rh, q);
+            r = __builtin_elementwise_fma(nbh, q, ay[j]); qy[j] = __builtin_elementwise_fma(r, rh, q);
+        }
+        const float big = fmaxf(fmaxf(fmaxf(fabsf(ax[0].x), fabsf(ax[0].y)), fmaxf(fabsf(ax[1].x), fabsf(ax[1].y))),
+                                fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
+        bool bad = !(big <= 0x1p100f);
+        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (yc == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                qx[j] = (f2){ax[j].x / p.wm1, ax[j].y / p.wm1}; qy[j] = (f2){ay[j].x / p.hm1, ay[j].y / p.hm1};
+            }
+        }
+    }
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f2 sx = ((qx[j] - 1.0f) + 1.0f) * (f2){p.hwm1, p.hwm1};
+        const f2 sy = ((qy[j] - 1.0f) + 1.0f) * (f2){p.hhm1, p.hhm1};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = 2 * j + i;
+            T.sx[k] = sx[i]; T.sy[k] = sy[i];
+            const int xi = (int)__builtin_amdgcn_fmed3f(floorf(sx[i]), -2.0f, wf), yi = (int)__builtin_amdgcn_fmed3f(floorf(sy[i]), -2.0f, hf);
+            minx = min(minx, xi); maxx = max(maxx, xi); miny = min(miny, yi); maxy = max(maxy, yi);
+        }
+    }
+    minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
+    if (NW > 1) {
+        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]); }
+    }
+    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
+    const bool empty = (maxx < minx) || (maxy < miny);
+    B.bx0 = minx & ~3; B.miny = miny;
+    const int bw = empty ? 4 : (((maxx + 4) & ~3) - B.bx0);
+    B.bh = empty ? 1 : (maxy - miny + 1); B.cw = bw >> 2; B.Pp = pitch_for(bw, TWQ); B.nch = B.bh * B.cw;
+    B.fits = !empty && (16 * (1 + B.bh * B.Pp) <= lds_bytes) && (B.nch <= ITERS * NT);
+}
+
+template <int NT, int ITERS>
+struct Stage15 { int slot[ITERS]; f4 q[ITERS][3]; unsigned mq[ITERS]; };
+
+template <int NT, int ITERS>
+__device__ __forceinline__ void v15_issue(const P& p, int n, unsigned hw, const B15& B, Stage15<NT, ITERS>& S) {
+    const float* __restrict__ sb = p.src + (size_t)n * 3 * hw; const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw;
+    const int tid = threadIdx.x;
+    const unsigned inv = inv20((unsigned)B.cw);
+    const int rounds = B.fits ? (B.nch + NT - 1) / NT : 0;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        S.slot[it] = -1;
+        if (it < rounds) {
+            const unsigned i = (unsigned)tid + it * NT;
+            const bool on = i < (unsigned)B.nch;
+            const unsigned r = (i * inv) >> 20, c4 = i - r * (unsigned)B.cw;
+            const unsigned g = on ? (unsigned)((B.miny + (int)r) * p.w + B.bx0) + c4 * 4u : 0u;
+            S.slot[it] = on ? 1 + (int)(r * (unsigned)B.Pp + c4) : -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S.q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
+            S.mq[it] = *reinterpret_cast<const unsigned*>(sm + g);
+        }
+    }
+}
+
+template <int NT, int ITERS>
+__device__ __forceinline__ void v15_write(f4* lds, const B15& B, const Stage15<NT, ITERS>& S) {
+    if (threadIdx.x == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        if (S.slot[it] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                lds[S.slot[it] + k * B.cw] = (f4){S.q[it][0][k], S.q[it][1][k], S.q[it][2][k], (float)(((S.mq[it] >> (8 * k)) & 0xffu) != 0u)};
+        }
+    }
+}
+
+template <int NT, int TWQ>
+__device__ __forceinline__ void v15_gather_store(const P& p, int tx, int ty, int n, unsigned hw, const T15& T, const B15& B,
+                                                 unsigned fm4, const unsigned char* smem) {
+    constexpr int TH = NT / TWQ;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const int x4 = tx * (TWQ * 4) + lx * 4, y = ty * TH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const unsigned pix = (unsigned)(min(y, h - 1) * w + min(x4, w - 4));
+    const float* __restrict__ sb = p.src + (size_t)n * 3 * hw; const uint8_t* __restrict__ sm = p.smask + (size_t)n * hw;
+    float* __restrict__ db = p.dst + (size_t)n * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n * hw;
+    const int cw16 = B.cw * 16, P16 = B.Pp * 16;
+    const float wf_ = (float)w, hf_ = (float)h;
+    f4 outv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float fx = floorf(T.sx[k]), fy = floorf(T.sy[k]);
+        const float ww = T.sx[k] - fx, e_ = 1.0f - ww, nn = T.sy[k] - fy, s_ = 1.0f - nn;
+        const float wg[4] = {s_ * e_, s_ * ww, nn * e_, nn * ww};
+        const int xi_ = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, wf_), yi_ = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, hf_);
+        const bool x0 = (unsigned)xi_ < (unsigned)w, x1 = (unsigned)(xi_ + 1) < (unsigned)w;
+        const bool y0 = (unsigned)yi_ < (unsigned)h, y1 = (unsigned)(yi_ + 1) < (unsigned)h;
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+        f4 tv[4];
+        if (B.fits) {
+            const int xl0 = xi_ - B.bx0, xl1 = xl0 + 1;
+            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+            const int r0 = 16 + (yi_ - B.miny) * P16, r1 = r0 + P16;
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else {
+            const int cx[4] = {xi_, xi_ + 1, xi_, xi_ + 1}, cy[4] = {yi_, yi_, yi_ + 1, yi_ + 1};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f4 r = tv[0] * wg[0];
+        r = __builtin_elementwise_fma(tv[1], (f4){wg[1], wg[1], wg[1], wg[1]}, r);
+        r = __builtin_elementwise_fma(tv[2], (f4){wg[2], wg[2], wg[2], wg[2]}, r);
+        r = __builtin_elementwise_fma(tv[3], (f4){wg[3], wg[3], wg[3], wg[3]}, r);
+        outv[k] = r;
+    }
+    if (inb) {
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fm4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        *reinterpret_cast<unsigned*>(vb + pix) = vo;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+    }
+}
+
+template <int NT, int TWQ, int ITERS>
+__global__ __launch_bounds__(NT, 3) void warp_v15(const P5 pp, const int lds_bytes) {
+    constexpr int TH = NT / TWQ, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[2][NW][4];
+    const P& p = pp.p;
+    int tx, ty2, n;                         // the launch grid counts tile PAIRS: tiles_y = ceil(h / (2 * TH))
+    if (!decode_tile(p, tx, ty2, n)) return;
+    const int tyA = 2 * ty2, tyB = 2 * ty2 + 1;
+    const bool haveB = tyB * TH < p.h;
+    const int tid = threadIdx.x, lx = tid % TWQ, ly = tid / TWQ;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    const int xq = min(tx * (TWQ * 4) + lx * 4, w - 4);
+    const unsigned pixA = (unsigned)(min(tyA * TH + ly, h - 1) * w + xq), pixB = (unsigned)(min(tyB * TH + ly, h - 1) * w + xq);
+    const float* __restrict__ fu = p.flow + (size_t)n * 2 * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n * hw;
+    const f4 uA = *reinterpret_cast<const f4*>(fu + pixA), vA = *reinterpret_cast<const f4*>(fu + hw + pixA);
+    const unsigned fmA = *reinterpret_cast<const unsigned*>(fm + pixA);
+    const f4 uB = *reinterpret_cast<const f4*>(fu + pixB), vB = *reinterpret_cast<const f4*>(fu + hw + pixB);
+    const unsigned fmB = *reinterpret_cast<const unsigned*>(fm + pixB);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    T15 TA, TB; B15 BA, BB;
+    Stage15<NT, ITERS> S;
+    v15_taps<NT, TWQ, ITERS>(pp, tx, tyA, uA, vA, TA, BA, red[0], lds_bytes);
+    v15_issue<NT, ITERS>(p, n, hw, BA, S);                                     // staging loads of A in flight ...
+    v15_taps<NT, TWQ, ITERS>(pp, tx, tyB, uB, vB, TB, BB, red[1], lds_bytes);  // ... while B's coordinates are computed
+    v15_write<NT, ITERS>(lds, BA, S);
+    lds_barrier();
+    if (haveB) v15_issue<NT, ITERS>(p, n, hw, BB, S);                          // staging loads of B in flight while A is gathered
+    v15_gather_store<NT, TWQ>(p, tx, tyA, n, hw, TA, BA, fmA, smem);
+    if (!haveB) return;
+    lds_barrier();
+    v15_write<NT, ITERS>(lds, BB, S);
+    lds_barrier();
+    v15_gather_store<NT, TWQ>(p, tx, tyB, n, hw, TB, BB, fmB, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // streaming ceilings with the same byte mix (no gather): dword-per-lane and 16-byte-per-lane
 // ---------------------------------------------------------------------------------------------
@@ -2584,6 +3744,8 @@ int main(int argc, char** argv) {
     RUN8A("abl v8 no LDS writes", 2)
     RUN8A("abl v8 no LDS gather reads", 3)
     RUN8A("abl v8 no stores", 4)
+    RUN8A("abl v8 store mask only (1 B/px)", 6)
+    RUN8A("abl v8 store mask + 1 channel (5 B/px)", 7)
     RUN8A("abl v8 no bbox reduction (fixed halo 8)", 5)
 #define RUN11(name, NT, TWQ, ITERS, LDSB, G) if (strstr(name, only)) { grid_for(TWQ * 4, NT / TWQ); unsigned g = G; \
         P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
@@ -2596,6 +3758,65 @@ int main(int argc, char** argv) {
     RUN11("v11 256t 32x32 48K g768", 256, 8, 4, 49152, 768)
     RUN11("v11 64t 16x16 13K g3072", 64, 4, 4, 13312, 3072)
     RUN11("v11 64t 16x16 13K g2048", 64, 4, 4, 13312, 2048)
+#define RUN8N(name, NT, TWQ, ITERS, LDSB, NTM) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, NT / TWQ); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v8n<NT, TWQ, ITERS, NTM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v8n<NT, TWQ, ITERS, NTM>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v8n<NT, TWQ, ITERS, NTM>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN8N("v8n 128t 32x16 26K plain", 128, 8, 4, 26624, 0)
+    RUN8N("v8n 128t 32x16 26K nt-stores", 128, 8, 4, 26624, 1)
+    RUN8N("v8n 128t 32x16 26K nt-flow-loads", 128, 8, 4, 26624, 2)
+    RUN8N("v8n 128t 32x16 26K nt-both", 128, 8, 4, 26624, 3)
+    RUN8N("v8n 256t 32x32 48K nt-both", 256, 8, 4, 49152, 3)
+#define RUN12(name, NT, TWQ, ITERS, LDSB, G) if (strstr(name, only)) { grid_for(TWQ * 4, NT / TWQ); unsigned g = G; \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v12<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v12<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v12<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN12("v12 128t 32x16 26K it3 g1536", 128, 8, 3, 26624, 1536)
+    RUN12("v12 128t 32x16 26K it4 g1536", 128, 8, 4, 26624, 1536)
+    RUN12("v12 128t 32x16 32K it3 g1280", 128, 8, 3, 32768, 1280)
+    RUN12("v12 256t 32x32 48K it4 g768", 256, 8, 4, 49152, 768)
+    RUN12("v12 64t 16x16 13K it4 g3072", 64, 4, 4, 13312, 3072)
+#define RUN13(name, NT, TWQ, ITERS, LDSB, G) if (strstr(name, only)) { grid_for(TWQ * 4, NT / TWQ); unsigned g = G; \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v13<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v13<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v13<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN13("v13 128t 32x16 26K g1536", 128, 8, 4, 26624, 1536)
+    RUN13("v13 128t 32x16 26K g3072", 128, 8, 4, 26624, 3072)
+    RUN13("v13 256t 32x32 48K g768", 256, 8, 4, 49152, 768)
+    RUN13("v13 64t 16x16 13K g3072", 64, 4, 4, 13312, 3072)
+#define RUN14(name, NT, TWQ, ITERS, LDSB) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, NT / TWQ); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v14<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v14<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v14<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN14("v14 128t 32x16 26K", 128, 8, 4, 26624)
+    RUN14("v14 256t 32x32 48K", 256, 8, 4, 49152)
+    RUN14("v14 64t 16x16 13K", 64, 4, 4, 13312)
+    RUN14("v14 128t 16x32 26K", 128, 4, 4, 26624)
+#define RUN15(name, NT, TWQ, ITERS, LDSB) if (strstr(name, only)) { unsigned g = grid_for(TWQ * 4, 2 * (NT / TWQ)); \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v15<NT, TWQ, ITERS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); \
+        hipLaunchKernelGGL((warp_v15<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v15<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
+    RUN15("v15 128t 2x(32x16) 26K", 128, 8, 4, 26624)
+    RUN15("v15 128t 2x(32x16) 26K it3", 128, 8, 3, 26624)
+    RUN15("v15 256t 2x(32x32) 48K", 256, 8, 4, 49152)
+    RUN15("v15 64t 2x(16x16) 13K", 64, 4, 4, 13312)
+    if (strstr("stamps8", only)) {
+        unsigned g = grid_for(32, 16); P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1;
+        unsigned long long* dst_; CK(hipMalloc(&dst_, 64 * 16 * 8)); CK(hipMemset(dst_, 0, 64 * 16 * 8));
+        CK(hipFuncSetAttribute((const void*)warp_v8t<128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 26624));
+        hipLaunchKernelGGL((warp_v8t<128, 8, 4>), dim3(g), dim3(128), 26624, 0, pp, 26624, dst_); CK(hipDeviceSynchronize());
+        unsigned long long hst[64 * 16]; CK(hipMemcpy(hst, dst_, sizeof(hst), hipMemcpyDeviceToHost));
+        double tot[16] = {0}; for (int i = 0; i < 64; ++i) for (int j = 0; j < 16; ++j) tot[j] += hst[i * 16 + j];
+        const char* nm[9] = {"tiles", "flow-load wait", "coords (VALU)", "bbox shuffles+barrier", "staging addr+issue", "staging wait", "lds write+barrier", "gather+blend", "stores drain"};
+        printf("v8 phase stamps (cycles), 128t 32x16 26K, per tile (tid 0 of each block):\n"); double sum = 0;
+        for (int j = 1; j < 9; ++j) { printf("   %-24s %9.1f\n", nm[j], tot[j] / tot[0]); sum += tot[j] / tot[0]; }
+        printf("   %-24s %9.1f\n", "total", sum);
+    }
     if (strstr("stamps", only)) {
         unsigned g = grid_for(32, 32); P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1;
         unsigned long long* dst_; CK(hipMalloc(&dst_, 64 * 8 * 8)); CK(hipMemset(dst_, 0, 64 * 8 * 8));
