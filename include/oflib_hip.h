@@ -46,6 +46,7 @@ extern "C" {
 #define OFL_E_NULL -1      /* a required pointer is NULL */
 #define OFL_E_SHAPE -2     /* n, c, h or w out of range (all must be >= 1; h*w < 2^24, utils.py:1118) */
 #define OFL_E_ARG -3       /* inconsistent optional arguments */
+#define OFL_E_UNSUPPORTED -4 /* this entry point cannot take the launch (alignment / channel count): use the general one */
 
 /* library / build identification: returns e.g. 11 for 0.1.1 */
 int ofl_version(void);
@@ -141,6 +142,29 @@ int ofl_splat_finalize_f32(const float* accum,
                            float* dst, float* density, uint8_t* warped, uint8_t* valid, float* mask_chan,
                            int32_t n, int32_t c, int32_t h, int32_t w,
                            int32_t round_mode, void* stream);
+
+/*
+ * Forward splat, single fused call (the fast path of the two passes above, same arguments and arithmetic):
+ * destination-tile-owned accumulation in LDS, normalise / masks / un-occlude fill in the same kernel -- no global
+ * atomics and no accumulator round trip through HBM.  Needs C <= 3, W % 4 == 0 and 16-byte aligned planes, else it
+ * returns OFL_E_UNSUPPORTED and the caller uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
+ *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  candidate lists (contents irrelevant on entry)
+ *   accum_fallback fp32[N * (1 + C + with_mask_chan) * H * W]      used (and zeroed in-stream) only when the flow is so
+ *                  rough that a destination tile has more than 16 candidate source tiles; the atomics path then
+ *                  runs inside the same call, decided on the device (no host sync).
+ */
+int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w);
+int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                        const float* xs, const float* ys, int64_t xy_bs,
+                        const float* data, int64_t data_bs, float data_sign,
+                        const uint8_t* weight_mask, int64_t weight_mask_bs,
+                        const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
+                        const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+                        int32_t with_mask_chan, int32_t occlude,
+                        float* dst, float* density, uint8_t* warped, uint8_t* valid, float* mask_chan,
+                        int32_t* workspace, int64_t workspace_ints, float* accum_fallback,
+                        int32_t n, int32_t c, int32_t h, int32_t w,
+                        int32_t round_mode, void* stream);
 
 /*
  * Per-batch-element flag word of a flow field (OR-ed into flags[n]; caller zeroes):

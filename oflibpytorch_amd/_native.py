@@ -18,7 +18,8 @@ FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2,
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
-_SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_flow_flags_f32")
+_SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints",
+            "ofl_splat_tiled_f32", "ofl_flow_flags_f32")
 _lib = None
 
 
@@ -51,10 +52,23 @@ def load_library(path: str = None):
     lib.ofl_splat_finalize_f32.argtypes = [p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                            i32, i32, i32, i32, i32, p]
     lib.ofl_flow_flags_f32.argtypes = [p, i64, p, i64, f32, p, i32, i32, i32, p]
+    lib.ofl_splat_tiled_workspace_ints.argtypes = [i32, i32, i32]
+    lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
+                                        p, i64, p, i32, i32, i32, i32, i32, p]
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
+    lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
     _lib = lib
     return lib
+
+
+_splat_path = 0
+
+
+def set_splat_path(mode: int):
+    """0 = auto (fused tiled kernel when eligible), 1 = general two-pass atomics path only (tests compare the two)."""
+    global _splat_path
+    _splat_path = int(mode)
 
 
 def set_warp_path(mode: int):
@@ -172,18 +186,30 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     cb, cbbs = (None, 0) if chan_mask_b is None else _planes(chan_mask_b, dev, torch.bool, n, "mask")
     mch = 1 if (want_valid or want_mask_chan) else 0
     occ = 1 if (occlude and f is not None) else 0
-    accum = torch.zeros((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
     st = _stream(dev)
-    _check(lib.ofl_splat_fwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
-                                 float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
-                                 _ptr(accum), n, c, h, w, st), "ofl_splat_fwd_f32")
     dst = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
     valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if (want_valid and not want_mask_chan) else None
     mchan = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_mask_chan else None
     density = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_density else None
     warped = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_warped else None
-    _check(lib.ofl_splat_finalize_f32(_ptr(accum), _ptr(f), fbs, _ptr(d), dbs, float(data_sign), _ptr(wm), wmbs,
-                                      _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ, _ptr(dst), _ptr(density),
-                                      _ptr(warped), _ptr(valid), _ptr(mchan), n, c, h, w, int(round_mode), st),
-           "ofl_splat_finalize_f32")
+    rc = -4
+    if _splat_path != 1 and c <= 3 and w % 4 == 0 and w >= 4:
+        # fused tiled path: LDS accumulation per destination tile; `accum` is only touched if the flow is too rough
+        ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
+        accum = torch.empty((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        rc = lib.ofl_splat_tiled_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
+                                     float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
+                                     _ptr(dst), _ptr(density), _ptr(warped), _ptr(valid), _ptr(mchan), _ptr(ws),
+                                     ws.numel(), _ptr(accum), n, c, h, w, int(round_mode), st)
+        if rc not in (0, -4):
+            _check(rc, "ofl_splat_tiled_f32")
+    if rc == -4:   # not eligible (alignment / channels): the general two-pass path
+        accum = torch.zeros((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        _check(lib.ofl_splat_fwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
+                                     float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
+                                     _ptr(accum), n, c, h, w, st), "ofl_splat_fwd_f32")
+        _check(lib.ofl_splat_finalize_f32(_ptr(accum), _ptr(f), fbs, _ptr(d), dbs, float(data_sign), _ptr(wm), wmbs,
+                                          _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ, _ptr(dst), _ptr(density),
+                                          _ptr(warped), _ptr(valid), _ptr(mchan), n, c, h, w, int(round_mode), st),
+               "ofl_splat_finalize_f32")
     return dst, (mchan if want_mask_chan else valid), density, warped

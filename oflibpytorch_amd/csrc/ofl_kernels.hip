@@ -580,10 +580,12 @@ struct SplatParams {
     int32_t round_mode;
     int32_t tiles_x, tiles_y;
     int64_t total_tiles, per_xcd;
+    const int32_t* run_if_set;   // optional device flag: the atomics path runs only when *run_if_set != 0
 };
 
 template <int CT>
 __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
+    if (p.run_if_set && *p.run_if_set == 0) return;
     const int64_t tile = logical_block(p.per_xcd);
     if (tile >= p.total_tiles) return;
     const int tx = (int)(tile % p.tiles_x);
@@ -664,6 +666,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
 // ------------------------------------------------------------------------------------------------
 template <int CT>
 __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p) {
+    if (p.run_if_set && *p.run_if_set == 0) return;
     const int64_t tile = logical_block(p.per_xcd);
     if (tile >= p.total_tiles) return;
     const int tx = (int)(tile % p.tiles_x);
@@ -717,6 +720,277 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
             if (p.mask_chan) p.mask_chan[(int64_t)n * hw + pix] = mch;
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// forward splat, tiled fast path (ofl_splat_tiled_f32): destination-tile-owned LDS accumulation, fused finalize
+//
+//  bin kernel : one block per 32 x 16 SOURCE tile: end points of its pixels -> bounding box of the destination pixels
+//               it touches -> appends itself to the candidate list of every destination tile under that box
+//               (fixed capacity; an overflow flags the launch for the atomics path).
+//  tile kernel: one block per 32 x 16 DESTINATION tile: zeroes (2 + C) accumulator planes in LDS (10 KB), walks its
+//               candidate source tiles (16-byte loads), adds the corner contributions that fall inside with LDS
+//               float atomics (accumulator de-interleaved by 4 along x -> bank-conflict free), then normalises,
+//               thresholds, un-occludes and stores with 16-byte stores.  No global atomics, no accumulator in HBM.
+// Same arithmetic as the two-pass path (weights, clamps, zero-flow rule, invalid-weight mask channel).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSpNT = 128, kSpTW = 32, kSpTH = 16, kSpMaxCand = 16;
+
+__device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-zero -> 0x01
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r |= (uint32_t)(((x >> (8 * k)) & 0xffu) != 0u) << (8 * k);
+    return r;
+}
+
+struct TiledParams {
+    SplatParams s;
+    int32_t* counts;       // [n * tiles]
+    int32_t* lists;        // [n * tiles * kSpMaxCand]
+    int32_t* overflow;     // [1]
+    int32_t tiles_x, tiles_y;
+    uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;
+    int64_t total, per_xcd;
+};
+
+__device__ __forceinline__ bool sp_decode(const TiledParams& p, int& tx, int& ty, int& n) {
+    const uint32_t b = blockIdx.x;
+    const uint32_t tile = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
+    if (tile >= (uint32_t)p.total) return false;
+    const uint32_t nn = fastdiv(tile, p.mi_m, p.mi_s);
+    const uint32_t rem = tile - nn * p.tiles_img;
+    const uint32_t yy = fastdiv(rem, p.mx_m, p.mx_s);
+    n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (uint32_t)p.tiles_x);
+    return true;
+}
+
+// end point + contribution test of the 4 source pixels of this thread (shared by both kernels)
+struct SpSrc { float x[4], y[4]; bool on[4]; bool zero[4]; bool wm[4]; };
+
+__device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4, int sy, bool inimg, uint32_t pix, uint32_t hw, SpSrc& q) {
+    f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    uint32_t wm4 = 0x01010101u;
+    if (inimg) {
+        if (s.flow) {
+            a = *reinterpret_cast<const f4*>(s.flow + n * s.flow_bs + pix);
+            b = *reinterpret_cast<const f4*>(s.flow + n * s.flow_bs + hw + pix);
+        } else {
+            a = *reinterpret_cast<const f4*>(s.xs + n * s.xy_bs + pix);
+            b = *reinterpret_cast<const f4*>(s.ys + n * s.xy_bs + pix);
+        }
+        if (s.weight_mask) wm4 = *reinterpret_cast<const uint32_t*>(s.weight_mask + n * s.weight_mask_bs + pix);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        q.zero[k] = false;
+        if (s.flow) {
+            q.x[k] = s.flow_sign * a[k] + (float)(sx4 + k);      // get_flow_endpoints utils.py:1056-1057
+            q.y[k] = s.flow_sign * b[k] + (float)sy;
+            if (s.occlude) q.zero[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr);
+        } else {
+            q.x[k] = a[k]; q.y[k] = b[k];
+        }
+        q.wm[k] = ((wm4 >> (8 * k)) & 0xffu) != 0u;
+        q.on[k] = inimg && q.wm[k] && !q.zero[k];
+    }
+}
+
+__global__ __launch_bounds__(kSpNT) void splat_bin_kernel(const TiledParams p) {
+    __shared__ int red[kSpNT / 64][4];
+    int tx, ty, n;
+    if (!sp_decode(p, tx, ty, n)) return;
+    const SplatParams& s = p.s;
+    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const int sx4 = tx * kSpTW + lx * 4, sy = ty * kSpTH + ly;
+    const bool inimg = (sx4 < w) && (sy < h);
+    SpSrc q;
+    sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
+    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (q.on[k]) {
+            // destination columns floor(x), floor(x)+1 (clamped corners carry weight 0: the box is clipped below)
+            const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf), y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf);
+            minx = min(minx, x0); maxx = max(maxx, x0 + 1); miny = min(miny, y0); maxy = max(maxy, y0 + 1);
+        }
+    }
+    // a masked-in zero-flow pixel may have to be copied through (un-occlude fill): its tile must meet itself
+    bool selfneed = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) selfneed |= inimg && q.zero[k] && q.wm[k];
+    const int selfwave = __any(selfneed) ? 1 : 0;
+    minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
+    __shared__ int selfred[kSpNT / 64];
+    if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; selfred[tid >> 6] = selfwave; }
+    __syncthreads();
+    if (tid != 0) return;
+    int self = 0;
+    for (int i = 0; i < kSpNT / 64; ++i) {
+        minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
+        self |= selfred[i];
+    }
+    minx = max(minx, 0); maxx = min(maxx, w - 1); miny = max(miny, 0); maxy = min(maxy, h - 1);
+    const int me = ty * p.tiles_x + tx;
+    const bool lands = !(maxx < minx || maxy < miny);
+    const int tx0 = lands ? minx / kSpTW : 1, tx1 = lands ? maxx / kSpTW : 0, ty0 = lands ? miny / kSpTH : 1, ty1 = lands ? maxy / kSpTH : 0;
+    if (lands && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) { atomicOr(p.overflow, 1); return; }
+    for (int dy = ty0; dy <= ty1; ++dy)
+        for (int dx = tx0; dx <= tx1; ++dx) {
+            const int64_t d = (int64_t)n * p.tiles_img + dy * p.tiles_x + dx;
+            const int slot = atomicAdd(&p.counts[d], 1);
+            if (slot < kSpMaxCand) p.lists[d * kSpMaxCand + slot] = me;
+            else atomicOr(p.overflow, 1);
+        }
+    if (self && !(lands && tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1)) {
+        const int64_t d = (int64_t)n * p.tiles_img + me;
+        const int slot = atomicAdd(&p.counts[d], 1);
+        if (slot < kSpMaxCand) p.lists[d * kSpMaxCand + slot] = me;
+        else atomicOr(p.overflow, 1);
+    }
+}
+
+template <int NC, bool MCH>
+__global__ __launch_bounds__(kSpNT) void splat_tile_kernel(const TiledParams p) {
+    constexpr int NPL = 1 + NC + (MCH ? 1 : 0);                 // density, data, invalid weight
+    __shared__ float acc[NPL][kSpTW * kSpTH];
+    if (*p.overflow != 0) return;                               // this launch takes the atomics path instead
+    int tx, ty, n;
+    if (!sp_decode(p, tx, ty, n)) return;
+    const SplatParams& s = p.s;
+    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
+    const float* __restrict__ db = s.data + n * s.data_bs;
+    const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
+    const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[pl][tid + i * kSpNT] = 0.0f;
+    const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
+    const int ncand = min(p.counts[dtile], kSpMaxCand);
+    const int me = ty * p.tiles_x + tx;
+    // own-pixel state for the un-occlude fill (captured when this tile meets itself as a source tile)
+    bool fill_ok[4] = {false, false, false, false};
+    f4 own[NC];
+    uint32_t own_cm = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) own[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    for (int ci = 0; ci < ncand; ++ci) {
+        const int st = p.lists[dtile * kSpMaxCand + ci];
+        const uint32_t sty = fastdiv((uint32_t)st, p.mx_m, p.mx_s), stx = (uint32_t)st - sty * (uint32_t)p.tiles_x;
+        const int sx4 = (int)stx * kSpTW + lx * 4, sy = (int)sty * kSpTH + ly;
+        const bool inimg = (sx4 < w) && (sy < h);
+        const uint32_t pix = (uint32_t)(sy * w + sx4);
+        SpSrc q;
+        sp_load_src(s, n, sx4, sy, inimg, pix, hw, q);
+        // corner geometry of the 4 pixels; which of them put anything inside this destination tile?
+        int ix[4][2], iy[4][2];
+        float wx[4][2], wy[4][2];
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xv = q.x[k], yv = q.y[k];
+            const float x0 = floorf(xv), y0 = floorf(yv), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+            const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
+            const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
+            wx[k][0] = (x1 - xv) * (x0 == x0s ? 1.0f : 0.0f);      // utils.py:1110
+            wx[k][1] = (xv - x0) * (x1 == x1s ? 1.0f : 0.0f);
+            wy[k][0] = (y1 - yv) * (y0 == y0s ? 1.0f : 0.0f);      // utils.py:1111
+            wy[k][1] = (yv - y0) * (y1 == y1s ? 1.0f : 0.0f);
+            ix[k][0] = (int)x0s - dx0; ix[k][1] = (int)x1s - dx0; iy[k][0] = (int)y0s - dy0; iy[k][1] = (int)y1s - dy0;
+            const bool inx = ((uint32_t)ix[k][0] < (uint32_t)kSpTW) || ((uint32_t)ix[k][1] < (uint32_t)kSpTW);
+            const bool iny = ((uint32_t)iy[k][0] < (uint32_t)kSpTH) || ((uint32_t)iy[k][1] < (uint32_t)kSpTH);
+            q.on[k] = q.on[k] && inx && iny;
+            hit |= q.on[k];
+        }
+        const bool self = (st == me);
+        f4 dv[NC];
+        uint32_t cm4 = 0x01010101u;
+        if (hit || (self && inimg)) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dv[c] = *reinterpret_cast<const f4*>(db + c * hw + pix);
+            if (MCH) {
+                if (cma) cm4 = nz_bytes(*reinterpret_cast<const uint32_t*>(cma + pix));
+                if (cmb) cm4 &= nz_bytes(*reinterpret_cast<const uint32_t*>(cmb + pix));
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dv[c] = (f4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (self && inimg) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fill_ok[k] = q.zero[k] && q.wm[k];       // mask & zero_mask (utils.py:1202)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) own[c] = dv[c];
+            own_cm = cm4;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!q.on[k]) continue;
+            const bool invalid = MCH && (((cm4 >> (8 * k)) & 0xffu) == 0u);
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx) {
+                    const float wgt = wy[k][ky] * wx[k][kx];               // utils.py:1114
+                    const int xl = ix[k][kx], yl = iy[k][ky];
+                    if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
+                    const int idx = yl * kSpTW + (xl & 3) * (kSpTW / 4) + (xl >> 2);
+                    atomicAdd(&acc[0][idx], wgt);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) atomicAdd(&acc[1 + c][idx], wgt * (s.data_sign * dv[c][k]));
+                    if (MCH && invalid) atomicAdd(&acc[1 + NC][idx], wgt);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- finalize this destination tile: thread -> 4 consecutive destination pixels (same mapping as above)
+    const int x4 = dx0 + lx * 4, y = dy0 + ly;
+    if (x4 >= w || y >= h) return;
+    const uint32_t pix = (uint32_t)(y * w + x4);
+    f4 den4, out[NC], mch4;
+    uint32_t warped4 = 0, valid4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = ly * kSpTW + k * (kSpTW / 4) + lx;
+        const float den = acc[0][idx];
+        const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
+        const bool warped = den > 0.0f;                            // utils.py:1197
+        const bool fill = s.occlude && fill_ok[k] && !warped;      // utils.py:1198-1203
+        den4[k] = den;
+        warped4 |= (uint32_t)warped << (8 * k);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            out[c][k] = apply_round(fill ? s.data_sign * own[c][k] : acc[1 + c][idx] / dcl, s.round_mode);
+        if (MCH) {
+            const float m = fill ? ((((own_cm >> (8 * k)) & 0xffu) != 0u) ? 1.0f : 0.0f) : (den - acc[1 + NC][idx]) / dcl;
+            mch4[k] = m;
+            valid4 |= (uint32_t)(m > kValidThr) << (8 * k);
+        }
+    }
+    float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *reinterpret_cast<f4*>(dst + c * hw + pix) = out[c];
+    if (s.density) *reinterpret_cast<f4*>(s.density + (int64_t)n * hw + pix) = den4;
+    if (s.warped) *reinterpret_cast<uint32_t*>(s.warped + (int64_t)n * hw + pix) = warped4;
+    if (MCH && s.valid) *reinterpret_cast<uint32_t*>(s.valid + (int64_t)n * hw + pix) = valid4;
+    if (MCH && s.mask_chan) *reinterpret_cast<f4*>(s.mask_chan + (int64_t)n * hw + pix) = mch4;
+}
+
+// zero the fallback accumulator only when the atomics path will run
+__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t n4, const int32_t* __restrict__ flag) {
+    if (*flag == 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<f4*>(ptr)[i] = (f4){0.f, 0.f, 0.f, 0.f};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -802,6 +1076,14 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
     OFL_LAUNCH_W(false, true, true) OFL_LAUNCH_W(true, true, true)
 #undef OFL_LAUNCH_W
     return OFL_E_ARG;
+}
+
+
+template <int NC>
+int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
+    if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true>), dim3(grid), dim3(kSpNT), 0, st, tp);
+    else hipLaunchKernelGGL((splat_tile_kernel<NC, false>), dim3(grid), dim3(kSpNT), 0, st, tp);
+    return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -945,6 +1227,88 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
         case 3: hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
         case 4: hipLaunchKernelGGL(splat_finalize_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
         default: hipLaunchKernelGGL(splat_finalize_kernel<0>, dim3(grid), dim3(256), 0, st, p); break;
+    }
+    return (int)hipGetLastError();
+}
+
+
+__attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w) {
+    const int64_t tiles = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH) * n;
+    return tiles * (1 + kSpMaxCand) + 4;
+}
+
+__attribute__((visibility("default"))) int ofl_splat_tiled_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, const float* xs, const float* ys, int64_t xy_bs,
+    const float* data, int64_t data_bs, float data_sign, const uint8_t* weight_mask, int64_t weight_mask_bs,
+    const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+    int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
+    float* mask_chan, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n, int32_t c,
+    int32_t h, int32_t w, int32_t round_mode, void* stream) {
+    if (!data || !dst || !workspace || !accum_fallback) return OFL_E_NULL;
+    if (!flow && !(xs && ys)) return OFL_E_NULL;
+    if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
+    if ((valid || mask_chan) && !with_mask_chan) return OFL_E_ARG;
+    if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
+    TiledParams tp = {};
+    unsigned grid_unused;
+    int rc = fill_splat(tp.s, flow, flow_bs, data, data_bs, data_sign, weight_mask, weight_mask_bs, chan_mask_a,
+                        chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, n, c, h, w, grid_unused);
+    if (rc) return rc;
+    // eligibility of the tiled path: <= 3 channels, rows of whole 16-byte groups, aligned planes
+    const bool ok = c <= 3 && w >= 4 && (w % 4) == 0 && aligned_to(data, 16) && aligned_to(dst, 16) && (data_bs % 4) == 0 &&
+                    (!flow || (aligned_to(flow, 16) && (flow_bs % 4) == 0)) &&
+                    (!xs || (aligned_to(xs, 16) && aligned_to(ys, 16) && (xy_bs % 4) == 0)) &&
+                    (!weight_mask || (aligned_to(weight_mask, 4) && (weight_mask_bs % 4) == 0)) &&
+                    (!chan_mask_a || (aligned_to(chan_mask_a, 4) && (chan_mask_a_bs % 4) == 0)) &&
+                    (!chan_mask_b || (aligned_to(chan_mask_b, 4) && (chan_mask_b_bs % 4) == 0)) &&
+                    (!density || aligned_to(density, 16)) && (!mask_chan || aligned_to(mask_chan, 16)) &&
+                    (!warped || aligned_to(warped, 4)) && (!valid || aligned_to(valid, 4));
+    if (!ok) return OFL_E_UNSUPPORTED;
+    if (workspace_ints < ofl_splat_tiled_workspace_ints(n, h, w)) return OFL_E_ARG;
+    tp.s.flow_sign = flow_sign; tp.s.xs = xs; tp.s.ys = ys; tp.s.xy_bs = xy_bs;
+    tp.s.dst = dst; tp.s.density = density; tp.s.warped = warped; tp.s.valid = valid; tp.s.mask_chan = mask_chan;
+    tp.s.round_mode = round_mode;
+    tp.tiles_x = (w + kSpTW - 1) / kSpTW; tp.tiles_y = (h + kSpTH - 1) / kSpTH;
+    tp.tiles_img = (uint32_t)(tp.tiles_x * tp.tiles_y);
+    tp.total = (int64_t)tp.tiles_img * n;
+    if (tp.total >= (1ll << 31)) return OFL_E_SHAPE;
+    tp.per_xcd = (tp.total + kXcds - 1) / kXcds;
+    magic_u32((uint32_t)tp.tiles_x, tp.mx_m, tp.mx_s);
+    magic_u32(tp.tiles_img, tp.mi_m, tp.mi_s);
+    tp.counts = workspace;
+    tp.lists = workspace + tp.total;
+    tp.overflow = workspace + tp.total * (1 + kSpMaxCand);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(tp.counts, 0, (size_t)tp.total * sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(tp.overflow, 0, 4 * sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    const unsigned grid = (unsigned)(tp.per_xcd * kXcds);
+    hipLaunchKernelGGL(splat_bin_kernel, dim3(grid), dim3(kSpNT), 0, st, tp);
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    switch (c) {
+        case 1: rc = launch_splat_tile<1>(tp, grid, st); break;
+        case 2: rc = launch_splat_tile<2>(tp, grid, st); break;
+        default: rc = launch_splat_tile<3>(tp, grid, st); break;
+    }
+    if (rc) return rc;
+    // atomics path, armed only if a candidate list overflowed (rough flows); every kernel below exits at once otherwise
+    SplatParams fb = tp.s;
+    fb.accum = accum_fallback;
+    fb.run_if_set = tp.overflow;
+    const int planes = 1 + c + (with_mask_chan ? 1 : 0);
+    const int64_t n4 = (int64_t)n * planes * h * w / 4;
+    hipLaunchKernelGGL(zero_if_set_kernel, dim3(2048), dim3(256), 0, st, accum_fallback, n4, tp.overflow);
+    unsigned g2;
+    tile_grid(n, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
+    switch (c) {
+        case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
+                hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
+        case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
+                hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
+        default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
+                 hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
     }
     return (int)hipGetLastError();
 }

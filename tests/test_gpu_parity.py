@@ -166,3 +166,79 @@ def test_exact_division_corner_cases(dev):
         ref = oracle.G(flow.numpy(), np.concatenate([src.numpy(), np.ones((1, 1, h, w), np.float32)], 1))
         assert np.array_equal(out.cpu().numpy(), ref[:, :3], equal_nan=True)
         assert np.array_equal(valid.cpu().numpy(), oracle.theta(ref[:, 3]))
+
+
+# ------------------------------------------------------------------------------------------------
+# forward splat: the fused tiled kernel vs the two-pass atomics path vs the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (3, 3, 130, 260)])
+@pytest.mark.parametrize("sigma", [0.0, 3.0, 60.0])
+def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev):
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    n, c, h, w = shape
+    flow = _smooth(n, h, w, max(sigma, 1.0), 21, dev)
+    if sigma == 0.0:
+        flow = flow * 0 + 2e-4                      # everything below the zero-flow threshold: pure un-occlude fill
+    flow[0, :, h // 4: h // 2, w // 4: w // 2] = 0   # zero-flow block (occlusion rule)
+    if sigma > 10:
+        flow[-1] *= 6                               # rough: candidate lists overflow -> in-call atomics fallback
+    g = torch.Generator().manual_seed(9)
+    data = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    wm = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    ca = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    for kw in (dict(weight_mask=wm, chan_mask_a=ca, chan_mask_b=wm, want_valid=True, want_density=True, want_warped=True),
+               dict(want_warped=True), dict(weight_mask=wm, occlude=False, want_density=True),
+               dict(flow_sign=-1.0, data_sign=-1.0, chan_mask_a=ca, weight_mask=wm, want_mask_chan=True)):
+        outs = []
+        for path in (0, 1):
+            _native.set_splat_path(path)
+            try:
+                outs.append(_native.splat_fwd(flow, data, **kw))
+            finally:
+                _native.set_splat_path(0)
+        scale = 120.0
+        for a, b in zip(*outs):
+            assert (a is None) == (b is None)
+            if a is None:
+                continue
+            if a.dtype == torch.bool:
+                assert torch.equal(a, b), "masks differ between tiled and two-pass splat for %s" % (kw,)
+            else:
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=3e-5, atol=3e-5 * scale)
+        # oracle
+        f = flow.cpu().numpy() * np.float32(kw.get("flow_sign", 1.0))
+        d = data.cpu().numpy() * np.float32(kw.get("data_sign", 1.0))
+        mc = np.ones((n, h, w), bool)
+        for key in ("chan_mask_a", "chan_mask_b"):
+            if key in kw:
+                mc &= kw[key].cpu().numpy()
+        dd = np.concatenate([d, mc[:, None].astype(np.float32)], 1)
+        m = kw["weight_mask"].cpu().numpy() if "weight_mask" in kw else None
+        ref, rwarped, rden = oracle.apply_s_flow(f, dd, m, kw.get("occlude", True), return_density=True)
+        np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref[:, :c], rtol=3e-5, atol=3e-5 * scale)
+        if kw.get("want_valid"):
+            assert np.array_equal(outs[0][1].cpu().numpy(), oracle.theta(ref[:, c]))
+        if kw.get("want_mask_chan"):
+            np.testing.assert_allclose(outs[0][1].cpu().numpy(), ref[:, c], rtol=3e-5, atol=3e-5)
+            assert np.array_equal(outs[0][1].cpu().numpy() == 1, ref[:, c] == 1)
+        if kw.get("want_density"):
+            np.testing.assert_allclose(outs[0][2].cpu().numpy(), rden, rtol=3e-5, atol=1e-5)
+        if kw.get("want_warped"):
+            assert np.array_equal(outs[0][3].cpu().numpy(), rwarped)
+
+
+def test_tiled_splat_explicit_positions(dev):
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    g = torch.Generator().manual_seed(4)
+    n, c, h, w = 2, 3, 40, 64
+    x = torch.rand(n, h, w, generator=g) * (w + 6) - 3
+    y = torch.rand(n, h, w, generator=g) * (h + 6) - 3
+    data = torch.rand(n, c, h, w, generator=g) * 50
+    m = torch.rand(n, h, w, generator=g) > 0.2
+    out, _, den, _ = _native.splat_fwd(None, data.to(dev), xs=x.to(dev), ys=y.to(dev), weight_mask=m.to(dev),
+                                       occlude=False, want_density=True)
+    ref, rden = oracle.grid_from_unstructured_data(x.numpy(), y.numpy(), data.numpy(), m.numpy())
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=3e-5, atol=3e-3)
+    np.testing.assert_allclose(den.cpu().numpy(), rden, rtol=3e-5, atol=1e-5)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Secondary timings of the other hot-path operations (not the headline metric): ms and Mpix/s per op on one GPU.
+
+    python tools/bench_ops.py [--batch 16] [--iters 10]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+import oflibpytorch_amd as ofl  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    a = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    n, h, w = a.batch, a.height, a.width
+    f1, f2, img, m1, m2, tm = bench.make_inputs(n, h, w, dev, 0)
+    px = n * h * w
+    rows = []
+    for ref in 'ts':
+        A, B = ofl.Flow(f1, ref, m1), ofl.Flow(f2, ref, m2)
+        rows.append(("apply '%s' C=3 +valid" % ref, 35, timeit(lambda: A.apply(img, target_mask=tm, return_valid_area=True), a.iters)))
+        rows.append(("switch_ref %s" % ref, 18, timeit(lambda: A.switch_ref(), a.iters)))
+        for mode in (3, 2, 1):
+            rows.append(("combine_with mode %d '%s'" % (mode, ref), 27, timeit(lambda: A.combine_with(B, mode), a.iters)))
+    print("B=%d %dx%d fp32, %d iters" % (n, h, w, a.iters))
+    for name, bpp, t in rows:
+        print("%-28s %8.3f ms  %9.1f Mpix/s  %7.1f GB/s algorithmic (%d B/px)" % (name, t * 1e3, px / t / 1e6, bpp * px / t / 1e9, bpp))
+
+
+if __name__ == "__main__":
+    main()
