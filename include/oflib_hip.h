@@ -56,6 +56,9 @@ int ofl_version(void);
  *                          planes; generic direct-gather kernel otherwise -- both restate the same arithmetic),
  *                      1 = generic direct-gather kernel only. */
 #define OFL_OPT_WARP_PATH 1
+/*   OFL_OPT_SPLAT_BINNING: 0 = tiled splat accumulates with LDS float atomics (default), 1 = atomic-free binning variant
+ *                          (integer LDS atomics + register sums; tiles it cannot take fall back to the float atomics). */
+#define OFL_OPT_SPLAT_BINNING 2
 int ofl_set_option(int32_t key, int32_t value);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,

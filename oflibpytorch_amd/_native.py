@@ -71,6 +71,11 @@ def set_splat_path(mode: int):
     _splat_path = int(mode)
 
 
+def set_splat_binning(on: bool):
+    """Tiled splat: False = LDS float atomics (default), True = atomic-free binning variant."""
+    _check(load_library().ofl_set_option(2, 1 if on else 0), "ofl_set_option")
+
+
 def set_warp_path(mode: int):
     """0 = auto (LDS-staged kernel when eligible), 1 = generic direct-gather kernel only (tests compare the two)."""
     _check(load_library().ofl_set_option(1, int(mode)), "ofl_set_option")

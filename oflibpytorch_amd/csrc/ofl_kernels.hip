@@ -752,6 +752,7 @@ struct TiledParams {
     int32_t tiles_x, tiles_y;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;
     int64_t total, per_xcd;
+    int32_t binning;       // 1: atomic-free binning first (tiles that overflow it fall back to LDS float atomics)
 };
 
 __device__ __forceinline__ bool sp_decode(const TiledParams& p, int& tx, int& ty, int& n) {
@@ -818,26 +819,18 @@ __global__ __launch_bounds__(kSpNT) void splat_bin_kernel(const TiledParams p) {
             minx = min(minx, x0); maxx = max(maxx, x0 + 1); miny = min(miny, y0); maxy = max(maxy, y0 + 1);
         }
     }
-    // a masked-in zero-flow pixel may have to be copied through (un-occlude fill): its tile must meet itself
-    bool selfneed = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) selfneed |= inimg && q.zero[k] && q.wm[k];
-    const int selfwave = __any(selfneed) ? 1 : 0;
     minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
-    __shared__ int selfred[kSpNT / 64];
-    if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; selfred[tid >> 6] = selfwave; }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
     __syncthreads();
     if (tid != 0) return;
-    int self = 0;
     for (int i = 0; i < kSpNT / 64; ++i) {
         minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
-        self |= selfred[i];
     }
     minx = max(minx, 0); maxx = min(maxx, w - 1); miny = max(miny, 0); maxy = min(maxy, h - 1);
+    if (maxx < minx || maxy < miny) return;       // nothing of this tile lands inside the image
+    const int tx0 = minx / kSpTW, tx1 = maxx / kSpTW, ty0 = miny / kSpTH, ty1 = maxy / kSpTH;
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) { atomicOr(p.overflow, 1); return; }
     const int me = ty * p.tiles_x + tx;
-    const bool lands = !(maxx < minx || maxy < miny);
-    const int tx0 = lands ? minx / kSpTW : 1, tx1 = lands ? maxx / kSpTW : 0, ty0 = lands ? miny / kSpTH : 1, ty1 = lands ? maxy / kSpTH : 0;
-    if (lands && (tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) { atomicOr(p.overflow, 1); return; }
     for (int dy = ty0; dy <= ty1; ++dy)
         for (int dx = tx0; dx <= tx1; ++dx) {
             const int64_t d = (int64_t)n * p.tiles_img + dy * p.tiles_x + dx;
@@ -845,136 +838,321 @@ __global__ __launch_bounds__(kSpNT) void splat_bin_kernel(const TiledParams p) {
             if (slot < kSpMaxCand) p.lists[d * kSpMaxCand + slot] = me;
             else atomicOr(p.overflow, 1);
         }
-    if (self && !(lands && tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1)) {
-        const int64_t d = (int64_t)n * p.tiles_img + me;
-        const int slot = atomicAdd(&p.counts[d], 1);
-        if (slot < kSpMaxCand) p.lists[d * kSpMaxCand + slot] = me;
-        else atomicOr(p.overflow, 1);
+}
+
+constexpr int kSpQueue = 1536;     // source pixels that touch the destination tile (compacted)
+constexpr int kSpBinCap = 12;      // contributions (source pixel, corner) one destination pixel can take on this path
+constexpr int kSpQueue2 = 2048;    // queue of the local atomics path (flushed when full)
+
+
+// accumulate queued source pixels with LDS float atomics (dense lanes) -- only for tiles the binning path cannot take
+template <int NC, bool MCH>
+__device__ __forceinline__ void sp_drain(const TiledParams& p, int n, int dx0, int dy0, const uint32_t* queue, int qlen, float* acc) {
+    constexpr int kPx = kSpTW * kSpTH;
+    const SplatParams& s = p.s;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    const float* __restrict__ db = s.data + n * s.data_bs;
+    for (int i = threadIdx.x; i < qlen; i += kSpNT) {
+        const uint32_t rec = queue[i];
+        const int sx = (int)(rec & 0xffffu), sy = (int)(rec >> 16);
+        const uint32_t pix = (uint32_t)(sy * w + sx);
+        float xv, yv;
+        if (s.flow) {
+            xv = s.flow_sign * s.flow[n * s.flow_bs + pix] + (float)sx;
+            yv = s.flow_sign * s.flow[n * s.flow_bs + hw + pix] + (float)sy;
+        } else {
+            xv = s.xs[n * s.xy_bs + pix]; yv = s.ys[n * s.xy_bs + pix];
+        }
+        float dv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dv[c] = s.data_sign * db[c * hw + pix];
+        bool invalid = false;
+        if (MCH) {
+            const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix] != 0 : true;
+            const bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix] != 0 : true;
+            invalid = !(a && b);
+        }
+        const float x0 = floorf(xv), y0 = floorf(yv), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+        const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
+        const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
+        const float wx[2] = {(x1 - xv) * (x0 == x0s ? 1.0f : 0.0f), (xv - x0) * (x1 == x1s ? 1.0f : 0.0f)};
+        const float wy[2] = {(y1 - yv) * (y0 == y0s ? 1.0f : 0.0f), (yv - y0) * (y1 == y1s ? 1.0f : 0.0f)};
+        const int ix[2] = {(int)x0s - dx0, (int)x1s - dx0}, iy[2] = {(int)y0s - dy0, (int)y1s - dy0};
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) {
+                const float wgt = wy[ky] * wx[kx];
+                const int xl = ix[kx], yl = iy[ky];
+                if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
+                const int idx = yl * kSpTW + (xl & 3) * (kSpTW / 4) + (xl >> 2);     // de-interleaved by 4: conflict-free finalize
+                atomicAdd(&acc[idx], wgt);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) atomicAdd(&acc[(1 + c) * kPx + idx], wgt * dv[c]);
+                if (MCH && invalid) atomicAdd(&acc[(1 + NC) * kPx + idx], wgt);
+            }
+        }
     }
 }
 
 template <int NC, bool MCH>
-__global__ __launch_bounds__(kSpNT) void splat_tile_kernel(const TiledParams p) {
-    constexpr int NPL = 1 + NC + (MCH ? 1 : 0);                 // density, data, invalid weight
-    __shared__ float acc[NPL][kSpTW * kSpTH];
-    if (*p.overflow != 0) return;                               // this launch takes the atomics path instead
-    int tx, ty, n;
-    if (!sp_decode(p, tx, ty, n)) return;
+__device__ __forceinline__ void splat_tile_atomics(const TiledParams& p, int tx, int ty, int n, int ncand, int64_t dtile,
+                                                unsigned char* raw, int* qcount) {
+    constexpr int kPx = kSpTW * kSpTH;
+    constexpr int NPL = 2 + NC;
+    float* acc = reinterpret_cast<float*>(raw);
+    uint32_t* queue = reinterpret_cast<uint32_t*>(acc + NPL * kPx);
     const SplatParams& s = p.s;
-    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3;
+    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3, lane = tid & 63;
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
     const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
-    const float* __restrict__ db = s.data + n * s.data_bs;
-    const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
-    const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
-#pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[pl][tid + i * kSpNT] = 0.0f;
-    const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
-    const int ncand = min(p.counts[dtile], kSpMaxCand);
-    const int me = ty * p.tiles_x + tx;
-    // own-pixel state for the un-occlude fill (captured when this tile meets itself as a source tile)
-    bool fill_ok[4] = {false, false, false, false};
-    f4 own[NC];
-    uint32_t own_cm = 0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) own[c] = (f4){0.f, 0.f, 0.f, 0.f};
+    const float wf = (float)w, hf = (float)h;
     __syncthreads();
-    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    for (int i = tid; i < NPL * kPx; i += kSpNT) acc[i] = 0.0f;
+    if (tid == 0) *qcount = 0;
+    __syncthreads();
     for (int ci = 0; ci < ncand; ++ci) {
         const int st = p.lists[dtile * kSpMaxCand + ci];
         const uint32_t sty = fastdiv((uint32_t)st, p.mx_m, p.mx_s), stx = (uint32_t)st - sty * (uint32_t)p.tiles_x;
         const int sx4 = (int)stx * kSpTW + lx * 4, sy = (int)sty * kSpTH + ly;
         const bool inimg = (sx4 < w) && (sy < h);
-        const uint32_t pix = (uint32_t)(sy * w + sx4);
         SpSrc q;
-        sp_load_src(s, n, sx4, sy, inimg, pix, hw, q);
-        // corner geometry of the 4 pixels; which of them put anything inside this destination tile?
-        int ix[4][2], iy[4][2];
-        float wx[4][2], wy[4][2];
-        bool hit = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float xv = q.x[k], yv = q.y[k];
-            const float x0 = floorf(xv), y0 = floorf(yv), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-            const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
-            const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
-            wx[k][0] = (x1 - xv) * (x0 == x0s ? 1.0f : 0.0f);      // utils.py:1110
-            wx[k][1] = (xv - x0) * (x1 == x1s ? 1.0f : 0.0f);
-            wy[k][0] = (y1 - yv) * (y0 == y0s ? 1.0f : 0.0f);      // utils.py:1111
-            wy[k][1] = (yv - y0) * (y1 == y1s ? 1.0f : 0.0f);
-            ix[k][0] = (int)x0s - dx0; ix[k][1] = (int)x1s - dx0; iy[k][0] = (int)y0s - dy0; iy[k][1] = (int)y1s - dy0;
-            const bool inx = ((uint32_t)ix[k][0] < (uint32_t)kSpTW) || ((uint32_t)ix[k][1] < (uint32_t)kSpTW);
-            const bool iny = ((uint32_t)iy[k][0] < (uint32_t)kSpTH) || ((uint32_t)iy[k][1] < (uint32_t)kSpTH);
-            q.on[k] = q.on[k] && inx && iny;
-            hit |= q.on[k];
-        }
-        const bool self = (st == me);
-        f4 dv[NC];
-        uint32_t cm4 = 0x01010101u;
-        if (hit || (self && inimg)) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dv[c] = *reinterpret_cast<const f4*>(db + c * hw + pix);
-            if (MCH) {
-                if (cma) cm4 = nz_bytes(*reinterpret_cast<const uint32_t*>(cma + pix));
-                if (cmb) cm4 &= nz_bytes(*reinterpret_cast<const uint32_t*>(cmb + pix));
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dv[c] = (f4){0.f, 0.f, 0.f, 0.f};
-        }
-        if (self && inimg) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) fill_ok[k] = q.zero[k] && q.wm[k];       // mask & zero_mask (utils.py:1202)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) own[c] = dv[c];
-            own_cm = cm4;
+        sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
+        if (*qcount > kSpQueue2 - 4 * kSpNT) {            // block-uniform: make room first
+            __syncthreads();
+            sp_drain<NC, MCH>(p, n, dx0, dy0, queue, *qcount, acc);
+            __syncthreads();
+            if (tid == 0) *qcount = 0;
+            __syncthreads();
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (!q.on[k]) continue;
-            const bool invalid = MCH && (((cm4 >> (8 * k)) & 0xffu) == 0u);
-#pragma unroll
-            for (int ky = 0; ky < 2; ++ky) {
-#pragma unroll
-                for (int kx = 0; kx < 2; ++kx) {
-                    const float wgt = wy[k][ky] * wx[k][kx];               // utils.py:1114
-                    const int xl = ix[k][kx], yl = iy[k][ky];
-                    if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
-                    const int idx = yl * kSpTW + (xl & 3) * (kSpTW / 4) + (xl >> 2);
-                    atomicAdd(&acc[0][idx], wgt);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) atomicAdd(&acc[1 + c][idx], wgt * (s.data_sign * dv[c][k]));
-                    if (MCH && invalid) atomicAdd(&acc[1 + NC][idx], wgt);
-                }
+            bool hit = false;
+            if (q.on[k]) {
+                const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf) - dx0;
+                const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf) - dy0;
+                hit = (x0 >= -1) && (x0 < kSpTW) && (y0 >= -1) && (y0 < kSpTH);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m != 0ull) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(qcount, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (hit) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)sy << 16) | (uint32_t)(sx4 + k);
             }
         }
+        __syncthreads();
     }
+    sp_drain<NC, MCH>(p, n, dx0, dy0, queue, *qcount, acc);
     __syncthreads();
-    // ---- finalize this destination tile: thread -> 4 consecutive destination pixels (same mapping as above)
     const int x4 = dx0 + lx * 4, y = dy0 + ly;
     if (x4 >= w || y >= h) return;
     const uint32_t pix = (uint32_t)(y * w + x4);
+    bool fill_ok[4] = {false, false, false, false};
+    if (s.occlude && s.flow) {
+        SpSrc own;
+        sp_load_src(s, n, x4, y, true, pix, hw, own);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fill_ok[k] = own.zero[k] && own.wm[k];
+    }
+    const float* __restrict__ db = s.data + n * s.data_bs;
     f4 den4, out[NC], mch4;
     uint32_t warped4 = 0, valid4 = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int idx = ly * kSpTW + k * (kSpTW / 4) + lx;
-        const float den = acc[0][idx];
-        const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
-        const bool warped = den > 0.0f;                            // utils.py:1197
-        const bool fill = s.occlude && fill_ok[k] && !warped;      // utils.py:1198-1203
+        const float den = acc[idx];
+        const float dcl = den < kDenMin ? kDenMin : den;
+        const bool warped = den > 0.0f;
+        const bool fill = fill_ok[k] && !warped;
         den4[k] = den;
         warped4 |= (uint32_t)warped << (8 * k);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            out[c][k] = apply_round(fill ? s.data_sign * own[c][k] : acc[1 + c][idx] / dcl, s.round_mode);
+            out[c][k] = apply_round(fill ? s.data_sign * db[c * hw + pix + k] : acc[(1 + c) * kPx + idx] / dcl, s.round_mode);
         if (MCH) {
-            const float m = fill ? ((((own_cm >> (8 * k)) & 0xffu) != 0u) ? 1.0f : 0.0f) : (den - acc[1 + NC][idx]) / dcl;
-            mch4[k] = m;
-            valid4 |= (uint32_t)(m > kValidThr) << (8 * k);
+            float mv;
+            if (fill) {
+                const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix + k] != 0 : true;
+                const bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix + k] != 0 : true;
+                mv = (a && b) ? 1.0f : 0.0f;
+            } else {
+                mv = (den - acc[(1 + NC) * kPx + idx]) / dcl;
+            }
+            mch4[k] = mv;
+            valid4 |= (uint32_t)(mv > kValidThr) << (8 * k);
+        }
+    }
+    float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *reinterpret_cast<f4*>(dst + c * hw + pix) = out[c];
+    if (s.density) *reinterpret_cast<f4*>(s.density + (int64_t)n * hw + pix) = den4;
+    if (s.warped) *reinterpret_cast<uint32_t*>(s.warped + (int64_t)n * hw + pix) = warped4;
+    if (MCH && s.valid) *reinterpret_cast<uint32_t*>(s.valid + (int64_t)n * hw + pix) = valid4;
+    if (MCH && s.mask_chan) *reinterpret_cast<f4*>(s.mask_chan + (int64_t)n * hw + pix) = mch4;
+}
+
+// The destination tile is accumulated WITHOUT float atomics: the touching source pixels are compacted into a queue,
+// every (source pixel, corner) pair is binned to its destination pixel with one integer LDS atomic, and each thread then
+// sums the bins of its own 4 destination pixels in registers.  A queue or bin overflow (strongly compressive flows)
+// flags the whole launch for the atomics path.
+template <int NC, bool MCH, bool BINNING>
+__global__ __launch_bounds__(kSpNT) void splat_tile_kernel(const TiledParams p) {
+    // LDS carving.  Binning path: qx | qy | qpix | bins | cnt.  Local atomics path (tile overflow): acc planes | queue2.
+    constexpr int kPx = kSpTW * kSpTH;
+    constexpr int kBytesA = kSpQueue * 12 + kPx * kSpBinCap * 2 + kPx * 4;
+    constexpr int kBytesB = (2 + NC) * kPx * 4 + kSpQueue2 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char raw[(BINNING && kBytesA > kBytesB) ? kBytesA : kBytesB];
+    __shared__ int qcount;
+    float* qx = reinterpret_cast<float*>(raw);
+    float* qy = qx + kSpQueue;
+    uint32_t* qpix = reinterpret_cast<uint32_t*>(qy + kSpQueue);
+    uint16_t* bins = reinterpret_cast<uint16_t*>(qpix + kSpQueue);
+    int* cnt = reinterpret_cast<int*>(bins + kPx * kSpBinCap);
+    if (*p.overflow != 0) return;                               // this launch takes the atomics path instead
+    int tx, ty, n;
+    if (!sp_decode(p, tx, ty, n)) return;
+    const SplatParams& s = p.s;
+    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3, lane = tid & 63;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cnt[tid + i * kSpNT] = 0;
+    if (tid == 0) qcount = 0;
+    const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
+    const int ncand = min(p.counts[dtile], kSpMaxCand);
+    if (!BINNING) {         // default in round 1: LDS float atomics (measured faster than the binning variant below)
+        splat_tile_atomics<NC, MCH>(p, tx, ty, n, ncand, dtile, raw, &qcount);
+        return;
+    }
+    __syncthreads();
+    const float wf = (float)w, hf = (float)h;
+    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    // ---- phase A: walk the candidate source tiles (16-byte loads); queue the pixels that touch this tile
+    bool qfull = false;
+    for (int ci = 0; ci < ncand; ++ci) {
+        const int st = p.lists[dtile * kSpMaxCand + ci];
+        const uint32_t sty = fastdiv((uint32_t)st, p.mx_m, p.mx_s), stx = (uint32_t)st - sty * (uint32_t)p.tiles_x;
+        const int sx4 = (int)stx * kSpTW + lx * 4, sy = (int)sty * kSpTH + ly;
+        const bool inimg = (sx4 < w) && (sy < h);
+        SpSrc q;
+        sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bool hit = false;
+            if (q.on[k]) {
+                const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf) - dx0;
+                const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf) - dy0;
+                hit = (x0 >= -1) && (x0 < kSpTW) && (y0 >= -1) && (y0 < kSpTH);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m != 0ull) {                             // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&qcount, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (hit) {
+                    if (pos < kSpQueue) { qx[pos] = q.x[k]; qy[pos] = q.y[k]; qpix[pos] = ((uint32_t)sy << 16) | (uint32_t)(sx4 + k); }
+                    else qfull = true;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int qlen = min(qcount, kSpQueue);
+    // ---- phase B: bin every (source pixel, corner) that lands inside with a non-zero weight to its destination pixel
+    bool binfull = false;
+    for (int i = tid; i < qlen; i += kSpNT) {
+        const float xv = qx[i], yv = qy[i];
+        const float x0 = floorf(xv), y0 = floorf(yv), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+        const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
+        const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
+        const float wx[2] = {(x1 - xv) * (x0 == x0s ? 1.0f : 0.0f), (xv - x0) * (x1 == x1s ? 1.0f : 0.0f)};
+        const float wy[2] = {(y1 - yv) * (y0 == y0s ? 1.0f : 0.0f), (yv - y0) * (y1 == y1s ? 1.0f : 0.0f)};
+        const int ix[2] = {(int)x0s - dx0, (int)x1s - dx0}, iy[2] = {(int)y0s - dy0, (int)y1s - dy0};
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) {
+                const int xl = ix[kx], yl = iy[ky];
+                if (wy[ky] * wx[kx] == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
+                const int d = yl * kSpTW + xl;
+                const int slot = atomicAdd(&cnt[d], 1);
+                if (slot < kSpBinCap) bins[d * kSpBinCap + slot] = (uint16_t)((i << 2) | (ky * 2 + kx));
+                else binfull = true;
+            }
+        }
+    }
+    if (__syncthreads_or((int)(qfull || binfull))) {     // compressive flow here: this tile re-runs with LDS float atomics
+        splat_tile_atomics<NC, MCH>(p, tx, ty, n, ncand, dtile, raw, &qcount);
+        return;
+    }
+    // ---- phase C: every thread sums the bins of its own 4 destination pixels in registers, then finalizes them
+    const int x4 = dx0 + lx * 4, y = dy0 + ly;
+    if (x4 >= w || y >= h) return;
+    const uint32_t pix = (uint32_t)(y * w + x4);
+    bool fill_ok[4] = {false, false, false, false};      // un-occlude fill candidates (utils.py:1198-1203)
+    if (s.occlude && s.flow) {
+        SpSrc own;
+        sp_load_src(s, n, x4, y, true, pix, hw, own);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fill_ok[k] = own.zero[k] && own.wm[k];
+    }
+    const float* __restrict__ db = s.data + n * s.data_bs;
+    const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
+    const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
+    f4 den4, out[NC], mch4;
+    uint32_t warped4 = 0, valid4 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = ly * kSpTW + lx * 4 + k;
+        const int m = min(cnt[d], kSpBinCap);
+        float den = 0.0f, inv = 0.0f, sum[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sum[c] = 0.0f;
+        for (int j = 0; j < m; ++j) {
+            const uint32_t e = bins[d * kSpBinCap + j];
+            const int i = (int)(e >> 2), kx = (int)(e & 1u), ky = (int)((e >> 1) & 1u);
+            const float xv = qx[i], yv = qy[i];
+            const uint32_t sp = qpix[i];
+            const uint32_t spix = (sp >> 16) * (uint32_t)w + (sp & 0xffffu);
+            // the corner's weight, exactly as in phase B / the reference (utils.py:1106-1114)
+            const float x0 = floorf(xv), y0 = floorf(yv);
+            const float xc = kx ? x0 + 1.0f : x0, yc = ky ? y0 + 1.0f : y0;
+            const float xcs = fminf(fmaxf(xc, 0.0f), wmax), ycs = fminf(fmaxf(yc, 0.0f), hmax);
+            const float wxk = (kx ? xv - x0 : (x0 + 1.0f) - xv) * (xc == xcs ? 1.0f : 0.0f);
+            const float wyk = (ky ? yv - y0 : (y0 + 1.0f) - yv) * (yc == ycs ? 1.0f : 0.0f);
+            const float wgt = wyk * wxk;
+            den += wgt;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sum[c] += wgt * (s.data_sign * db[c * hw + spix]);
+            if (MCH) {
+                const bool a = cma ? cma[spix] != 0 : true, b = cmb ? cmb[spix] != 0 : true;
+                if (!(a && b)) inv += wgt;
+            }
+        }
+        const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
+        const bool warped = den > 0.0f;                            // utils.py:1197
+        const bool fill = fill_ok[k] && !warped;
+        den4[k] = den;
+        warped4 |= (uint32_t)warped << (8 * k);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            out[c][k] = apply_round(fill ? s.data_sign * db[c * hw + pix + k] : sum[c] / dcl, s.round_mode);
+        if (MCH) {
+            float mv;
+            if (fill) {
+                const bool a = cma ? cma[pix + k] != 0 : true, b = cmb ? cmb[pix + k] != 0 : true;
+                mv = (a && b) ? 1.0f : 0.0f;
+            } else {
+                mv = (den - inv) / dcl;
+            }
+            mch4[k] = mv;
+            valid4 |= (uint32_t)(mv > kValidThr) << (8 * k);
         }
     }
     float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
@@ -1046,6 +1224,7 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 }
 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
+int g_splat_binning = 0;   // ofl_set_option(OFL_OPT_SPLAT_BINNING, .): 1 = atomic-free binning variant of the tiled splat
 
 template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
@@ -1081,8 +1260,13 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 
 template <int NC>
 int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
-    if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true>), dim3(grid), dim3(kSpNT), 0, st, tp);
-    else hipLaunchKernelGGL((splat_tile_kernel<NC, false>), dim3(grid), dim3(kSpNT), 0, st, tp);
+    if (tp.binning) {
+        if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true, true>), dim3(grid), dim3(kSpNT), 0, st, tp);
+        else hipLaunchKernelGGL((splat_tile_kernel<NC, false, true>), dim3(grid), dim3(kSpNT), 0, st, tp);
+    } else {
+        if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true, false>), dim3(grid), dim3(kSpNT), 0, st, tp);
+        else hipLaunchKernelGGL((splat_tile_kernel<NC, false, false>), dim3(grid), dim3(kSpNT), 0, st, tp);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1097,6 +1281,7 @@ __attribute__((visibility("default"))) int ofl_version(void) { return 11; }
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
+    if (key == OFL_OPT_SPLAT_BINNING && (value == 0 || value == 1)) { g_splat_binning = value; return OFL_OK; }
     return OFL_E_ARG;
 }
 
@@ -1275,6 +1460,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     tp.per_xcd = (tp.total + kXcds - 1) / kXcds;
     magic_u32((uint32_t)tp.tiles_x, tp.mx_m, tp.mx_s);
     magic_u32(tp.tiles_img, tp.mi_m, tp.mi_s);
+    tp.binning = g_splat_binning;
     tp.counts = workspace;
     tp.lists = workspace + tp.total;
     tp.overflow = workspace + tp.total * (1 + kSpMaxCand);

@@ -171,9 +171,17 @@ def test_exact_division_corner_cases(dev):
 # ------------------------------------------------------------------------------------------------
 # forward splat: the fused tiled kernel vs the two-pass atomics path vs the oracle
 # ------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[False, True], ids=["lds-atomics", "binning"])
+def splat_variant(request):
+    from oflibpytorch_amd import _native
+    _native.set_splat_binning(request.param)
+    yield request.param
+    _native.set_splat_binning(False)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (3, 3, 130, 260)])
 @pytest.mark.parametrize("sigma", [0.0, 3.0, 60.0])
-def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev):
+def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev, splat_variant):
     from oflibpytorch_amd import _native
     from oracle import oracle
     n, c, h, w = shape

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--only", type=str, default="")
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     n, h, w = a.batch, a.height, a.width
@@ -39,6 +40,10 @@ def main():
     rows = []
     for ref in 'ts':
         A, B = ofl.Flow(f1, ref, m1), ofl.Flow(f2, ref, m2)
+        if a.only:
+            if a.only == "apply_s" and ref == 's':
+                rows.append(("apply 's' C=3 +valid", 35, timeit(lambda: A.apply(img, target_mask=tm, return_valid_area=True), a.iters)))
+            continue
         rows.append(("apply '%s' C=3 +valid" % ref, 35, timeit(lambda: A.apply(img, target_mask=tm, return_valid_area=True), a.iters)))
         rows.append(("switch_ref %s" % ref, 18, timeit(lambda: A.switch_ref(), a.iters)))
         for mode in (3, 2, 1):

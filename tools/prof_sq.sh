@@ -5,7 +5,7 @@ out=$1; shift
 export TMPDIR=/tmp
 root=$PWD
 mkdir -p "$root/gpurun_out/$out"
-PROG=("$@"); case "${PROG[0]}" in ./*|tools/*) PROG[0]="$root/${PROG[0]#./}";; esac
+PROG=("$@"); [ "${PROG[0]}" = "python3" ] && PROG[1]="$root/${PROG[1]}"; case "${PROG[0]}" in ./*|tools/*) PROG[0]="$root/${PROG[0]#./}";; esac
 pass() {
   name=$1; shift
   (cd /tmp && timeout 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$root/gpurun_out/$out/$name" -- "${PROG[@]}" > "$root/gpurun_out/$out/$name.log" 2>&1)
