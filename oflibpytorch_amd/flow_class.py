@@ -63,6 +63,26 @@ class Flow(object):
             obj._mask = obj._mask.to(obj._device)
         return obj
 
+    @classmethod
+    def _deferred(cls, flow_vectors, ref: str = None, mask=None, device=None) -> FlowAlias:
+        """Internal: like the public constructor (same structural checks and errors) but the finiteness test is not
+        run yet -- the first kernel that reads the vectors produces the flag word as a by-product and the same
+        ValueError is raised then (tensor-level wrappers: the error surfaces inside the same call)."""
+        obj = cls.__new__(cls)
+        obj._flag_cache, obj._pending_flags, obj._mask = None, None, None
+        obj._vecs = get_valid_vecs(flow_vectors, error_string="Error setting flow vectors: ", _check_finite=False)
+        obj._device = obj._vecs.device
+        obj.ref = ref
+        if mask is not None:
+            m = get_valid_mask(mask, desired_shape=obj.shape, error_string="Error setting flow mask: ")
+            obj._mask = m.to(obj._vecs.device)
+        obj.device = device
+        return obj
+
+    def _flags_known(self) -> bool:
+        key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+        return self._flag_cache is not None and self._flag_cache[0] == key
+
     # -- flags: finiteness + zero tests, one fused reduction per tensor version ------------------
     def _flags(self) -> list:
         key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
@@ -580,8 +600,14 @@ class Flow(object):
         thresholded = False if thresholded is None else thresholded
         if not isinstance(thresholded, bool):
             raise TypeError("Error combining flows: Thresholded needs to be a boolean")
-        self._require_finite("Error combining flows: ")
-        flow._require_finite("Error combining flows: ")
+        speculative = None
+        if mode == 3 and not (self._flags_known() and flow._flags_known()):
+            # flags not known yet: launch the fused composition right away; it returns both operands' flag words as a
+            # by-product, and the reference's validation / early-exit decisions are taken afterwards (result discarded
+            # if one of them fires).  One pass over the data instead of validation passes + the composition.
+            speculative = self._combine3(flow, speculative=True)
+        self._require_finite("Error setting flow vectors: " if speculative is not None else "Error combining flows: ")
+        flow._require_finite("Error setting flow vectors: " if speculative is not None else "Error combining flows: ")
 
         bit = _native.FLAG_NZ_THR_MASKED if thresholded else _native.FLAG_NZ_MASKED
         if self._all_zero(bit):                                                      # flow_class.py:1729-1737
@@ -591,6 +617,8 @@ class Flow(object):
 
         ref = self._ref
         if mode == 3:
+            if speculative is not None and not (flow if ref == 't' else self)._all_zero(_native.FLAG_NZ_THR):
+                return speculative
             return self._combine3(flow)
         if mode == 1:
             if ref == 's':                                                           # :1759-1760
@@ -603,16 +631,22 @@ class Flow(object):
             _griddata_unavailable("combine_with(mode=2, ref='t')")
         return flow - flow.apply(self.invert().apply(self))                          # :1773
 
-    def _combine3(self, flow: FlowAlias) -> FlowAlias:
+    def _combine3(self, flow: FlowAlias, speculative: bool = False) -> FlowAlias:
         """mode 3: 't'  f3 = f2 + G(f2, f1),  m3 = m2 & theta(G(f2, [m1]))           (flow_class.py:1808)
                    's'  f3 = f1 + G(-f1, f2), m3 = m1 & theta(G(-f1, [m2]))          (flow_class.py:1804)"""
         if self._ref == 't':
             warper, sign, src = flow, 1.0, self
         else:
             warper, sign, src = self, -1.0, flow
-        if warper._all_zero(_native.FLAG_NZ_THR):
+        if not speculative and warper._all_zero(_native.FLAG_NZ_THR):
             # apply_flow's thresholded early exit inside .apply (utils.py:497): the gather is the identity
             return warper + Flow._wrap(src._vecs, src._ref, src._and_masks(warper._mask), self._device)
-        vecs, valid, _, _ = _native.warp_bwd(warper._vecs, src._vecs, flow_sign=sign, src_mask=src._mask,
-                                             flow_mask=warper._mask, want_valid=True, addend=warper._vecs)
+        vecs, valid, wf, sf = _native.warp_bwd(warper._vecs, src._vecs, flow_sign=sign, src_mask=src._mask,
+                                               flow_mask=warper._mask, want_valid=True, addend=warper._vecs,
+                                               want_flags=speculative, want_src_flags=speculative)
+        if speculative:
+            if not warper._flags_known():
+                warper._set_pending_flags(wf)
+            if not src._flags_known():
+                src._set_pending_flags(sf)
         return Flow._wrap(vecs, self._ref, valid, self._device)

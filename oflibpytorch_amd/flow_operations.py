@@ -23,7 +23,8 @@ def combine_flows(input_1, input_2, mode: int, ref: str = None, thresholded: boo
               "not work anymore in future versions - use flow_obj1.combine_with(flow_obj2) instead. combine_flows() "
               "will be reserved for use with Torch tensors and NumPy arrays only.")
         return input_1.combine_with(input_2, mode=mode, thresholded=thresholded)
-    result = Flow(input_1, ref).combine_with(Flow(input_2, ref), mode=mode, thresholded=thresholded)
+    # deferred validation: the composition kernel reports finiteness / zero flags of both operands as a by-product
+    result = Flow._deferred(input_1, ref).combine_with(Flow._deferred(input_2, ref), mode=mode, thresholded=thresholded)
     return _unwrap(result, input_1)
 
 

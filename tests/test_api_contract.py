@@ -1,0 +1,146 @@
+"""CPU tier: argument validation and error classes of the host mirror -- the reference's contract
+(TypeError for wrong Python types, ValueError for wrong shapes / values; reference tests
+test_flow_class.py:1099-1141, 2127-2140, test_utils.py:587-602, test_flow_operations.py)."""
+import numpy as np
+import pytest
+import torch
+
+import oflibpytorch_amd as ofl
+from oflibpytorch_amd import Flow
+
+
+@pytest.fixture(autouse=True)
+def _oracle(oracle_native):
+    yield
+
+
+def _flow(n=1, h=12, w=16, ref='t', seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return Flow(torch.randn(n, 2, h, w, generator=g) * 2, ref)
+
+
+def test_flow_constructor_contract():
+    with pytest.raises(TypeError):
+        Flow([[1, 2], [3, 4]])
+    with pytest.raises(ValueError):
+        Flow(torch.zeros(2, 2))                      # 2 dims
+    with pytest.raises(ValueError):
+        Flow(torch.zeros(3, 5, 7))                   # neither 2-H-W nor H-W-2
+    bad = torch.zeros(1, 2, 5, 7); bad[0, 1, 2, 3] = float('nan')
+    with pytest.raises(ValueError):
+        Flow(bad)
+    with pytest.raises(ValueError):
+        Flow(torch.zeros(2, 5, 7), 'x')
+    with pytest.raises(TypeError):
+        Flow(torch.zeros(2, 5, 7), 3)
+    with pytest.raises(ValueError):
+        Flow(torch.zeros(2, 5, 7), 't', torch.ones(5, 8))          # mask shape
+    with pytest.raises(ValueError):
+        Flow(torch.zeros(2, 5, 7), 't', torch.full((5, 7), 2.0))   # mask values
+    with pytest.raises(TypeError):
+        Flow(torch.zeros(2, 5, 7), 't', 'mask')
+    f = Flow(np.zeros((5, 7, 2), 'float32'))                        # H-W-2 numpy accepted
+    assert f.shape == (1, 5, 7) and f.ref == 't' and f.mask.dtype == torch.bool and bool(f.mask.all())
+    assert f.vecs.dtype == torch.float32 and f.vecs_numpy.shape == (1, 5, 7, 2)
+
+
+def test_apply_contract():
+    f = _flow()
+    img = torch.rand(3, 12, 16)
+    for kw in ({"return_valid_area": 'yes'}, {"consider_mask": 1}, {"cut": 0}):
+        with pytest.raises(TypeError):
+            f.apply(img, **kw)
+    with pytest.raises(TypeError):
+        f.apply('image')
+    with pytest.raises(ValueError):
+        f.apply(torch.rand(1, 1, 3, 12, 16))
+    with pytest.raises(ValueError):
+        f.apply(torch.rand(3, 11, 16))                               # shape mismatch, no padding
+    with pytest.raises(TypeError):
+        f.apply(img, target_mask='m', return_valid_area=True)
+    with pytest.raises(ValueError):
+        f.apply(img, target_mask=torch.ones(11, 16, dtype=torch.bool), return_valid_area=True)
+    with pytest.raises(TypeError):
+        f.apply(img, target_mask=torch.ones(12, 16), return_valid_area=True)      # not bool
+    with pytest.raises(TypeError):
+        f.apply(torch.rand(3, 14, 18), padding=1)                                  # get_valid_padding (utils.py:215-232)
+    with pytest.raises(ValueError):
+        f.apply(torch.rand(3, 14, 18), padding=[1, 1, 1])
+    with pytest.raises(ValueError):
+        f.apply(torch.rand(3, 14, 18), padding=[1, 1, 1, -1])
+    with pytest.raises(ValueError):
+        f.apply(torch.rand(3, 14, 18), padding=[2, 2, 1, 1])                      # does not add up
+    with pytest.warns(UserWarning):
+        f.apply(img, target_mask=torch.ones(12, 16, dtype=torch.bool))
+    out = f.apply(torch.rand(3, 14, 18), padding=[1, 1, 1, 1])
+    assert out.shape == (3, 12, 16)
+    out = f.apply(torch.rand(3, 14, 18), padding=[1, 1, 1, 1], cut=False)
+    assert out.shape == (3, 14, 18)
+
+
+def test_combine_contract():
+    a, b = _flow(2), _flow(2, seed=1)
+    with pytest.raises(TypeError):
+        a.combine_with(b.vecs, 3)
+    with pytest.raises(ValueError):
+        a.combine_with(_flow(1), 3)                                   # batch mismatch
+    with pytest.raises(ValueError):
+        a.combine_with(_flow(2, ref='s'), 3)                          # reference mismatch
+    with pytest.raises(ValueError):
+        a.combine_with(b, 0)
+    with pytest.raises(TypeError):
+        a.combine_with(b, 3, thresholded='no')
+    bad = torch.randn(2, 12, 16); bad[1, 3, 3] = float('inf')
+    with pytest.raises(ValueError):
+        ofl.combine_flows(bad, torch.zeros(2, 12, 16), 3, 't')       # deferred validation still raises, same call
+    with pytest.raises(ValueError):
+        ofl.combine_flows(torch.ones(2, 12, 16), bad, 3, 's')
+    z = torch.zeros(2, 12, 16)
+    f = torch.randn(2, 12, 16)
+    assert torch.equal(ofl.combine_flows(z, f, 3, 't'), f)            # zero first operand: the second comes back
+    assert torch.equal(ofl.combine_flows(f, z, 3, 't'), f)
+    out = ofl.combine_flows(f.numpy(), torch.randn(2, 12, 16).numpy(), 3)
+    assert isinstance(out, torch.Tensor) and out.shape == (2, 12, 16)
+
+
+def test_misc_contract():
+    f = _flow(2)
+    with pytest.raises(TypeError):
+        f.is_zero(masked='x')
+    with pytest.raises(TypeError):
+        f.is_zero(thresholded=1)
+    with pytest.raises(ValueError):
+        f.switch_ref('maybe')
+    with pytest.raises(ValueError):
+        f.invert('x')
+    with pytest.raises(TypeError):
+        f + 'flow'
+    with pytest.raises(ValueError):
+        f + torch.zeros(2, 2, 5, 5)
+    with pytest.raises(ValueError):
+        f * [1, 2, 3]
+    with pytest.raises(TypeError):
+        f * 'two'
+    with pytest.raises(TypeError):
+        f.select('0')
+    with pytest.raises(IndexError):
+        f.select(5)
+    with pytest.raises(ValueError):
+        f.pad([1, 1, 1, 1], mode='wrap')
+    assert f.select(1).shape == (1, 12, 16) and f[2:8, 4:10].shape == (2, 6, 6)
+    assert (f * 2).vecs.allclose(f.vecs * 2) and (f / 2).vecs.allclose(f.vecs / 2) and (-f).vecs.allclose(-f.vecs)
+    assert f.pad([1, 2, 3, 4]).shape == (2, 15, 23) and f.pad([1, 2, 3, 4]).unpad([1, 2, 3, 4]).shape == f.shape
+    assert f.copy().vecs.data_ptr() == f.vecs.data_ptr()                            # aliasing like the reference
+    with pytest.raises(ValueError):
+        ofl.apply_flow(torch.zeros(2, 5, 7) + 1, torch.rand(3, 5, 8), 't')
+    with pytest.raises(TypeError):
+        ofl.apply_flow(torch.zeros(2, 5, 7) + 1, np.zeros((5, 7)), 't')
+    with pytest.raises(ValueError):
+        ofl.apply_flow(torch.ones(2, 2, 5, 7), torch.rand(3, 1, 5, 7), 't')       # batch 2 vs 3
+    ofl.unset_pure_pytorch()
+    try:
+        assert ofl.get_pure_pytorch() is False
+        with pytest.raises(NotImplementedError):
+            Flow(torch.ones(2, 5, 7), 's').apply(torch.rand(5, 7))
+    finally:
+        ofl.set_pure_pytorch()
