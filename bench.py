@@ -195,7 +195,8 @@ def main():
             "value_with_flow_construction": round(world * px / (el2 / k2) / 1e6, 1),
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(h, w, args.cpu_seconds, os.cpu_count() or 1)
+            # 64 OpenMP threads is where the oracle peaks on the 2 x 64-core host of the GPU box (tools/cpu_threads_probe.py)
+            out["cpu_baseline"] = cpu_baseline(h, w, args.cpu_seconds, min(os.cpu_count() or 1, 64))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
