@@ -3394,7 +3394,7 @@ __device__ __forceinline__ void v15_write(f4* lds, const B15& B, const Stage15<N
     }
 }
 
-template <int NT, int TWQ>
+template <int NT, int TWQ, int ABL = 0>
 __device__ __forceinline__ void v15_gather_store(const P& p, int tx, int ty, int n, unsigned hw, const T15& T, const B15& B,
                                                  unsigned fm4, const unsigned char* smem) {
     constexpr int TH = NT / TWQ;
@@ -3444,14 +3444,16 @@ __device__ __forceinline__ void v15_gather_store(const P& p, int tx, int ty, int
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             vo |= (unsigned)((outv[k][3] > 0.99999f) && (((fm4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        if (ABL != 1 || vo == 0x12345678u) {
         *reinterpret_cast<unsigned*>(vb + pix) = vo;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             *reinterpret_cast<f4*>(db + c * hw + pix) = (f4){outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+        }
     }
 }
 
-template <int NT, int TWQ, int ITERS>
+template <int NT, int TWQ, int ITERS, int ABL = 0>
 __global__ __launch_bounds__(NT, 3) void warp_v15(const P5 pp, const int lds_bytes) {
     constexpr int TH = NT / TWQ, NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -3480,12 +3482,148 @@ __global__ __launch_bounds__(NT, 3) void warp_v15(const P5 pp, const int lds_byt
     v15_write<NT, ITERS>(lds, BA, S);
     lds_barrier();
     if (haveB) v15_issue<NT, ITERS>(p, n, hw, BB, S);                          // staging loads of B in flight while A is gathered
-    v15_gather_store<NT, TWQ>(p, tx, tyA, n, hw, TA, BA, fmA, smem);
+    v15_gather_store<NT, TWQ, ABL>(p, tx, tyA, n, hw, TA, BA, fmA, smem);
     if (!haveB) return;
     lds_barrier();
     v15_write<NT, ITERS>(lds, BB, S);
     lds_barrier();
-    v15_gather_store<NT, TWQ>(p, tx, tyB, n, hw, TB, BB, fmB, smem);
+    v15_gather_store<NT, TWQ, ABL>(p, tx, tyB, n, hw, TB, BB, fmB, smem);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// V16: persistent blocks with a dedicated STORE wave.  Waves 0-1 (128 threads) run the V15 two-tile pipeline but put
+// their results into an LDS output buffer; wave 2 copies that buffer to global memory.  The compute waves never issue a
+// global store, so their in-order vmcnt queue only ever holds loads: the flow of the next tile pair is prefetched
+// into the (dead) flow registers and no wait ever covers a store acknowledgement; the store wave's acknowledgements
+// drain while the block is already working on the next tiles.
+// ---------------------------------------------------------------------------------------------
+template <int ITERS, int ABL = 0>
+__global__ __launch_bounds__(192, 3) void warp_v16(const P5 pp, const int lds_bytes) {
+    constexpr int NT = 128, TWQ = 8, TH = 16, NW = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // staging slots | output buffer
+    __shared__ int red[2][NW][4];
+    const P& p = pp.p;
+    const int tid = threadIdx.x;
+    const bool storer = tid >= NT;
+    const int w = p.w, h = p.h;
+    const unsigned hw = (unsigned)(h * w);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    float* outb = reinterpret_cast<float*>(smem + lds_bytes);               // [3][512] floats + [128] dwords of valid bytes
+    unsigned* outv = reinterpret_cast<unsigned*>(outb + 3 * 512);
+    const int lx = tid % TWQ, ly = (tid % NT) / TWQ;
+
+    int tx, ty2, n;
+    bool have = decode_tile_at(p, 0, tx, ty2, n);
+    f4 uA, vA, uB, vB; unsigned fmA = 0, fmB = 0;
+    auto load_flow = [&](int tx_, int ty2_, int n_) {
+        const int xq = min(tx_ * (TWQ * 4) + lx * 4, w - 4);
+        const unsigned pixA = (unsigned)(min(2 * ty2_ * TH + ly, h - 1) * w + xq), pixB = (unsigned)(min((2 * ty2_ + 1) * TH + ly, h - 1) * w + xq);
+        const float* __restrict__ fu = p.flow + (size_t)n_ * 2 * hw; const uint8_t* __restrict__ fm = p.fmask + (size_t)n_ * hw;
+        uA = *reinterpret_cast<const f4*>(fu + pixA); vA = *reinterpret_cast<const f4*>(fu + hw + pixA);
+        uB = *reinterpret_cast<const f4*>(fu + pixB); vB = *reinterpret_cast<const f4*>(fu + hw + pixB);
+        fmA = *reinterpret_cast<const unsigned*>(fm + pixA); fmB = *reinterpret_cast<const unsigned*>(fm + pixB);
+    };
+    if (have && !storer) load_flow(tx, ty2, n);
+
+    // the store wave copies one tile's results from the LDS output buffer to global memory (lane l: float4 #l and #l+64)
+    auto store_tile = [&](int tx_, int ty_, int n_) {
+        const int l = tid - NT;
+        float* __restrict__ db = p.dst + (size_t)n_ * 3 * hw; uint8_t* __restrict__ vb = p.valid + (size_t)n_ * hw;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int i4 = l + 64 * half, row = i4 >> 3, x4 = (i4 & 7) * 4;
+            const int gx = tx_ * 32 + x4, gy = ty_ * TH + row;
+            if (gx < w && gy < h) {
+                const unsigned pix = (unsigned)(gy * w + gx);
+                if (ABL != 1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) *reinterpret_cast<f4*>(db + c * hw + pix) = *reinterpret_cast<const f4*>(outb + c * 512 + i4 * 4);
+                *reinterpret_cast<unsigned*>(vb + pix) = outv[i4];
+                }
+            }
+        }
+    };
+    // compute waves: gather + blend one tile, results into the LDS output buffer
+    auto gather_tile = [&](int tx_, int ty_, const T15& T, const B15& B, unsigned fm4, int n_) {
+        const float* __restrict__ sb = p.src + (size_t)n_ * 3 * hw; const uint8_t* __restrict__ sm = p.smask + (size_t)n_ * hw;
+        const int cw16 = B.cw * 16, P16 = B.Pp * 16;
+        const float wf_ = (float)w, hf_ = (float)h;
+        f4 outp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float fx = floorf(T.sx[k]), fy = floorf(T.sy[k]);
+            const float ww = T.sx[k] - fx, e_ = 1.0f - ww, nn = T.sy[k] - fy, s_ = 1.0f - nn;
+            const float wg[4] = {s_ * e_, s_ * ww, nn * e_, nn * ww};
+            const int xi_ = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, wf_), yi_ = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, hf_);
+            const bool x0 = (unsigned)xi_ < (unsigned)w, x1 = (unsigned)(xi_ + 1) < (unsigned)w;
+            const bool y0 = (unsigned)yi_ < (unsigned)h, y1 = (unsigned)(yi_ + 1) < (unsigned)h;
+            const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+            f4 tv[4];
+            if (B.fits) {
+                const int xl0 = xi_ - B.bx0, xl1 = xl0 + 1;
+                const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
+                const int r0 = 16 + (yi_ - B.miny) * P16, r1 = r0 + P16;
+                const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+            } else {
+                const int cx[4] = {xi_, xi_ + 1, xi_, xi_ + 1}, cy[4] = {yi_, yi_, yi_ + 1, yi_ + 1};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned og = ok[j] ? (unsigned)(cy[j] * w + cx[j]) : 0u;
+                    tv[j] = ok[j] ? (f4){sb[og], sb[hw + og], sb[2 * hw + og], (float)(sm[og] != 0)} : (f4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            f4 r = tv[0] * wg[0];
+            r = __builtin_elementwise_fma(tv[1], (f4){wg[1], wg[1], wg[1], wg[1]}, r);
+            r = __builtin_elementwise_fma(tv[2], (f4){wg[2], wg[2], wg[2], wg[2]}, r);
+            r = __builtin_elementwise_fma(tv[3], (f4){wg[3], wg[3], wg[3], wg[3]}, r);
+            outp[k] = r;
+        }
+        unsigned vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            vo |= (unsigned)((outp[k][3] > 0.99999f) && (((fm4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        const int i4 = ly * 8 + lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4*>(outb + c * 512 + i4 * 4) = (f4){outp[0][c], outp[1][c], outp[2][c], outp[3][c]};
+        outv[i4] = vo;
+    };
+
+    for (unsigned it = 1; have; ++it) {
+        const int tyA = 2 * ty2, tyB = tyA + 1;
+        const bool haveB = tyB * TH < h;
+        int ntx, nty2, nn;
+        const bool nhave = decode_tile_at(p, it, ntx, nty2, nn);
+        if (!storer) {
+            T15 TA, TB; B15 BA, BB;
+            Stage15<NT, ITERS> S;
+            const unsigned fA = fmA, fB = fmB;
+            v15_taps<NT, TWQ, ITERS>(pp, tx, tyA, uA, vA, TA, BA, red[0], lds_bytes);          // barrier #1 inside
+            v15_issue<NT, ITERS>(p, n, hw, BA, S);
+            v15_taps<NT, TWQ, ITERS>(pp, tx, tyB, uB, vB, TB, BB, red[1], lds_bytes);          // barrier #2 inside
+            if (nhave) load_flow(ntx, nty2, nn);             // prefetch: the flow registers are dead from here on
+            v15_write<NT, ITERS>(lds, BA, S);
+            lds_barrier();                                                                     // #3
+            if (haveB) v15_issue<NT, ITERS>(p, n, hw, BB, S);
+            gather_tile(tx, tyA, TA, BA, fA, n);
+            lds_barrier();                                                                     // #4: A's results are in the buffer
+            if (haveB) v15_write<NT, ITERS>(lds, BB, S);
+            lds_barrier();                                                                     // #5: (store wave has read A)
+            if (haveB) gather_tile(tx, tyB, TB, BB, fB, n);
+            lds_barrier();                                                                     // #6: B's results are in the buffer
+        } else {
+            lds_barrier(); lds_barrier(); lds_barrier();                                       // #1 #2 #3
+            lds_barrier();                                                                     // #4
+            store_tile(tx, tyA, n);
+            lds_barrier();                                                                     // #5
+            lds_barrier();                                                                     // #6
+            if (haveB) store_tile(tx, tyB, n);
+        }
+        lds_barrier();          // #7: output buffer, staging slots and `red` are free for the next pair
+        tx = ntx; ty2 = nty2; n = nn; have = nhave;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3803,8 +3941,21 @@ int main(int argc, char** argv) {
         report(name, time_it([&] { hipLaunchKernelGGL((warp_v15<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
     RUN15("v15 128t 2x(32x16) 26K", 128, 8, 4, 26624)
     RUN15("v15 128t 2x(32x16) 26K it3", 128, 8, 3, 26624)
+    if (strstr("v15 abl no stores", only)) { unsigned g = grid_for(32, 32); P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1;
+        CK(hipFuncSetAttribute((const void*)warp_v15<128, 8, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 26624));
+        report("v15 abl no stores", time_it([&] { hipLaunchKernelGGL((warp_v15<128, 8, 3, 1>), dim3(g), dim3(128), 26624, 0, pp, 26624); }, it)); }
     RUN15("v15 256t 2x(32x32) 48K", 256, 8, 4, 49152)
     RUN15("v15 64t 2x(16x16) 13K", 64, 4, 4, 13312)
+#define RUN16(name, ITERS, LDSB, G, ABL) if (strstr(name, only)) { grid_for(32, 32); unsigned g = G; \
+        P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1; \
+        CK(hipFuncSetAttribute((const void*)warp_v16<ITERS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB + 6656)); \
+        hipLaunchKernelGGL((warp_v16<ITERS, ABL>), dim3(g), dim3(192), LDSB + 6656, 0, pp, LDSB); if (!ABL) check(name); \
+        report(name, time_it([&] { hipLaunchKernelGGL((warp_v16<ITERS, ABL>), dim3(g), dim3(192), LDSB + 6656, 0, pp, LDSB); }, it)); }
+    RUN16("v16 store-wave 26K g1024", 3, 26624, 1024, 0)
+    RUN16("v16 store-wave 26K g1280", 3, 26624, 1280, 0)
+    RUN16("v16 store-wave 24K g1280", 3, 24576, 1280, 0)
+    RUN16("v16 store-wave 26K g768", 3, 26624, 768, 0)
+    RUN16("v16 store-wave 26K g1024 nostores", 3, 26624, 1024, 1)
     if (strstr("stamps8", only)) {
         unsigned g = grid_for(32, 16); P5 pp; pp.p = p; pp.rw = 1.0f / p.wm1; pp.rh = 1.0f / p.hm1;
         unsigned long long* dst_; CK(hipMalloc(&dst_, 64 * 16 * 8)); CK(hipMemset(dst_, 0, 64 * 16 * 8));
