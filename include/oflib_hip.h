@@ -59,6 +59,9 @@ int ofl_version(void);
 /*   OFL_OPT_SPLAT_BINNING: 0 = tiled splat accumulates with LDS float atomics (default), 1 = atomic-free binning variant
  *                          (integer LDS atomics + register sums; tiles it cannot take fall back to the float atomics). */
 #define OFL_OPT_SPLAT_BINNING 2
+/*   OFL_OPT_WARP_SHEAR: 1 = the LDS-staged warp kernel stages a y-sheared box (default), 0 = plain bounding box
+ *   (speed only; the results are identical). */
+#define OFL_OPT_WARP_SHEAR 3
 int ofl_set_option(int32_t key, int32_t value);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,

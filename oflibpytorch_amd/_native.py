@@ -32,7 +32,7 @@ def load_library(path: str = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or _build.LIB_PATH
+    path = path or os.environ.get("OFL_HIP_LIB") or _build.LIB_PATH   # OFL_HIP_LIB: A/B of two builds (tools/ab_warp.py)
     if not os.path.exists(path):
         try:
             _build.build()
@@ -74,6 +74,11 @@ def set_splat_path(mode: int):
 def set_splat_binning(on: bool):
     """Tiled splat: False = LDS float atomics (default), True = atomic-free binning variant."""
     _check(load_library().ofl_set_option(2, 1 if on else 0), "ofl_set_option")
+
+
+def set_warp_shear(on: bool):
+    """LDS-staged warp kernel: True = y-sheared staging box (default), False = plain bounding box (speed only)."""
+    _check(load_library().ofl_set_option(3, 1 if on else 0), "ofl_set_option")
 
 
 def set_warp_path(mode: int):

@@ -89,7 +89,7 @@ struct WarpParams {
     int32_t tiles_x, tiles_y;
     int64_t total_tiles, per_xcd;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;   // magic divisors by tiles_x and by tiles per image
-    int32_t lds_bytes;
+    int32_t lds_bytes, shear;
 };
 
 constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
@@ -202,11 +202,29 @@ __device__ __forceinline__ int lds_pitch(int n) {   // smallest P >= n with P % 
 }
 
 struct LdsCoords { float sx[4], sy[4]; };                              // un-normalised sample positions of 4 pixels
-struct LdsBox { int bx0, miny, cw, Pp, bh, nch; bool fits; };          // wave-uniform staging geometry
+struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits; };   // wave-uniform staging geometry
+
+// Y-SHEARED box: a 32-wide tile under a flow with dv/dx != 0 touches a slanted band of source rows, and a plain bounding
+// box wastes the two triangles above and below it.  Chunk column c (4 pixels) of the staged box therefore starts at image
+// row miny + lds_shear(c, sq), with one block-uniform slope sq (rows per chunk column, Q8).  The box is taken in the
+// sheared coordinate y' = y - lds_shear(x >> 2, sq): every slope is correct; a good one makes the box ~12 % smaller and
+// boxes that overflow the LDS budget ~10x rarer (2.7 % -> 0.25 % of the tiles of the bench workload).
+__device__ __forceinline__ int lds_shear(int c, int sq) { return __mul24(c, sq) >> 8; }
+
+// slope estimate from the flow at the two ends of the row between the block's two tiles (scalar loads: uniform addresses)
+__device__ __forceinline__ int lds_slope(const WarpParams& p, const float* __restrict__ fu, uint32_t hw, int tx, int ty2) {
+    const int w = p.w, h = p.h;
+    const int y = min(ty2 * (2 * kLdsTH) + kLdsTH, h - 1), xa = min(tx * (kLdsTWQ * 4), w - 1), xb = min(xa + kLdsTWQ * 4 - 1, w - 1);
+    const float ul = fu[y * w + xa], ur = fu[y * w + xb], vl = fu[hw + y * w + xa], vr = fu[hw + y * w + xb];
+    const float dx = (float)(xb - xa) - p.flow_sign * (ur - ul), dy = -p.flow_sign * (vr - vl);
+    float q = 1024.0f * dy / dx;                                   // 256 * dy / (dx / 4)
+    q = (dx > 4.0f) ? __builtin_amdgcn_fmed3f(q, -4096.0f, 4096.0f) : 0.0f;   // NaN, folds, degenerate spans: no shear
+    return __builtin_amdgcn_readfirstlane((int)rintf(q));
+}
 template <int NC> struct LdsStage { int slot[kLdsIters]; f4 q[kLdsIters][NC]; uint32_t mq[kLdsIters]; };
 
 // steps 1-2 for one tile
-__device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int ty, const f4& u4, const f4& v4,
+__device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
                                                LdsCoords& T, LdsBox& B, int (*red)[4]) {
     constexpr int NW = kLdsNT / 64;
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
@@ -260,7 +278,9 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
             // coordinate lands on 0 through the conversion and is blended with NaN weights like the reference's)
             const int xi = (int)__builtin_amdgcn_fmed3f(floorf(sx[i]), -2.0f, wf);
             const int yi = (int)__builtin_amdgcn_fmed3f(floorf(sy[i]), -2.0f, hf);
-            minx = min(minx, xi); maxx = max(maxx, xi); miny = min(miny, yi); maxy = max(maxy, yi);
+            const int s0 = lds_shear(xi >> 2, sq), s1 = lds_shear((xi + 1) >> 2, sq);   // west / east tap columns
+            minx = min(minx, xi); maxx = max(maxx, xi);
+            miny = min(miny, yi - max(s0, s1)); maxy = max(maxy, yi + 1 - min(s0, s1));
         }
     }
     minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
@@ -273,14 +293,15 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
             miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
         }
     }
-    // touched columns [minx, maxx + 1] / rows [miny, maxy + 1], clipped to the image (wave-uniform)
+    // touched columns [minx, maxx + 1] clipped to the image; sheared rows [miny, maxy] as they are (a staged row that falls
+    // outside the image is skipped and never read back)   (wave-uniform)
     minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
-    miny = max(__builtin_amdgcn_readfirstlane(miny), 0); maxy = min(__builtin_amdgcn_readfirstlane(maxy) + 1, h - 1);
-    const bool empty = (maxx < minx) || (maxy < miny);
-    B.bx0 = minx & ~3; B.miny = miny;
+    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
+    const bool empty = maxx < minx;
+    B.bx0 = minx & ~3; B.miny = miny; B.sq = sq; B.cbase = B.bx0 >> 2;
     const int bw = empty ? 4 : (((maxx + 4) & ~3) - B.bx0);
     B.bh = empty ? 1 : (maxy - miny + 1); B.cw = bw >> 2; B.Pp = lds_pitch(bw); B.nch = B.bh * B.cw;
-    B.fits = !empty && (16 * (1 + B.bh * B.Pp) <= p.lds_bytes) && (B.nch <= kLdsIters * kLdsNT);
+    B.fits = !empty && (B.bh <= 4096) && (16 * (1 + B.bh * B.Pp) <= p.lds_bytes) && (B.nch <= kLdsIters * kLdsNT);
 }
 
 // step 3a: issue the staging loads of a tile into registers (nothing waits here)
@@ -295,10 +316,12 @@ __device__ __forceinline__ void lds_issue(const WarpParams& p, const float* __re
         S.slot[it] = -1;
         if (it < rounds) {
             const uint32_t i = (uint32_t)tid + it * kLdsNT;
-            const bool on = i < (uint32_t)B.nch;
-            const uint32_t r = (i * inv) >> 20, c4 = i - r * (uint32_t)B.cw;
-            const uint32_t g = on ? (uint32_t)((B.miny + (int)r) * p.w + B.bx0) + c4 * 4u : 0u;
-            S.slot[it] = on ? 1 + (int)(r * (uint32_t)B.Pp + c4) : -1;
+            // 24-bit multiplies (full rate): i < 2^9, inv <= 2^20, rows and columns < 2^13, h * w < 2^24
+            const uint32_t r = __umul24(i, inv) >> 20, c4 = i - __umul24(r, (uint32_t)B.cw);
+            const int y = B.miny + (int)r + lds_shear(B.cbase + (int)c4, B.sq);
+            const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h);
+            const uint32_t g = on ? (uint32_t)(__mul24(y, p.w) + B.bx0) + c4 * 4u : 0u;
+            S.slot[it] = on ? 1 + (int)(__umul24(r, (uint32_t)B.Pp) + c4) : -1;
 #pragma unroll
             for (int c = 0; c < NC; ++c) S.q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
             S.mq[it] = (VALID && sm) ? *reinterpret_cast<const uint32_t*>(sm + g) : 0x01010101u;
@@ -325,20 +348,14 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
     }
 }
 
-// step 4: gather from LDS (or from global memory when the box did not fit), blend, epilogue, store
-template <int NC, bool VALID, bool ADD>
-__device__ __forceinline__ void lds_gather_store(const WarpParams& p, int tx, int ty, int n, uint32_t hw,
-                                                 const float* __restrict__ sb, const uint8_t* __restrict__ sm,
-                                                 const LdsCoords& T, const LdsBox& B, uint32_t fmask4,
-                                                 const unsigned char* smem) {
-    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+// step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
+template <int NC, bool VALID>
+__device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
+                                           const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+                                           const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4]) {
     const int w = p.w, h = p.h;
-    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
-    const bool inb = (x4 < w) && (y < h);
-    const uint32_t pix = (uint32_t)(min(y, h - 1) * w + min(x4, w - 4));
     const int cw16 = B.cw * 16, P16 = B.Pp * 16;
     const float wf = (float)w, hf = (float)h;
-    f4 outv[4];   // per pixel: (c0, c1, c2, mask channel)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float fx = floorf(T.sx[k]), fy = floorf(T.sy[k]);
@@ -352,9 +369,10 @@ __device__ __forceinline__ void lds_gather_store(const WarpParams& p, int tx, in
         f4 tv[4];
         if (B.fits) {
             const int xl0 = xi - B.bx0, xl1 = xl0 + 1;
-            const int cp0 = (xl0 & 3) * cw16 + ((xl0 & ~3) << 2), cp1 = (xl1 & 3) * cw16 + ((xl1 & ~3) << 2);
-            const int r0 = 16 + (yi - B.miny) * P16, r1 = r0 + P16;
-            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r0 + cp1 : 0, ok[2] ? r1 + cp0 : 0, ok[3] ? r1 + cp1 : 0};
+            const int cp0 = __mul24(xl0 & 3, cw16) + ((xl0 & ~3) << 2), cp1 = __mul24(xl1 & 3, cw16) + ((xl1 & ~3) << 2);
+            const int yr = yi - B.miny;   // row in the sheared box, per tap column
+            const int r0 = 16 + __mul24(yr - lds_shear(xi >> 2, B.sq), P16), r1 = 16 + __mul24(yr - lds_shear((xi + 1) >> 2, B.sq), P16);
+            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r1 + cp1 : 0, ok[2] ? r0 + P16 + cp0 : 0, ok[3] ? r1 + P16 + cp1 : 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
         } else {
@@ -378,6 +396,26 @@ __device__ __forceinline__ void lds_gather_store(const WarpParams& p, int tx, in
         r = __builtin_elementwise_fma(tv[3], (f4){wg[3], wg[3], wg[3], wg[3]}, r);
         outv[k] = r;
     }
+}
+
+// the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
+template <int NC>
+__device__ __forceinline__ void lds_load_addend(const WarpParams& p, int tx, int ty, int n, uint32_t hw, f4 (&a)[NC]) {
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const uint32_t pix = (uint32_t)(min(ty * kLdsTH + ly, p.h - 1) * p.w + min(tx * (kLdsTWQ * 4) + lx * 4, p.w - 4));
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a[c] = *reinterpret_cast<const f4*>(p.addend + n * p.addend_bs + c * hw + pix);
+}
+
+// step 4b: valid mask, epilogue (a_sign * addend + g_sign * G, rounding), 16-byte stores
+template <int NC, bool VALID, bool ADD>
+__device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, int n, uint32_t hw, uint32_t fmask4,
+                                          const f4 (&outv)[4], const f4 (&addend)[NC]) {
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h;
+    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
+    const bool inb = (x4 < w) && (y < h);
+    const uint32_t pix = (uint32_t)(min(y, h - 1) * w + min(x4, w - 4));
     if (inb) {
         if (VALID) {
             uint32_t vo = 0;
@@ -390,10 +428,7 @@ __device__ __forceinline__ void lds_gather_store(const WarpParams& p, int tx, in
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
-            if (ADD) {   // re-read rather than kept in registers across the pipeline (an L2 hit when it aliases the flow)
-                const f4 a = *reinterpret_cast<const f4*>(p.addend + n * p.addend_bs + c * hw + pix);
-                o = a * p.a_sign + o * p.g_sign;
-            }
+            if (ADD) o = addend[c] * p.a_sign + o * p.g_sign;
             if (p.round_mode != OFL_ROUND_NONE) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], p.round_mode);
@@ -444,18 +479,30 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     LdsCoords TA, TB;
     LdsBox BA, BB;
     LdsStage<NC> S;
-    lds_coords_box(p, tx, tyA, uA, vA, TA, BA, red[0]);
+    const int sq = p.shear ? lds_slope(p, fu, hw, tx, ty2) : 0;
+    lds_coords_box(p, tx, tyA, uA, vA, sq, TA, BA, red[0]);
     lds_issue<NC, VALID>(p, sb, sm, hw, BA, S);                 // staging loads of A fly ...
-    lds_coords_box(p, tx, tyB, uB, vB, TB, BB, red[1]);         // ... while B's coordinates are computed
+    lds_coords_box(p, tx, tyB, uB, vB, sq, TB, BB, red[1]);     // ... while B's coordinates are computed
     lds_write<NC, VALID>(lds, BA, S);
     lds_barrier();
+    // the vmcnt queue is in order: the addend (an L2 hit when it is the flow itself) is fetched BEFORE B's staging loads /
+    // A's stores, so that waiting for it never waits for them
+    // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
+    constexpr bool EARLY = ADD && NC <= 2;
+    f4 outv[4], aA[NC], aB[NC];
+    if (EARLY) lds_load_addend<NC>(p, tx, tyA, n, hw, aA);
     if (haveB) lds_issue<NC, VALID>(p, sb, sm, hw, BB, S);      // staging loads of B fly while A is gathered and stored
-    lds_gather_store<NC, VALID, ADD>(p, tx, tyA, n, hw, sb, sm, TA, BA, fmA, smem);
+    lds_gather<NC, VALID>(p, hw, sb, sm, TA, BA, smem, outv);
+    if (EARLY && haveB) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
+    if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyA, n, hw, aA);
+    lds_store<NC, VALID, ADD>(p, tx, tyA, n, hw, fmA, outv, aA);
     if (!haveB) return;
     lds_barrier();
     lds_write<NC, VALID>(lds, BB, S);
     lds_barrier();
-    lds_gather_store<NC, VALID, ADD>(p, tx, tyB, n, hw, sb, sm, TB, BB, fmB, smem);
+    lds_gather<NC, VALID>(p, hw, sb, sm, TB, BB, smem, outv);
+    if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
+    lds_store<NC, VALID, ADD>(p, tx, tyB, n, hw, fmB, outv, aB);
 }
 
 // CT = compile-time channel count (0: run-time p.c)
@@ -1224,6 +1271,7 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 }
 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
+int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_binning = 0;   // ofl_set_option(OFL_OPT_SPLAT_BINNING, .): 1 = atomic-free binning variant of the tiled splat
 
 template <int NC>
@@ -1282,6 +1330,7 @@ __attribute__((visibility("default"))) int ofl_version(void) { return 11; }
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_BINNING && (value == 0 || value == 1)) { g_splat_binning = value; return OFL_OK; }
+    if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     return OFL_E_ARG;
 }
 
@@ -1307,7 +1356,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
     p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
     p.rcp_wm1 = 1.0f / p.wm1; p.rcp_hm1 = 1.0f / p.hm1;
-    p.lds_bytes = kLdsBytes;
+    p.lds_bytes = kLdsBytes; p.shear = g_warp_shear;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
     // LDS-staged fast path: <= 3 channels, rows that are whole 16-byte groups, 16-byte aligned planes

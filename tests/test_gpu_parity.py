@@ -84,6 +84,53 @@ def test_cpu_tensors_are_staged_through_the_gpu(dev):
 
 
 # ------------------------------------------------------------------------------------------------
+# y-sheared staging boxes (flows with a strong dv/dx): shear on == shear off == generic kernel == oracle, bit for bit
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 3, 160, 256), (2, 2, 96, 384), (1, 1, 70, 132)])
+@pytest.mark.parametrize("slope", [0.3, -0.8, 2.5, -7.0])
+def test_sheared_boxes_agree(shape, slope, dev):
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(3)
+    xs = torch.arange(w, dtype=torch.float32)[None, None, None, :] - w / 2
+    ys = torch.arange(h, dtype=torch.float32)[None, None, :, None] - h / 2
+    flow = torch.cat([0.15 * ys.expand(n, 1, h, w) + 0.05 * xs, slope * xs.expand(n, 1, h, w) - 0.1 * ys], 1)
+    flow = (flow + torch.randn(n, 2, h, w, generator=g) * 0.4).contiguous().to(dev)
+    src = (torch.rand(n, c, h, w, generator=g) * 200 - 50).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    fmk = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    add = torch.randn(n, c, h, w, generator=g).to(dev)
+    for kw in (dict(src_mask=sm, flow_mask=fmk, want_valid=True),
+               dict(flow_sign=-1.0, src_mask=sm, want_valid=True, addend=add, a_sign=1.0, g_sign=1.0)):
+        outs = []
+        for path, shear in ((0, True), (0, False), (1, True)):
+            _native.set_warp_path(path)
+            _native.set_warp_shear(shear)
+            try:
+                outs.append(_native.warp_bwd(flow, src, **kw))
+            finally:
+                _native.set_warp_path(0)
+                _native.set_warp_shear(True)
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b), "sheared / plain / generic staging differ for %s" % (kw,)
+        f = flow.cpu().numpy() * np.float32(kw.get("flow_sign", 1.0))
+        s = np.concatenate([src.cpu().numpy(), sm.cpu().numpy().astype(np.float32)[:, None]], 1)
+        gref = oracle.G(f, s)
+        exp = gref[:, :c]
+        if "addend" in kw:
+            exp = np.float32(kw["a_sign"]) * add.cpu().numpy() + np.float32(kw["g_sign"]) * exp
+        assert np.array_equal(outs[0][0].cpu().numpy(), exp, equal_nan=True)
+        expv = gref[:, c] > np.float32(0.99999)
+        if "flow_mask" in kw:
+            expv &= fmk.cpu().numpy()
+        assert np.array_equal(outs[0][1].cpu().numpy(), expv)
+
+
+# ------------------------------------------------------------------------------------------------
 # the LDS-staged fast path and the generic direct-gather kernel must agree bit for bit, and both with the oracle
 # ------------------------------------------------------------------------------------------------
 def _smooth(n, h, w, sigma, seed, dev):
