@@ -56,9 +56,6 @@ int ofl_version(void);
  *                          planes; generic direct-gather kernel otherwise -- both restate the same arithmetic),
  *                      1 = generic direct-gather kernel only. */
 #define OFL_OPT_WARP_PATH 1
-/*   OFL_OPT_SPLAT_BINNING: 0 = tiled splat accumulates with LDS float atomics (default), 1 = atomic-free binning variant
- *                          (integer LDS atomics + register sums; tiles it cannot take fall back to the float atomics). */
-#define OFL_OPT_SPLAT_BINNING 2
 /*   OFL_OPT_WARP_SHEAR: 1 = the LDS-staged warp kernel stages a y-sheared box (default), 0 = plain bounding box
  *   (speed only; the results are identical). */
 #define OFL_OPT_WARP_SHEAR 3
@@ -150,14 +147,23 @@ int ofl_splat_finalize_f32(const float* accum,
                            int32_t round_mode, void* stream);
 
 /*
- * Forward splat, single fused call (the fast path of the two passes above, same arguments and arithmetic):
- * destination-tile-owned accumulation in LDS, normalise / masks / un-occlude fill in the same kernel -- no global
- * atomics and no accumulator round trip through HBM.  Needs C <= 3, W % 4 == 0 and 16-byte aligned planes, else it
- * returns OFL_E_UNSUPPORTED and the caller uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
- *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  candidate lists (contents irrelevant on entry)
- *   accum_fallback fp32[N * (1 + C + with_mask_chan) * H * W]      used (and zeroed in-stream) only when the flow is so
- *                  rough that a destination tile has more than 16 candidate source tiles; the atomics path then
- *                  runs inside the same call, decided on the device (no host sync).
+ * Forward splat, single fused call (the fast path of the two passes above, same arguments):
+ * a route kernel sorts every source pixel into the queue of the destination tile(s) it touches; a tile kernel then sums
+ * each destination pixel's contributions in registers, per corner class in raster order of the source pixels and
+ * ((c0 + c1) + c2) + c3 across the classes -- the order of the reference's four scatter_add_ passes and corner sum
+ * (utils.py:1133-1143): results are BIT-IDENTICAL to the reference's (and from run to run), not just within a tolerance.
+ * Normalise / masks / un-occlude fill happen in the same kernel; no float atomics, no accumulator in HBM.
+ * Needs C <= 3, W % 4 == 0, W < 65536, H < 32768 and 16-byte aligned planes, else it returns OFL_E_UNSUPPORTED and the caller
+ * uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
+ *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  queue lengths / offsets + the packed record pool
+ *                  (28 bytes x 1.5 records per pixel; the batch is processed in passes so that it stays under ~1 GiB);
+ *                  contents irrelevant on entry; afterwards workspace[0] = 1 if the launch fell back to the two-pass
+ *                  path, workspace[1] = number of tiles that left the exact path
+ *   accum_fallback fp32[N * (1 + C + with_mask_chan) * H * W]      used (and zeroed in-stream) only when the record pool
+ *                  overflows (> 1.5 records per pixel on average) or a 32 x 16 source tile spreads over > 48 destination
+ *                  tiles; the two-pass global-atomics path then runs inside the same call, decided on the device (no
+ *                  host sync; tolerance instead of bit-exactness).  A fold of the flow (> 12 sources in one corner
+ *                  class of one destination pixel) makes only ITS tile fall back to (LDS) float atomics.
  */
 int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w);
 int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,

@@ -771,18 +771,38 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 
 
 // ------------------------------------------------------------------------------------------------
-// forward splat, tiled fast path (ofl_splat_tiled_f32): destination-tile-owned LDS accumulation, fused finalize
+// forward splat, routed fast path (ofl_splat_tiled_f32): sort by destination tile, then exact per-tile accumulation
 //
-//  bin kernel : one block per 32 x 16 SOURCE tile: end points of its pixels -> bounding box of the destination pixels
-//               it touches -> appends itself to the candidate list of every destination tile under that box
-//               (fixed capacity; an overflow flags the launch for the atomics path).
-//  tile kernel: one block per 32 x 16 DESTINATION tile: zeroes (2 + C) accumulator planes in LDS (10 KB), walks its
-//               candidate source tiles (16-byte loads), adds the corner contributions that fall inside with LDS
-//               float atomics (accumulator de-interleaved by 4 along x -> bank-conflict free), then normalises,
-//               thresholds, un-occludes and stores with 16-byte stores.  No global atomics, no accumulator in HBM.
-// Same arithmetic as the two-pass path (weights, clamps, zero-flow rule, invalid-weight mask channel).
+//  route kernel (run twice: COUNT, then WRITE): one block per 32 x 16 SOURCE tile.  End points of its pixels; every pixel
+//     goes, as a 12-byte record (end point x, y, raster key), to the queue of each DESTINATION tile one of its four
+//     corners falls into (1.1 queues per pixel on smooth flows).  Ranks come from LDS integer atomics per local
+//     destination tile, then ONE global atomic per (source tile, destination tile).  The COUNT run only sizes the
+//     queues; a one-block scan turns the lengths into offsets into one packed record pool; the WRITE run fills it.
+//  tile kernel : one block per 32 x 16 DESTINATION tile.
+//     A  its queue (end point, key, data x data_sign, mask channel: written by the route kernel) -> LDS, 16-byte loads;
+//     B  every (record, corner) with a non-zero weight inside the tile is pushed on the list of its (destination pixel,
+//        corner class): one LDS atomic exchange on the list head;
+//     C  each thread sums the lists of its own 2 destination pixels in registers: per corner class in raster order of
+//        the source pixels (1-2 contributions need no ordering, 3-4 are sorted in registers, up to 12 by repeated
+//        minimum search), then ((c0 + c1) + c2) + c3 -- exactly the order of the reference's four scatter_add_ passes
+//        and its corner sum (utils.py:1133-1143), products rounded before they are added: BIT-IDENTICAL to the
+//        reference, and run to run; normalise, threshold, un-occlude, store.
+//     A queue longer than the LDS records (1024) is processed in 2 or 4 bands of destination rows, each band compacting
+//     the records that touch it.
+//  No float atomics, no accumulator in HBM.
+//  Only a fold of the flow (> 12 sources in one corner class of one destination pixel, or > ~3000 records for one tile)
+//  makes THAT tile fall back to LDS float atomics over the same queue (tolerance instead of bit-exactness for that
+//  tile).  The launch-level two-pass path only runs for input the pool cannot hold (> 1.5 records per pixel on average)
+//  or source tiles that spread over > 48 destination tiles.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSpNT = 128, kSpTW = 32, kSpTH = 16, kSpMaxCand = 16;
+constexpr int kSpNT = 128, kSpTW = 32, kSpTH = 16;
+constexpr int kSpNT2 = 256;       // threads of the tile kernel: 2 destination pixels per thread
+#ifndef OFL_SP_Q
+#define OFL_SP_Q 1024
+#endif
+constexpr int kSpQ = OFL_SP_Q;    // records the tile kernel holds in LDS at a time (1024 measured faster than 768 + one more block per CU)
+constexpr int kSpRouteMax = 48;   // destination tiles one source tile may feed
+constexpr int kSpLong = 12;       // longest list (contributions to one corner class of one destination pixel) summed in raster order
 
 __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-zero -> 0x01
     uint32_t r = 0;
@@ -793,13 +813,15 @@ __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-ze
 
 struct TiledParams {
     SplatParams s;
-    int32_t* counts;       // [n * tiles]
-    int32_t* lists;        // [n * tiles * kSpMaxCand]
-    int32_t* overflow;     // [1]
+    int32_t* counts;       // [n * tiles] queue lengths
+    int32_t* offsets;      // [n * tiles] queue starts in the pool (exclusive scan of counts)
+    int32_t* cursor;       // [n * tiles] fill level during the WRITE run
+    float* pool;           // [3 + C + mask channel][pool_cap]: end point x | end point y | raster key (bits) | data ... | mask channel
+    int64_t pool_cap;
+    int32_t* overflow;     // [4]: launch falls back | tiles that left the exact path | - | -
     int32_t tiles_x, tiles_y;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;
     int64_t total, per_xcd;
-    int32_t binning;       // 1: atomic-free binning first (tiles that overflow it fall back to LDS float atomics)
 };
 
 __device__ __forceinline__ bool sp_decode(const TiledParams& p, int& tx, int& ty, int& n) {
@@ -813,7 +835,7 @@ __device__ __forceinline__ bool sp_decode(const TiledParams& p, int& tx, int& ty
     return true;
 }
 
-// end point + contribution test of the 4 source pixels of this thread (shared by both kernels)
+// end point + contribution test of the 4 source pixels of a thread
 struct SpSrc { float x[4], y[4]; bool on[4]; bool zero[4]; bool wm[4]; };
 
 __device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4, int sy, bool inimg, uint32_t pix, uint32_t hw, SpSrc& q) {
@@ -844,8 +866,11 @@ __device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4
     }
 }
 
-__global__ __launch_bounds__(kSpNT) void splat_bin_kernel(const TiledParams p) {
+template <bool WRITE>
+__global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p) {
     __shared__ int red[kSpNT / 64][4];
+    __shared__ int lcount[kSpRouteMax], lbase[kSpRouteMax];
+    if (WRITE && *p.overflow != 0) return;
     int tx, ty, n;
     if (!sp_decode(p, tx, ty, n)) return;
     const SplatParams& s = p.s;
@@ -856,77 +881,405 @@ __global__ __launch_bounds__(kSpNT) void splat_bin_kernel(const TiledParams p) {
     const bool inimg = (sx4 < w) && (sy < h);
     SpSrc q;
     sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
+    if (tid < kSpRouteMax) lcount[tid] = 0;
+    // destination tile columns / rows of the (at most two) in-image corner columns / rows of every pixel; -1: none
+    int tca[4], tcb[4], tra[4], trb[4];
     int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
     const float wf = (float)w, hf = (float)h;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        tca[k] = tcb[k] = tra[k] = trb[k] = -1;
         if (q.on[k]) {
-            // destination columns floor(x), floor(x)+1 (clamped corners carry weight 0: the box is clipped below)
+            // a corner outside the image is clamped by the reference and carries weight 0 (utils.py:1106-1111)
             const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf), y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf);
-            minx = min(minx, x0); maxx = max(maxx, x0 + 1); miny = min(miny, y0); maxy = max(maxy, y0 + 1);
+            if ((uint32_t)x0 < (uint32_t)w) tca[k] = x0 / kSpTW;
+            if ((uint32_t)(x0 + 1) < (uint32_t)w) tcb[k] = (x0 + 1) / kSpTW;
+            if ((uint32_t)y0 < (uint32_t)h) tra[k] = y0 / kSpTH;
+            if ((uint32_t)(y0 + 1) < (uint32_t)h) trb[k] = (y0 + 1) / kSpTH;
+            if (tcb[k] == tca[k]) tcb[k] = -1;
+            if (trb[k] == tra[k]) trb[k] = -1;
+            if (tca[k] < 0) { tca[k] = tcb[k]; tcb[k] = -1; }
+            if (tra[k] < 0) { tra[k] = trb[k]; trb[k] = -1; }
+            if (tca[k] >= 0 && tra[k] >= 0) {
+                minx = min(minx, tca[k]); maxx = max(maxx, max(tca[k], tcb[k]));
+                miny = min(miny, tra[k]); maxy = max(maxy, max(tra[k], trb[k]));
+            }
         }
     }
     minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
     if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
     __syncthreads();
-    if (tid != 0) return;
+#pragma unroll
     for (int i = 0; i < kSpNT / 64; ++i) {
         minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
     }
-    minx = max(minx, 0); maxx = min(maxx, w - 1); miny = max(miny, 0); maxy = min(maxy, h - 1);
-    if (maxx < minx || maxy < miny) return;       // nothing of this tile lands inside the image
-    const int tx0 = minx / kSpTW, tx1 = maxx / kSpTW, ty0 = miny / kSpTH, ty1 = maxy / kSpTH;
-    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 64) { atomicOr(p.overflow, 1); return; }
-    const int me = ty * p.tiles_x + tx;
-    for (int dy = ty0; dy <= ty1; ++dy)
-        for (int dx = tx0; dx <= tx1; ++dx) {
-            const int64_t d = (int64_t)n * p.tiles_img + dy * p.tiles_x + dx;
-            const int slot = atomicAdd(&p.counts[d], 1);
-            if (slot < kSpMaxCand) p.lists[d * kSpMaxCand + slot] = me;
-            else atomicOr(p.overflow, 1);
+    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx);
+    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
+    if (maxx < minx || maxy < miny) return;                      // nothing of this tile lands inside the image
+    const int ntx = maxx - minx + 1, nt = ntx * (maxy - miny + 1);
+    if (nt > kSpRouteMax) { if (tid == 0) atomicOr(p.overflow, 1); return; }
+    // local rank of every (pixel, destination tile) pair: LDS atomics; packed (local tile << 12 | rank), ~0 = none
+    uint32_t pr[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tc = (j & 1) ? tcb[k] : tca[k], tr = (j & 2) ? trb[k] : tra[k];
+            pr[k][j] = 0xffffffffu;
+            if (tc >= 0 && tr >= 0) {
+                const int lt = (tr - miny) * ntx + (tc - minx);
+                pr[k][j] = ((uint32_t)lt << 12) | (uint32_t)atomicAdd(&lcount[lt], 1);
+            }
         }
+    }
+    __syncthreads();
+    if (tid < nt && lcount[tid]) {
+        const int64_t d = (int64_t)n * p.tiles_img + (miny + tid / ntx) * p.tiles_x + (minx + tid % ntx);
+        if (WRITE) lbase[tid] = p.offsets[d] + atomicAdd(&p.cursor[d], lcount[tid]);
+        else atomicAdd(&p.counts[d], lcount[tid]);
+    }
+    if (!WRITE) return;
+    __syncthreads();
+    // the records carry the pixel's data (x data_sign) and mask channel: the tile kernel reads everything coalesced
+    const int nc = s.c;
+    f4 dat[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    uint32_t mc4 = 0x01010101u;
+    if (inimg) {
+        const uint32_t pix = (uint32_t)(sy * w + sx4);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < nc) dat[c] = *reinterpret_cast<const f4*>(s.data + n * s.data_bs + c * hw + pix);
+        if (s.with_mask_chan) {
+            if (s.chan_mask_a) mc4 = nz_bytes(*reinterpret_cast<const uint32_t*>(s.chan_mask_a + n * s.chan_mask_a_bs + pix));
+            if (s.chan_mask_b) mc4 &= nz_bytes(*reinterpret_cast<const uint32_t*>(s.chan_mask_b + n * s.chan_mask_b_bs + pix));
+        }
+    }
+    uint32_t* pk = reinterpret_cast<uint32_t*>(p.pool + 2 * p.pool_cap);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (pr[k][j] != 0xffffffffu) {
+                const int pos = lbase[pr[k][j] >> 12] + (int)(pr[k][j] & 0xfffu);
+                p.pool[pos] = q.x[k]; p.pool[p.pool_cap + pos] = q.y[k];
+                pk[pos] = ((uint32_t)sy << 16) | (uint32_t)(sx4 + k);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < nc) p.pool[(3 + c) * p.pool_cap + pos] = s.data_sign * dat[c][k];
+                if (s.with_mask_chan) p.pool[(3 + nc) * p.pool_cap + pos] = ((mc4 >> (8 * k)) & 1u) ? 1.0f : 0.0f;
+            }
+        }
+    }
 }
 
-constexpr int kSpQueue = 1536;     // source pixels that touch the destination tile (compacted)
-constexpr int kSpBinCap = 12;      // contributions (source pixel, corner) one destination pixel can take on this path
-constexpr int kSpQueue2 = 2048;    // queue of the local atomics path (flushed when full)
+// queue lengths -> queue offsets (exclusive scan, one block, 4096 coalesced elements per step); a pool too small for the
+// records flags the launch
+__global__ __launch_bounds__(1024) void splat_scan_kernel(const TiledParams p) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < p.total; base += 4096) {
+        const int64_t i0 = base + tid * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < p.total) ? ((p.counts[i0 + k] + 3) & ~3) : 0;   // queues start on 16-byte boundaries
+        const int mine = v[0] + v[1] + v[2] + v[3];
+        int inc = mine;                                   // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int i = 0; i < wv; ++i) before += wsum[i];
+        int run = before + inc - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < p.total) p.offsets[i0 + k] = run; run += v[k]; }
+        __syncthreads();
+        if (tid == 1023) carry = run;
+        __syncthreads();
+    }
+    if (tid == 0 && (int64_t)carry > p.pool_cap) atomicOr(p.overflow, 1);
+}
 
+// weights and destination-local corner positions of one end point, exactly as the reference (utils.py:1098-1114)
+__device__ __forceinline__ void sp_corners(float xv, float yv, float wmax, float hmax, int dx0, int dy0,
+                                           float (&wx)[2], float (&wy)[2], int (&ix)[2], int (&iy)[2]) {
+    const float x0 = floorf(xv), y0 = floorf(yv), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
+    const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
+    wx[0] = (x1 - xv) * (x0 == x0s ? 1.0f : 0.0f); wx[1] = (xv - x0) * (x1 == x1s ? 1.0f : 0.0f);
+    wy[0] = (y1 - yv) * (y0 == y0s ? 1.0f : 0.0f); wy[1] = (yv - y0) * (y1 == y1s ? 1.0f : 0.0f);
+    ix[0] = (int)x0s - dx0; ix[1] = (int)x1s - dx0; iy[0] = (int)y0s - dy0; iy[1] = (int)y1s - dy0;
+}
 
-// accumulate queued source pixels with LDS float atomics (dense lanes) -- only for tiles the binning path cannot take
+#ifndef OFL_SP_ABL
+#define OFL_SP_ABL 0   // timing ablations of the tile kernel (tools only): 1 no list building, 2 no list walking, 4 no data columns
+#endif
 template <int NC, bool MCH>
-__device__ __forceinline__ void sp_drain(const TiledParams& p, int n, int dx0, int dy0, const uint32_t* queue, int qlen, float* acc) {
-    constexpr int kPx = kSpTW * kSpTH;
+__global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p) {
+    constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0), NREC = 3 + NCH, kRounds = kSpQ / kSpNT2;
+    constexpr uint32_t kEnd = 0xffffu;
+    // LDS: records [x | y | key | data ... | mask channel][kSpQ] | list heads [kPx][4] | list links [kSpQ][4]
+    // (the float-atomics fallback re-uses heads + links as accumulator planes)
+    __shared__ __attribute__((aligned(16))) unsigned char raw[kSpQ * 4 * NREC + kPx * 4 * 4 + kSpQ * 4 * 2];
+    __shared__ int qcount;
+    static_assert(kPx * 16 + kSpQ * 8 >= (1 + NCH) * kPx * 4, "fallback planes must fit the list area");
+    float* rec = reinterpret_cast<float*>(raw);                       // rec[a * kSpQ + i]
+    const float* rx = rec; const float* ry = rec + kSpQ;
+    const uint32_t* rkey = reinterpret_cast<const uint32_t*>(rec + 2 * kSpQ);
+    const float* rdat = rec + 3 * kSpQ;                               // [NCH][kSpQ]
+    uint32_t* head = reinterpret_cast<uint32_t*>(rec + NREC * kSpQ);  // [kPx][4]: newest record of the list, kEnd = empty
+    uint16_t* link = reinterpret_cast<uint16_t*>(head + kPx * 4);     // [kSpQ][4]: next record of the same list
+    float* acc = reinterpret_cast<float*>(head);                      // fallback: [1 + NCH][kPx]
+    int tx, ty, n;
+    if (!sp_decode(p, tx, ty, n)) return;
     const SplatParams& s = p.s;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
+    const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
     const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
+    const int launch_over = *p.overflow, qlen = p.counts[dtile], qoff = p.offsets[dtile];   // one round trip for the three
+    if (launch_over != 0) return;                                     // this launch takes the global-atomics path instead
+    const float* __restrict__ gq = p.pool + qoff;                     // column a of the queue: gq[a * pool_cap + i], 16-byte aligned
     const float* __restrict__ db = s.data + n * s.data_bs;
-    for (int i = threadIdx.x; i < qlen; i += kSpNT) {
-        const uint32_t rec = queue[i];
-        const int sx = (int)(rec & 0xffffu), sy = (int)(rec >> 16);
-        const uint32_t pix = (uint32_t)(sy * w + sx);
-        float xv, yv;
-        if (s.flow) {
-            xv = s.flow_sign * s.flow[n * s.flow_bs + pix] + (float)sx;
-            yv = s.flow_sign * s.flow[n * s.flow_bs + hw + pix] + (float)sy;
-        } else {
-            xv = s.xs[n * s.xy_bs + pix]; yv = s.ys[n * s.xy_bs + pix];
-        }
-        float dv[NC];
+    const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
+    const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
+    // this thread's 2 destination pixels
+    const int lx = tid & 15, ly = tid >> 4;
+    const int x2 = dx0 + lx * 2, y = dy0 + ly;
+    const bool inimg = (x2 < w) && (y < h);
+    const uint32_t pix = (uint32_t)(min(y, h - 1) * w + min(x2, w - 2));
+    bool fill_ok[2] = {false, false};                    // un-occlude fill candidates (utils.py:1198-1203)
+    if (s.occlude && s.flow && inimg) {
+        const f2 a = *reinterpret_cast<const f2*>(s.flow + n * s.flow_bs + pix), b = *reinterpret_cast<const f2*>(s.flow + n * s.flow_bs + hw + pix);
+        uint32_t wm2 = 0x0101u;
+        if (s.weight_mask) wm2 = *reinterpret_cast<const uint16_t*>(s.weight_mask + n * s.weight_mask_bs + pix);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) dv[c] = s.data_sign * db[c * hw + pix];
-        bool invalid = false;
-        if (MCH) {
-            const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix] != 0 : true;
-            const bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix] != 0 : true;
-            invalid = !(a && b);
+        for (int k = 0; k < 2; ++k)
+            fill_ok[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr) && (((wm2 >> (8 * k)) & 0xffu) != 0u);
+    }
+    // normalise, masks, un-occlude fill, store (tot: density, channels, mask channel)
+    auto finalize = [&](const float (&tot)[2][1 + NCH]) {
+        f2 den2, out[NC], mch2;
+        uint32_t warped2 = 0, valid2 = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float den = tot[k][0];
+            const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
+            const bool warped = den > 0.0f;                            // utils.py:1197
+            const bool fill = fill_ok[k] && !warped;
+            den2[k] = den;
+            warped2 |= (uint32_t)warped << (8 * k);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                out[c][k] = apply_round(fill ? s.data_sign * db[c * hw + pix + k] : tot[k][1 + c] / dcl, s.round_mode);
+            if (MCH) {
+                float mv;
+                if (fill) {
+                    const bool a = cma ? cma[pix + k] != 0 : true, b = cmb ? cmb[pix + k] != 0 : true;
+                    mv = (a && b) ? 1.0f : 0.0f;
+                } else {
+                    mv = tot[k][1 + NC] / dcl;
+                }
+                mch2[k] = mv;
+                valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
+            }
         }
-        const float x0 = floorf(xv), y0 = floorf(yv), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-        const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
-        const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
-        const float wx[2] = {(x1 - xv) * (x0 == x0s ? 1.0f : 0.0f), (xv - x0) * (x1 == x1s ? 1.0f : 0.0f)};
-        const float wy[2] = {(y1 - yv) * (y0 == y0s ? 1.0f : 0.0f), (yv - y0) * (y1 == y1s ? 1.0f : 0.0f)};
-        const int ix[2] = {(int)x0s - dx0, (int)x1s - dx0}, iy[2] = {(int)y0s - dy0, (int)y1s - dy0};
+        float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) *reinterpret_cast<f2*>(dst + c * hw + pix) = out[c];
+        if (s.density) *reinterpret_cast<f2*>(s.density + (int64_t)n * hw + pix) = den2;
+        if (s.warped) *reinterpret_cast<uint16_t*>(s.warped + (int64_t)n * hw + pix) = (uint16_t)warped2;
+        if (MCH && s.valid) *reinterpret_cast<uint16_t*>(s.valid + (int64_t)n * hw + pix) = (uint16_t)valid2;
+        if (MCH && s.mask_chan) *reinterpret_cast<f2*>(s.mask_chan + (int64_t)n * hw + pix) = mch2;
+    };
+    // one record's contribution to a corner class: the corner is not clamped (its weight was non-zero), so the
+    // reference's weight is (x1 - x, x - x0) * 1 (utils.py:1110-1114); product rounded, then added
+    auto add_record = [&](uint32_t i, int kx, int ky, float (&a)[1 + NCH]) {
+        const float xv = rx[i], yv = ry[i];
+        const float x0 = floorf(xv), y0 = floorf(yv);
+        const float wxk = (kx ? xv - x0 : (x0 + 1.0f) - xv) * 1.0f, wyk = (ky ? yv - y0 : (y0 + 1.0f) - yv) * 1.0f;
+        const float wgt = wyk * wxk;
+        a[0] += wgt;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) a[1 + c] += wgt * rdat[c * kSpQ + i];
+    };
+
+    // bands of destination rows: 1 when the whole queue fits the LDS records
+    int nb = 1;
+    if (qlen > kSpQ) {                                    // a band of r rows sees about (r + 1) / 16 of the records
+        nb = 2;
+        if (qlen * (kSpTH / 2 + 1) > (kSpQ - kSpQ / 8) * kSpTH) nb = 4;
+        if (qlen * (kSpTH / 4 + 1) > (kSpQ - kSpQ / 8) * kSpTH) nb = 0;   // a fold: straight to the float atomics
+    }
+    const int rows = nb ? kSpTH / nb : kSpTH;
+    bool over = nb == 0;
+    for (int band = 0; band < nb; ++band) {
+        const int r0 = band * rows, r1 = r0 + rows;
+#pragma unroll
+        for (int i = 0; i < kPx * 4 / kSpNT2; ++i) head[tid + i * kSpNT2] = kEnd;
+        int nrec = qlen;
+        if (nb == 1) {
+            // ---- A (whole queue): coalesced 16-byte copy into LDS (the queue is padded to whole groups of 4 records)
+            static_assert(kSpQ <= kSpNT2 * 4, "one 16-byte group per thread");
+            if (tid * 4 < qlen) {
+#pragma unroll
+                for (int a = 0; a < ((OFL_SP_ABL & 4) ? 3 : NREC); ++a)
+                    *reinterpret_cast<f4*>(rec + a * kSpQ + tid * 4) = *reinterpret_cast<const f4*>(gq + a * p.pool_cap + tid * 4);
+            }
+        } else {
+            // ---- A (band): compact the records with a corner row inside the band
+            if (tid == 0) qcount = 0;
+            __syncthreads();
+            for (int base = 0; base < qlen; base += 2 * kSpNT2) {     // two groups of records in flight
+                float col[2][NREC];
+                bool hit[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = base + u * kSpNT2 + tid;
+                    hit[u] = i < qlen;
+                    if (hit[u]) {
+#pragma unroll
+                        for (int a = 0; a < NREC; ++a) col[u][a] = gq[a * p.pool_cap + i];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (hit[u]) {
+                        const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(col[u][1]), -2.0f, (float)h) - dy0;
+                        hit[u] = (y0 >= r0 - 1) && (y0 < r1);
+                    }
+                    const unsigned long long m = __ballot(hit[u]);
+                    if (m != 0ull) {                             // wave-uniform
+                        int bpos = 0;
+                        if (lane == 0) bpos = atomicAdd(&qcount, __popcll(m));
+                        bpos = __builtin_amdgcn_readfirstlane(bpos);
+                        const int pos = bpos + __popcll(m & ((1ull << lane) - 1ull));
+                        if (hit[u] && pos < kSpQ) {
+#pragma unroll
+                            for (int a = 0; a < NREC; ++a) rec[a * kSpQ + pos] = col[u][a];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            nrec = qcount;
+            if (nrec > kSpQ) { over = true; nrec = 0; }     // block-uniform
+        }
+        __syncthreads();                                     // records and list heads are in place
+        // ---- B: every (record, corner) joins the list of its (destination pixel, corner class)
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int i = tid + r * kSpNT2;
+            if (i < nrec && !(OFL_SP_ABL & 1)) {
+                float wx[2], wy[2]; int ix[2], iy[2];
+                sp_corners(rx[i], ry[i], wmax, hmax, dx0, dy0, wx, wy, ix, iy);
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) {
+                        const int xl = ix[kx], yl = iy[ky];
+                        // a zero weight adds +0 to a non-negative sum: skipping it changes nothing (finite data)
+                        if (wy[ky] * wx[kx] == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || yl < r0 || yl >= r1) continue;
+                        const int cls = ky * 2 + kx;
+                        link[i * 4 + cls] = (uint16_t)atomicExch(&head[(yl * kSpTW + xl) * 4 + cls], (uint32_t)i);
+                    }
+                }
+            }
+        }
+        over = __syncthreads_or((int)over) != 0;
+        if (over) break;
+        // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize
+        // Within a corner class the reference adds the contributions in raster order of the source pixels = ascending
+        // key.  One or two contributions need no ordering (a two-term sum is commutative), three or four are sorted in
+        // registers, up to kSpLong by repeated minimum search; a longer list (a fold of the flow) sends the tile to the
+        // float-atomics fallback.
+        const bool mine = inimg && ly >= r0 && ly < r1;
+        bool toolong = false;
+        float tot[2][1 + NCH];
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int d = ly * kSpTW + lx * 2 + k;
+                const uint4 hd = *reinterpret_cast<const uint4*>(head + d * 4);
+                const uint32_t heads[4] = {hd.x, hd.y, hd.z, hd.w};
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls) {
+                    const int kx = cls & 1, ky = cls >> 1;
+                    float a[1 + NCH];
+#pragma unroll
+                    for (int c = 0; c < 1 + NCH; ++c) a[c] = 0.0f;
+                    const uint32_t e0 = (OFL_SP_ABL & 2) ? kEnd : heads[cls];
+                    if (e0 != kEnd) {
+                        const uint32_t e1 = link[e0 * 4 + cls];
+                        if (e1 == kEnd) {                                  // one contribution (the usual case)
+                            add_record(e0, kx, ky, a);
+                        } else {
+                            const uint32_t e2 = link[e1 * 4 + cls];
+                            if (e2 == kEnd) {                              // two: order-free
+                                add_record(e0, kx, ky, a); add_record(e1, kx, ky, a);
+                            } else {
+                                const uint32_t e3 = link[e2 * 4 + cls];
+                                const uint32_t e4 = e3 == kEnd ? kEnd : (uint32_t)link[e3 * 4 + cls];
+                                if (e4 == kEnd) {                          // three or four: sorting network on the keys
+                                    uint32_t e[4] = {e0, e1, e2, e3};
+                                    uint32_t key[4] = {rkey[e0], rkey[e1], rkey[e2], e3 == kEnd ? 0xffffffffu : rkey[e3 & 1023u]};
+#define OFL_CSWAP(a_, b_) { const bool sw = key[a_] > key[b_]; const uint32_t tk = sw ? key[b_] : key[a_], te = sw ? e[b_] : e[a_]; \
+                            key[b_] = sw ? key[a_] : key[b_]; e[b_] = sw ? e[a_] : e[b_]; key[a_] = tk; e[a_] = te; }
+                                    OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
+#undef OFL_CSWAP
+                                    add_record(e[0], kx, ky, a); add_record(e[1], kx, ky, a); add_record(e[2], kx, ky, a);
+                                    if (e[3] != kEnd) add_record(e[3], kx, ky, a);
+                                } else {                                   // longer: bounded minimum search
+                                    int len = 5;
+                                    for (uint32_t e = link[e4 * 4 + cls]; e != kEnd && len <= kSpLong; e = link[e * 4 + cls]) ++len;
+                                    if (len > kSpLong) {
+                                        toolong = true;
+                                    } else {
+                                        int last = -1;                     // keys are < 2^31 (16-bit rows and columns < 2^15)
+                                        for (int t = 0; t < len; ++t) {
+                                            uint32_t best = kEnd; int bkey = 0x7fffffff;
+                                            for (uint32_t e = e0; e != kEnd; e = link[e * 4 + cls]) {
+                                                const int kk = (int)rkey[e];
+                                                if (kk > last && kk < bkey) { bkey = kk; best = e; }
+                                            }
+                                            add_record(best, kx, ky, a);
+                                            last = bkey;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = cls == 0 ? a[c] : tot[k][c] + a[c];   // ((c0 + c1) + c2) + c3
+                }
+            }
+        }
+        over = __syncthreads_or((int)toolong) != 0;
+        if (over) break;
+        if (mine) finalize(tot);
+        if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
+    }
+    if (!over) return;
+    // ---- fallback for this tile (a band of destination rows that more than kSpQ records touch): LDS float atomics,
+    // records streamed from the queue (plane 0 density, then the data channels; the mask channel accumulates the INVALID
+    // weight so that an all-valid pixel is exactly 1 in any order)
+    if (tid == 0) atomicAdd(&p.overflow[1], 1);                       // statistics: tiles that left the exact path
+    __syncthreads();
+    for (int i = tid; i < (1 + NCH) * kPx; i += kSpNT2) acc[i] = 0.0f;
+    __syncthreads();
+    for (int i = tid; i < qlen; i += kSpNT2) {
+        float dd[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dd[c] = gq[(3 + c) * p.pool_cap + i];
+        const bool invalid = MCH ? (gq[(3 + NC) * p.pool_cap + i] == 0.0f) : false;
+        float wx[2], wy[2]; int ix[2], iy[2];
+        sp_corners(gq[i], gq[p.pool_cap + i], wmax, hmax, dx0, dy0, wx, wy, ix, iy);
 #pragma unroll
         for (int ky = 0; ky < 2; ++ky) {
 #pragma unroll
@@ -934,281 +1287,25 @@ __device__ __forceinline__ void sp_drain(const TiledParams& p, int n, int dx0, i
                 const float wgt = wy[ky] * wx[kx];
                 const int xl = ix[kx], yl = iy[ky];
                 if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
-                const int idx = yl * kSpTW + (xl & 3) * (kSpTW / 4) + (xl >> 2);     // de-interleaved by 4: conflict-free finalize
-                atomicAdd(&acc[idx], wgt);
-#pragma unroll
-                for (int c = 0; c < NC; ++c) atomicAdd(&acc[(1 + c) * kPx + idx], wgt * dv[c]);
-                if (MCH && invalid) atomicAdd(&acc[(1 + NC) * kPx + idx], wgt);
-            }
-        }
-    }
-}
-
-template <int NC, bool MCH>
-__device__ __forceinline__ void splat_tile_atomics(const TiledParams& p, int tx, int ty, int n, int ncand, int64_t dtile,
-                                                unsigned char* raw, int* qcount) {
-    constexpr int kPx = kSpTW * kSpTH;
-    constexpr int NPL = 2 + NC;
-    float* acc = reinterpret_cast<float*>(raw);
-    uint32_t* queue = reinterpret_cast<uint32_t*>(acc + NPL * kPx);
-    const SplatParams& s = p.s;
-    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3, lane = tid & 63;
-    const int w = s.w, h = s.h;
-    const uint32_t hw = (uint32_t)(h * w);
-    const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
-    const float wf = (float)w, hf = (float)h;
-    __syncthreads();
-    for (int i = tid; i < NPL * kPx; i += kSpNT) acc[i] = 0.0f;
-    if (tid == 0) *qcount = 0;
-    __syncthreads();
-    for (int ci = 0; ci < ncand; ++ci) {
-        const int st = p.lists[dtile * kSpMaxCand + ci];
-        const uint32_t sty = fastdiv((uint32_t)st, p.mx_m, p.mx_s), stx = (uint32_t)st - sty * (uint32_t)p.tiles_x;
-        const int sx4 = (int)stx * kSpTW + lx * 4, sy = (int)sty * kSpTH + ly;
-        const bool inimg = (sx4 < w) && (sy < h);
-        SpSrc q;
-        sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
-        if (*qcount > kSpQueue2 - 4 * kSpNT) {            // block-uniform: make room first
-            __syncthreads();
-            sp_drain<NC, MCH>(p, n, dx0, dy0, queue, *qcount, acc);
-            __syncthreads();
-            if (tid == 0) *qcount = 0;
-            __syncthreads();
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bool hit = false;
-            if (q.on[k]) {
-                const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf) - dx0;
-                const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf) - dy0;
-                hit = (x0 >= -1) && (x0 < kSpTW) && (y0 >= -1) && (y0 < kSpTH);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ull) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(qcount, __popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (hit) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)sy << 16) | (uint32_t)(sx4 + k);
-            }
-        }
-        __syncthreads();
-    }
-    sp_drain<NC, MCH>(p, n, dx0, dy0, queue, *qcount, acc);
-    __syncthreads();
-    const int x4 = dx0 + lx * 4, y = dy0 + ly;
-    if (x4 >= w || y >= h) return;
-    const uint32_t pix = (uint32_t)(y * w + x4);
-    bool fill_ok[4] = {false, false, false, false};
-    if (s.occlude && s.flow) {
-        SpSrc own;
-        sp_load_src(s, n, x4, y, true, pix, hw, own);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fill_ok[k] = own.zero[k] && own.wm[k];
-    }
-    const float* __restrict__ db = s.data + n * s.data_bs;
-    f4 den4, out[NC], mch4;
-    uint32_t warped4 = 0, valid4 = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = ly * kSpTW + k * (kSpTW / 4) + lx;
-        const float den = acc[idx];
-        const float dcl = den < kDenMin ? kDenMin : den;
-        const bool warped = den > 0.0f;
-        const bool fill = fill_ok[k] && !warped;
-        den4[k] = den;
-        warped4 |= (uint32_t)warped << (8 * k);
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            out[c][k] = apply_round(fill ? s.data_sign * db[c * hw + pix + k] : acc[(1 + c) * kPx + idx] / dcl, s.round_mode);
-        if (MCH) {
-            float mv;
-            if (fill) {
-                const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix + k] != 0 : true;
-                const bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix + k] != 0 : true;
-                mv = (a && b) ? 1.0f : 0.0f;
-            } else {
-                mv = (den - acc[(1 + NC) * kPx + idx]) / dcl;
-            }
-            mch4[k] = mv;
-            valid4 |= (uint32_t)(mv > kValidThr) << (8 * k);
-        }
-    }
-    float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) *reinterpret_cast<f4*>(dst + c * hw + pix) = out[c];
-    if (s.density) *reinterpret_cast<f4*>(s.density + (int64_t)n * hw + pix) = den4;
-    if (s.warped) *reinterpret_cast<uint32_t*>(s.warped + (int64_t)n * hw + pix) = warped4;
-    if (MCH && s.valid) *reinterpret_cast<uint32_t*>(s.valid + (int64_t)n * hw + pix) = valid4;
-    if (MCH && s.mask_chan) *reinterpret_cast<f4*>(s.mask_chan + (int64_t)n * hw + pix) = mch4;
-}
-
-// The destination tile is accumulated WITHOUT float atomics: the touching source pixels are compacted into a queue,
-// every (source pixel, corner) pair is binned to its destination pixel with one integer LDS atomic, and each thread then
-// sums the bins of its own 4 destination pixels in registers.  A queue or bin overflow (strongly compressive flows)
-// flags the whole launch for the atomics path.
-template <int NC, bool MCH, bool BINNING>
-__global__ __launch_bounds__(kSpNT) void splat_tile_kernel(const TiledParams p) {
-    // LDS carving.  Binning path: qx | qy | qpix | bins | cnt.  Local atomics path (tile overflow): acc planes | queue2.
-    constexpr int kPx = kSpTW * kSpTH;
-    constexpr int kBytesA = kSpQueue * 12 + kPx * kSpBinCap * 2 + kPx * 4;
-    constexpr int kBytesB = (2 + NC) * kPx * 4 + kSpQueue2 * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char raw[(BINNING && kBytesA > kBytesB) ? kBytesA : kBytesB];
-    __shared__ int qcount;
-    float* qx = reinterpret_cast<float*>(raw);
-    float* qy = qx + kSpQueue;
-    uint32_t* qpix = reinterpret_cast<uint32_t*>(qy + kSpQueue);
-    uint16_t* bins = reinterpret_cast<uint16_t*>(qpix + kSpQueue);
-    int* cnt = reinterpret_cast<int*>(bins + kPx * kSpBinCap);
-    if (*p.overflow != 0) return;                               // this launch takes the atomics path instead
-    int tx, ty, n;
-    if (!sp_decode(p, tx, ty, n)) return;
-    const SplatParams& s = p.s;
-    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3, lane = tid & 63;
-    const int w = s.w, h = s.h;
-    const uint32_t hw = (uint32_t)(h * w);
-    const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cnt[tid + i * kSpNT] = 0;
-    if (tid == 0) qcount = 0;
-    const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
-    const int ncand = min(p.counts[dtile], kSpMaxCand);
-    if (!BINNING) {         // default in round 1: LDS float atomics (measured faster than the binning variant below)
-        splat_tile_atomics<NC, MCH>(p, tx, ty, n, ncand, dtile, raw, &qcount);
-        return;
-    }
-    __syncthreads();
-    const float wf = (float)w, hf = (float)h;
-    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
-    // ---- phase A: walk the candidate source tiles (16-byte loads); queue the pixels that touch this tile
-    bool qfull = false;
-    for (int ci = 0; ci < ncand; ++ci) {
-        const int st = p.lists[dtile * kSpMaxCand + ci];
-        const uint32_t sty = fastdiv((uint32_t)st, p.mx_m, p.mx_s), stx = (uint32_t)st - sty * (uint32_t)p.tiles_x;
-        const int sx4 = (int)stx * kSpTW + lx * 4, sy = (int)sty * kSpTH + ly;
-        const bool inimg = (sx4 < w) && (sy < h);
-        SpSrc q;
-        sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bool hit = false;
-            if (q.on[k]) {
-                const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf) - dx0;
-                const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf) - dy0;
-                hit = (x0 >= -1) && (x0 < kSpTW) && (y0 >= -1) && (y0 < kSpTH);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ull) {                             // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&qcount, __popcll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
-                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (hit) {
-                    if (pos < kSpQueue) { qx[pos] = q.x[k]; qy[pos] = q.y[k]; qpix[pos] = ((uint32_t)sy << 16) | (uint32_t)(sx4 + k); }
-                    else qfull = true;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int qlen = min(qcount, kSpQueue);
-    // ---- phase B: bin every (source pixel, corner) that lands inside with a non-zero weight to its destination pixel
-    bool binfull = false;
-    for (int i = tid; i < qlen; i += kSpNT) {
-        const float xv = qx[i], yv = qy[i];
-        const float x0 = floorf(xv), y0 = floorf(yv), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-        const float x0s = fminf(fmaxf(x0, 0.0f), wmax), x1s = fminf(fmaxf(x1, 0.0f), wmax);
-        const float y0s = fminf(fmaxf(y0, 0.0f), hmax), y1s = fminf(fmaxf(y1, 0.0f), hmax);
-        const float wx[2] = {(x1 - xv) * (x0 == x0s ? 1.0f : 0.0f), (xv - x0) * (x1 == x1s ? 1.0f : 0.0f)};
-        const float wy[2] = {(y1 - yv) * (y0 == y0s ? 1.0f : 0.0f), (yv - y0) * (y1 == y1s ? 1.0f : 0.0f)};
-        const int ix[2] = {(int)x0s - dx0, (int)x1s - dx0}, iy[2] = {(int)y0s - dy0, (int)y1s - dy0};
-#pragma unroll
-        for (int ky = 0; ky < 2; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < 2; ++kx) {
-                const int xl = ix[kx], yl = iy[ky];
-                if (wy[ky] * wx[kx] == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
                 const int d = yl * kSpTW + xl;
-                const int slot = atomicAdd(&cnt[d], 1);
-                if (slot < kSpBinCap) bins[d * kSpBinCap + slot] = (uint16_t)((i << 2) | (ky * 2 + kx));
-                else binfull = true;
+                atomicAdd(&acc[d], wgt);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) atomicAdd(&acc[(1 + c) * kPx + d], wgt * dd[c]);
+                if (MCH && invalid) atomicAdd(&acc[(1 + NC) * kPx + d], wgt);
             }
         }
     }
-    if (__syncthreads_or((int)(qfull || binfull))) {     // compressive flow here: this tile re-runs with LDS float atomics
-        splat_tile_atomics<NC, MCH>(p, tx, ty, n, ncand, dtile, raw, &qcount);
-        return;
+    __syncthreads();
+    if (!inimg) return;
+    float tot[2][1 + NCH];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int d = ly * kSpTW + lx * 2 + k;
+#pragma unroll
+        for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
+        if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];          // density - invalid weight
     }
-    // ---- phase C: every thread sums the bins of its own 4 destination pixels in registers, then finalizes them
-    const int x4 = dx0 + lx * 4, y = dy0 + ly;
-    if (x4 >= w || y >= h) return;
-    const uint32_t pix = (uint32_t)(y * w + x4);
-    bool fill_ok[4] = {false, false, false, false};      // un-occlude fill candidates (utils.py:1198-1203)
-    if (s.occlude && s.flow) {
-        SpSrc own;
-        sp_load_src(s, n, x4, y, true, pix, hw, own);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) fill_ok[k] = own.zero[k] && own.wm[k];
-    }
-    const float* __restrict__ db = s.data + n * s.data_bs;
-    const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
-    const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
-    f4 den4, out[NC], mch4;
-    uint32_t warped4 = 0, valid4 = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int d = ly * kSpTW + lx * 4 + k;
-        const int m = min(cnt[d], kSpBinCap);
-        float den = 0.0f, inv = 0.0f, sum[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) sum[c] = 0.0f;
-        for (int j = 0; j < m; ++j) {
-            const uint32_t e = bins[d * kSpBinCap + j];
-            const int i = (int)(e >> 2), kx = (int)(e & 1u), ky = (int)((e >> 1) & 1u);
-            const float xv = qx[i], yv = qy[i];
-            const uint32_t sp = qpix[i];
-            const uint32_t spix = (sp >> 16) * (uint32_t)w + (sp & 0xffffu);
-            // the corner's weight, exactly as in phase B / the reference (utils.py:1106-1114)
-            const float x0 = floorf(xv), y0 = floorf(yv);
-            const float xc = kx ? x0 + 1.0f : x0, yc = ky ? y0 + 1.0f : y0;
-            const float xcs = fminf(fmaxf(xc, 0.0f), wmax), ycs = fminf(fmaxf(yc, 0.0f), hmax);
-            const float wxk = (kx ? xv - x0 : (x0 + 1.0f) - xv) * (xc == xcs ? 1.0f : 0.0f);
-            const float wyk = (ky ? yv - y0 : (y0 + 1.0f) - yv) * (yc == ycs ? 1.0f : 0.0f);
-            const float wgt = wyk * wxk;
-            den += wgt;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) sum[c] += wgt * (s.data_sign * db[c * hw + spix]);
-            if (MCH) {
-                const bool a = cma ? cma[spix] != 0 : true, b = cmb ? cmb[spix] != 0 : true;
-                if (!(a && b)) inv += wgt;
-            }
-        }
-        const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
-        const bool warped = den > 0.0f;                            // utils.py:1197
-        const bool fill = fill_ok[k] && !warped;
-        den4[k] = den;
-        warped4 |= (uint32_t)warped << (8 * k);
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            out[c][k] = apply_round(fill ? s.data_sign * db[c * hw + pix + k] : sum[c] / dcl, s.round_mode);
-        if (MCH) {
-            float mv;
-            if (fill) {
-                const bool a = cma ? cma[pix + k] != 0 : true, b = cmb ? cmb[pix + k] != 0 : true;
-                mv = (a && b) ? 1.0f : 0.0f;
-            } else {
-                mv = (den - inv) / dcl;
-            }
-            mch4[k] = mv;
-            valid4 |= (uint32_t)(mv > kValidThr) << (8 * k);
-        }
-    }
-    float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) *reinterpret_cast<f4*>(dst + c * hw + pix) = out[c];
-    if (s.density) *reinterpret_cast<f4*>(s.density + (int64_t)n * hw + pix) = den4;
-    if (s.warped) *reinterpret_cast<uint32_t*>(s.warped + (int64_t)n * hw + pix) = warped4;
-    if (MCH && s.valid) *reinterpret_cast<uint32_t*>(s.valid + (int64_t)n * hw + pix) = valid4;
-    if (MCH && s.mask_chan) *reinterpret_cast<f4*>(s.mask_chan + (int64_t)n * hw + pix) = mch4;
+    finalize(tot);
 }
 
 // zero the fallback accumulator only when the atomics path will run
@@ -1272,7 +1369,6 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
-int g_splat_binning = 0;   // ofl_set_option(OFL_OPT_SPLAT_BINNING, .): 1 = atomic-free binning variant of the tiled splat
 
 template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
@@ -1308,13 +1404,8 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 
 template <int NC>
 int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
-    if (tp.binning) {
-        if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true, true>), dim3(grid), dim3(kSpNT), 0, st, tp);
-        else hipLaunchKernelGGL((splat_tile_kernel<NC, false, true>), dim3(grid), dim3(kSpNT), 0, st, tp);
-    } else {
-        if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true, false>), dim3(grid), dim3(kSpNT), 0, st, tp);
-        else hipLaunchKernelGGL((splat_tile_kernel<NC, false, false>), dim3(grid), dim3(kSpNT), 0, st, tp);
-    }
+    if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true>), dim3(grid), dim3(kSpNT2), 0, st, tp);
+    else hipLaunchKernelGGL((splat_tile_kernel<NC, false>), dim3(grid), dim3(kSpNT2), 0, st, tp);
     return (int)hipGetLastError();
 }
 
@@ -1329,7 +1420,6 @@ __attribute__((visibility("default"))) int ofl_version(void) { return 11; }
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
-    if (key == OFL_OPT_SPLAT_BINNING && (value == 0 || value == 1)) { g_splat_binning = value; return OFL_OK; }
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     return OFL_E_ARG;
 }
@@ -1466,9 +1556,23 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 }
 
 
+constexpr int kSpRecFloats = 7;   // floats per record: x, y, key, up to 3 data channels, mask channel
+// records the pool of one pass holds: 1.5 per pixel (smooth flows need ~1.1), and the images per pass (<= ~1 GiB)
+static int64_t splat_pool_records(int64_t images, int32_t h, int32_t w) {
+    const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
+    return ((images * h * w * 3 / 2 + 3 * tiles + 255) / 256) * 256;
+}
+static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
+    const int64_t tiles_img = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
+    int64_t c = ((int64_t)1 << 28) / (3 * tiles_img + kSpRecFloats * splat_pool_records(1, h, w));
+    if (c < 1) c = 1;
+    return c < n ? c : n;
+}
+
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w) {
-    const int64_t tiles = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH) * n;
-    return tiles * (1 + kSpMaxCand) + 4;
+    const int64_t tiles_img = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
+    const int64_t chunk = splat_chunk_images(n, h, w);
+    return 8 + 3 * chunk * tiles_img + kSpRecFloats * splat_pool_records(chunk, h, w);
 }
 
 __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
@@ -1488,9 +1592,9 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     int rc = fill_splat(tp.s, flow, flow_bs, data, data_bs, data_sign, weight_mask, weight_mask_bs, chan_mask_a,
                         chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, n, c, h, w, grid_unused);
     if (rc) return rc;
-    // eligibility of the tiled path: <= 3 channels, rows of whole 16-byte groups, aligned planes
-    const bool ok = c <= 3 && w >= 4 && (w % 4) == 0 && aligned_to(data, 16) && aligned_to(dst, 16) && (data_bs % 4) == 0 &&
-                    (!flow || (aligned_to(flow, 16) && (flow_bs % 4) == 0)) &&
+    // eligibility of the routed path: <= 3 channels, rows of whole 16-byte groups, aligned planes, 16-bit coordinates
+    const bool ok = c <= 3 && w >= 4 && (w % 4) == 0 && w < 65536 && h < 32768 && aligned_to(data, 16) && aligned_to(dst, 16) &&
+                    (data_bs % 4) == 0 && (!flow || (aligned_to(flow, 16) && (flow_bs % 4) == 0)) &&
                     (!xs || (aligned_to(xs, 16) && aligned_to(ys, 16) && (xy_bs % 4) == 0)) &&
                     (!weight_mask || (aligned_to(weight_mask, 4) && (weight_mask_bs % 4) == 0)) &&
                     (!chan_mask_a || (aligned_to(chan_mask_a, 4) && (chan_mask_a_bs % 4) == 0)) &&
@@ -1504,31 +1608,56 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     tp.s.round_mode = round_mode;
     tp.tiles_x = (w + kSpTW - 1) / kSpTW; tp.tiles_y = (h + kSpTH - 1) / kSpTH;
     tp.tiles_img = (uint32_t)(tp.tiles_x * tp.tiles_y);
-    tp.total = (int64_t)tp.tiles_img * n;
-    if (tp.total >= (1ll << 31)) return OFL_E_SHAPE;
-    tp.per_xcd = (tp.total + kXcds - 1) / kXcds;
+    if ((int64_t)tp.tiles_img * n >= (1ll << 31)) return OFL_E_SHAPE;
     magic_u32((uint32_t)tp.tiles_x, tp.mx_m, tp.mx_s);
     magic_u32(tp.tiles_img, tp.mi_m, tp.mi_s);
-    tp.binning = g_splat_binning;
-    tp.counts = workspace;
-    tp.lists = workspace + tp.total;
-    tp.overflow = workspace + tp.total * (1 + kSpMaxCand);
+    const int64_t chunk = splat_chunk_images(n, h, w), ctiles = chunk * tp.tiles_img;
+    tp.overflow = workspace;
+    tp.counts = workspace + 4;
+    tp.offsets = tp.counts + ctiles;
+    tp.cursor = tp.offsets + ctiles;
+    tp.pool = reinterpret_cast<float*>(workspace + ((4 + 3 * ctiles + 3) & ~(int64_t)3));   // 16-byte aligned columns
+    tp.pool_cap = splat_pool_records(chunk, h, w);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(tp.counts, 0, (size_t)tp.total * sizeof(int32_t), st);
+    hipError_t e = hipMemsetAsync(tp.overflow, 0, 4 * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(tp.overflow, 0, 4 * sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
-    const unsigned grid = (unsigned)(tp.per_xcd * kXcds);
-    hipLaunchKernelGGL(splat_bin_kernel, dim3(grid), dim3(kSpNT), 0, st, tp);
-    rc = (int)hipGetLastError();
-    if (rc) return rc;
-    switch (c) {
-        case 1: rc = launch_splat_tile<1>(tp, grid, st); break;
-        case 2: rc = launch_splat_tile<2>(tp, grid, st); break;
-        default: rc = launch_splat_tile<3>(tp, grid, st); break;
+    const SplatParams full = tp.s;
+    const int64_t hw = (int64_t)h * w;
+    for (int64_t n0 = 0; n0 < n; n0 += chunk) {          // same stream: the queues of a pass are re-used by the next one
+        const int64_t nn = (n - n0) < chunk ? (n - n0) : chunk;
+        SplatParams& q = tp.s;
+        q = full;
+        q.n = (int32_t)nn;
+        if (q.flow) q.flow = full.flow + n0 * full.flow_bs;
+        if (q.xs) { q.xs = full.xs + n0 * full.xy_bs; q.ys = full.ys + n0 * full.xy_bs; }
+        q.data = full.data + n0 * full.data_bs;
+        if (q.weight_mask) q.weight_mask = full.weight_mask + n0 * full.weight_mask_bs;
+        if (q.chan_mask_a) q.chan_mask_a = full.chan_mask_a + n0 * full.chan_mask_a_bs;
+        if (q.chan_mask_b) q.chan_mask_b = full.chan_mask_b + n0 * full.chan_mask_b_bs;
+        q.dst = full.dst + n0 * c * hw;
+        if (q.density) q.density = full.density + n0 * hw;
+        if (q.warped) q.warped = full.warped + n0 * hw;
+        if (q.valid) q.valid = full.valid + n0 * hw;
+        if (q.mask_chan) q.mask_chan = full.mask_chan + n0 * hw;
+        tp.total = (int64_t)tp.tiles_img * nn;
+        tp.per_xcd = (tp.total + kXcds - 1) / kXcds;
+        e = hipMemsetAsync(tp.counts, 0, (size_t)ctiles * 3 * sizeof(int32_t), st);      // counts | offsets | cursor
+        if (e != hipSuccess) return (int)e;
+        const unsigned grid = (unsigned)(tp.per_xcd * kXcds);
+        hipLaunchKernelGGL(splat_route_kernel<false>, dim3(grid), dim3(kSpNT), 0, st, tp);
+        hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, st, tp);
+        hipLaunchKernelGGL(splat_route_kernel<true>, dim3(grid), dim3(kSpNT), 0, st, tp);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
+        switch (c) {
+            case 1: rc = launch_splat_tile<1>(tp, grid, st); break;
+            case 2: rc = launch_splat_tile<2>(tp, grid, st); break;
+            default: rc = launch_splat_tile<3>(tp, grid, st); break;
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
-    // atomics path, armed only if a candidate list overflowed (rough flows); every kernel below exits at once otherwise
+    tp.s = full;
+    // two-pass global-atomics path, armed only if a queue overflowed (rough flows); every kernel below exits at once otherwise
     SplatParams fb = tp.s;
     fb.accum = accum_fallback;
     fb.run_if_set = tp.overflow;

@@ -4,9 +4,9 @@ C ABI) must reproduce what the reference produced.
 Bars (BASELINE.json north_star):
   * backward-gather ('t') family -- the kernel restates the reference's fp32 operation order, so values AND
     masks are compared BIT-EXACT;
-  * forward-splat ('s') family -- accumulation order differs from the reference's raster order (atomics /
-    LDS), so values are held to rtol 2e-5 / atol 2e-5 * max|expected| and masks must still match bit for bit
-    on these fixtures (the mask channel is order-independent by construction, see ofl_kernels.hip).
+  * forward-splat ('s') family -- the routed kernel (W % 4 == 0, C <= 3: every fixture but two) sums each destination
+    pixel's contributions in the reference's own order, so values AND masks are compared BIT-EXACT as well; the general
+    two-pass path (float atomics) is held to rtol 2e-5 / atol 2e-5 * max|expected| with masks bit for bit.
 """
 import numpy as np
 import pytest
@@ -57,7 +57,11 @@ def test_golden_case_gpu(cid, golden, dev):
     if uses_splat(case):
         _, exp = golden.arrays(case)
         scale = max([float(np.abs(v).max()) for v in exp.values() if v.dtype.kind == 'f' and v.size] + [1.0])
-        case_runner.check_case(case, golden, got, exact_values=False, rtol=2e-5, atol=2e-5 * scale, max_mask_flips=0)
+        widths = {int(v.shape[-1]) for v in exp.values() if v.ndim >= 2}
+        if cid not in ("kats.gfud_rotation",) and all(wd % 4 == 0 for wd in widths):
+            case_runner.check_case(case, golden, got, exact_values=True)      # routed exact path
+        else:
+            case_runner.check_case(case, golden, got, exact_values=False, rtol=2e-5, atol=2e-5 * scale, max_mask_flips=0)
     else:
         case_runner.check_case(case, golden, got, exact_values=True)
 
@@ -218,17 +222,9 @@ def test_exact_division_corner_cases(dev):
 # ------------------------------------------------------------------------------------------------
 # forward splat: the fused tiled kernel vs the two-pass atomics path vs the oracle
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[False, True], ids=["lds-atomics", "binning"])
-def splat_variant(request):
-    from oflibpytorch_amd import _native
-    _native.set_splat_binning(request.param)
-    yield request.param
-    _native.set_splat_binning(False)
-
-
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (3, 3, 130, 260)])
 @pytest.mark.parametrize("sigma", [0.0, 3.0, 60.0])
-def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev, splat_variant):
+def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev):
     from oflibpytorch_amd import _native
     from oracle import oracle
     n, c, h, w = shape
@@ -281,6 +277,41 @@ def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev, splat_varian
             np.testing.assert_allclose(outs[0][2].cpu().numpy(), rden, rtol=3e-5, atol=1e-5)
         if kw.get("want_warped"):
             assert np.array_equal(outs[0][3].cpu().numpy(), rwarped)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 70, 132), (2, 1, 48, 64), (1, 3, 130, 260)])
+@pytest.mark.parametrize("sigma", [0.7, 1.5])
+def test_exact_splat_is_bit_identical_to_the_oracle(shape, sigma, dev):
+    """The exact tile path sums each destination pixel's contributions per corner class in raster order of the sources,
+    then ((c0 + c1) + c2) + c3: the reference's order (utils.py:1133-1143).  No tolerance."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    n, c, h, w = shape
+    flow = _smooth(n, h, w, sigma, 33, dev)
+    flow[0, :, h // 4: h // 2, w // 4: w // 2] = 0
+    g = torch.Generator().manual_seed(10)
+    data = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    wm = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    ca = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    try:
+        for kw in (dict(weight_mask=wm, chan_mask_a=ca, want_mask_chan=True, want_density=True, want_warped=True),
+                   dict(want_density=True), dict(flow_sign=-1.0, data_sign=-1.0, weight_mask=wm, occlude=False, want_density=True)):
+            for rep in range(2):                       # and run to run
+                out = _native.splat_fwd(flow, data, **kw)
+                f = flow.cpu().numpy() * np.float32(kw.get("flow_sign", 1.0))
+                d = data.cpu().numpy() * np.float32(kw.get("data_sign", 1.0))
+                mc = kw["chan_mask_a"].cpu().numpy() if "chan_mask_a" in kw else np.ones((n, h, w), bool)
+                dd = np.concatenate([d, mc[:, None].astype(np.float32)], 1)
+                m = kw["weight_mask"].cpu().numpy() if "weight_mask" in kw else None
+                ref, rwarped, rden = oracle.apply_s_flow(f, dd, m, kw.get("occlude", True), return_density=True)
+                assert np.array_equal(out[0].cpu().numpy(), ref[:, :c]), "values differ from the oracle (%s)" % (kw,)
+                assert np.array_equal(out[2].cpu().numpy(), rden)
+                if kw.get("want_mask_chan"):
+                    assert np.array_equal(out[1].cpu().numpy(), ref[:, c])
+                if kw.get("want_warped"):
+                    assert np.array_equal(out[3].cpu().numpy(), rwarped)
+    finally:
+        pass
 
 
 def test_tiled_splat_explicit_positions(dev):

@@ -49,6 +49,10 @@ def main():
         for mode in (3, 2, 1):
             rows.append(("combine_with mode %d '%s'" % (mode, ref), 27, timeit(lambda: A.combine_with(B, mode), a.iters)))
     print("B=%d %dx%d fp32, %d iters" % (n, h, w, a.iters))
+    from oflibpytorch_amd import _native
+    if _native._last_splat_stats is not None:
+        st = _native._last_splat_stats.cpu().tolist()
+        print("last routed splat: launch-level fallback %d, tiles on the LDS-atomics fallback %d" % (st[0], st[1]))
     for name, bpp, t in rows:
         print("%-28s %8.3f ms  %9.1f Mpix/s  %7.1f GB/s algorithmic (%d B/px)" % (name, t * 1e3, px / t / 1e6, bpp * px / t / 1e9, bpp))
 

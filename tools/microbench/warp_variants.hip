@@ -3931,6 +3931,10 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL((warp_v14<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); check(name); \
         report(name, time_it([&] { hipLaunchKernelGGL((warp_v14<NT, TWQ, ITERS>), dim3(g), dim3(NT), LDSB, 0, pp, LDSB); }, it)); }
     RUN14("v14 128t 32x16 26K", 128, 8, 4, 26624)
+    RUN14("v14 128t 32x16 22K", 128, 8, 4, 22528)
+    RUN14("v14 128t 32x16 20K", 128, 8, 4, 20480)
+    RUN14("v14 128t 32x16 18K", 128, 8, 4, 18432)
+    RUN14("v14 128t 32x16 16K", 128, 8, 4, 16384)
     RUN14("v14 256t 32x32 48K", 256, 8, 4, 49152)
     RUN14("v14 64t 16x16 13K", 64, 4, 4, 13312)
     RUN14("v14 128t 16x32 26K", 128, 4, 4, 26624)
