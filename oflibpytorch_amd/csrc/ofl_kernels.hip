@@ -90,6 +90,7 @@ struct WarpParams {
     int64_t total_tiles, per_xcd;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;   // magic divisors by tiles_x and by tiles per image
     int32_t lds_bytes, shear;
+    int32_t add_is_flow;             // mode 3: the addend is the flow operand itself (same planes): no second fetch
 };
 
 constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
@@ -202,7 +203,7 @@ __device__ __forceinline__ int lds_pitch(int n) {   // smallest P >= n with P % 
 }
 
 struct LdsCoords { float sx[4], sy[4]; };                              // un-normalised sample positions of 4 pixels
-struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits; };   // wave-uniform staging geometry
+struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits, interior; };   // wave-uniform staging geometry (interior: box staged, every tap of every pixel inside the image)
 
 // Y-SHEARED box: a 32-wide tile under a flow with dv/dx != 0 touches a slanted band of source rows, and a plain bounding
 // box wastes the two triangles above and below it.  Chunk column c (4 pixels) of the staged box therefore starts at image
@@ -295,13 +296,18 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
     }
     // touched columns [minx, maxx + 1] clipped to the image; sheared rows [miny, maxy] as they are (a staged row that falls
     // outside the image is skipped and never read back)   (wave-uniform)
-    minx = max(__builtin_amdgcn_readfirstlane(minx), 0); maxx = min(__builtin_amdgcn_readfirstlane(maxx) + 1, w - 1);
+    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx) + 1;
+    const bool xin = (minx >= 0) && (maxx <= w - 1);             // no tap column was clipped
+    minx = max(minx, 0); maxx = min(maxx, w - 1);
     miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
     const bool empty = maxx < minx;
     B.bx0 = minx & ~3; B.miny = miny; B.sq = sq; B.cbase = B.bx0 >> 2;
     const int bw = empty ? 4 : (((maxx + 4) & ~3) - B.bx0);
     B.bh = empty ? 1 : (maxy - miny + 1); B.cw = bw >> 2; B.Pp = lds_pitch(bw); B.nch = B.bh * B.cw;
     B.fits = !empty && (B.bh <= 4096) && (16 * (1 + B.bh * B.Pp) <= p.lds_bytes) && (B.nch <= kLdsIters * kLdsNT);
+    // image rows the box's first and last chunk column cover (the shear is monotonic in the column)
+    const int sa = lds_shear(B.cbase, sq), sb_ = lds_shear(B.cbase + B.cw - 1, sq);
+    B.interior = B.fits && xin && (miny + min(sa, sb_) >= 0) && (maxy + max(sa, sb_) <= h - 1);
 }
 
 // step 3a: issue the staging loads of a tile into registers (nothing waits here)
@@ -349,10 +355,10 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
 }
 
 // step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
-template <int NC, bool VALID>
-__device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
-                                           const float* __restrict__ sb, const uint8_t* __restrict__ sm,
-                                           const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4]) {
+template <int NC, bool VALID, bool INTERIOR>
+__device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw,
+                                                const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+                                                const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4]) {
     const int w = p.w, h = p.h;
     const int cw16 = B.cw * 16, P16 = B.Pp * 16;
     const float wf = (float)w, hf = (float)h;
@@ -361,13 +367,15 @@ __device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
         const float fx = floorf(T.sx[k]), fy = floorf(T.sy[k]);
         const float ww = T.sx[k] - fx, e = 1.0f - ww, nn = T.sy[k] - fy, s = 1.0f - nn;
         const float wg[4] = {s * e, s * ww, nn * e, nn * ww};
-        const int xi = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, wf), yi = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, hf);
+        // interior tile: the clamps are the identity and every tap is valid
+        const int xi = INTERIOR ? (int)fx : (int)__builtin_amdgcn_fmed3f(fx, -2.0f, wf);
+        const int yi = INTERIOR ? (int)fy : (int)__builtin_amdgcn_fmed3f(fy, -2.0f, hf);
         // west column valid <=> 0 <= xi <= w-1 ; east <=> -1 <= xi <= w-2   (rows alike)
-        const bool x0 = (uint32_t)xi < (uint32_t)w, x1 = (uint32_t)(xi + 1) < (uint32_t)w;
-        const bool y0 = (uint32_t)yi < (uint32_t)h, y1 = (uint32_t)(yi + 1) < (uint32_t)h;
+        const bool x0 = INTERIOR || (uint32_t)xi < (uint32_t)w, x1 = INTERIOR || (uint32_t)(xi + 1) < (uint32_t)w;
+        const bool y0 = INTERIOR || (uint32_t)yi < (uint32_t)h, y1 = INTERIOR || (uint32_t)(yi + 1) < (uint32_t)h;
         const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
         f4 tv[4];
-        if (B.fits) {
+        if (INTERIOR || B.fits) {
             const int xl0 = xi - B.bx0, xl1 = xl0 + 1;
             const int cp0 = __mul24(xl0 & 3, cw16) + ((xl0 & ~3) << 2), cp1 = __mul24(xl1 & 3, cw16) + ((xl1 & ~3) << 2);
             const int yr = yi - B.miny;   // row in the sheared box, per tap column
@@ -396,6 +404,14 @@ __device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
         r = __builtin_elementwise_fma(tv[3], (f4){wg[3], wg[3], wg[3], wg[3]}, r);
         outv[k] = r;
     }
+}
+
+template <int NC, bool VALID>
+__device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
+                                           const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+                                           const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4]) {
+    if (B.interior) lds_gather_impl<NC, VALID, true>(p, hw, sb, sm, T, B, smem, outv);
+    else lds_gather_impl<NC, VALID, false>(p, hw, sb, sm, T, B, smem, outv);
 }
 
 // the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
@@ -490,10 +506,11 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
     constexpr bool EARLY = ADD && NC <= 2;
     f4 outv[4], aA[NC], aB[NC];
-    if (EARLY) lds_load_addend<NC>(p, tx, tyA, n, hw, aA);
+    const bool reuse = EARLY && NC == 2 && p.add_is_flow;         // block-uniform
+    if (EARLY) { if (reuse) { aA[0] = uA; aA[NC - 1] = vA; } else lds_load_addend<NC>(p, tx, tyA, n, hw, aA); }
     if (haveB) lds_issue<NC, VALID>(p, sb, sm, hw, BB, S);      // staging loads of B fly while A is gathered and stored
     lds_gather<NC, VALID>(p, hw, sb, sm, TA, BA, smem, outv);
-    if (EARLY && haveB) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
+    if (EARLY && haveB) { if (reuse) { aB[0] = uB; aB[NC - 1] = vB; } else lds_load_addend<NC>(p, tx, tyB, n, hw, aB); }
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyA, n, hw, aA);
     lds_store<NC, VALID, ADD>(p, tx, tyA, n, hw, fmA, outv, aA);
     if (!haveB) return;
@@ -1416,7 +1433,7 @@ int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 11; }
+__attribute__((visibility("default"))) int ofl_version(void) { return 12; }
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -1447,6 +1464,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
     p.rcp_wm1 = 1.0f / p.wm1; p.rcp_hm1 = 1.0f / p.hm1;
     p.lds_bytes = kLdsBytes; p.shear = g_warp_shear;
+    p.add_is_flow = (addend != nullptr && addend == flow && addend_bs == flow_bs && c == 2) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
     // LDS-staged fast path: <= 3 channels, rows that are whole 16-byte groups, 16-byte aligned planes
