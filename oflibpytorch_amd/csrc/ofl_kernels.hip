@@ -167,6 +167,20 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
     return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+// the same for two 16-bit lanes at once (v_pk_min_i16 / v_pk_max_i16): (x, y) boxes reduce in half the instructions
+typedef short s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pk_min16(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b))); }
+__device__ __forceinline__ int pk_max16(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b))); }
+__device__ __forceinline__ int wave_pk_min_dpp(int v) {
+    v = pk_min16(v, OFL_DPP(v, 0xB1)); v = pk_min16(v, OFL_DPP(v, 0x4E)); v = pk_min16(v, OFL_DPP(v, 0x141)); v = pk_min16(v, OFL_DPP(v, 0x140));
+    return pk_min16(pk_min16(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                    pk_min16(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_pk_max_dpp(int v) {
+    v = pk_max16(v, OFL_DPP(v, 0xB1)); v = pk_max16(v, OFL_DPP(v, 0x4E)); v = pk_max16(v, OFL_DPP(v, 0x141)); v = pk_max16(v, OFL_DPP(v, 0x140));
+    return pk_max16(pk_max16(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+                    pk_max16(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 __device__ __forceinline__ int wave_max_dpp(int v) {
     v = max(v, OFL_DPP(v, 0xB1));
     v = max(v, OFL_DPP(v, 0x4E));
@@ -252,8 +266,8 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
                                 fmaxf(fmaxf(fabsf(ay[0].x), fabsf(ay[0].y)), fmaxf(fabsf(ay[1].x), fabsf(ay[1].y))));
         bool bad = !(big <= 0x1p100f);
         // a tiny non-zero operand needs |x - u| < 2^-61 with integer x >= 0: only column 0 / row 0 can produce one
-        if (xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
-        if (yc == 0) {
+        if (tx == 0 && xc == 0) bad |= (fabsf(ax[0].x) < 0x1p-60f) && (ax[0].x != 0.0f);
+        if (ty == 0 && yc == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) bad |= (fabsf(ay[k >> 1][k & 1]) < 0x1p-60f) && (ay[k >> 1][k & 1] != 0.0f);
         }
@@ -284,16 +298,16 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
             miny = min(miny, yi - max(s0, s1)); maxy = max(maxy, yi + 1 - min(s0, s1));
         }
     }
-    minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
+    // block-wide box: columns and (sheared) rows fit 16 bits (checked on the host), so (x, y) pairs reduce together
+    int lo = (int)(((uint32_t)minx & 0xffffu) | ((uint32_t)miny << 16)), hi = (int)(((uint32_t)maxx & 0xffffu) | ((uint32_t)maxy << 16));
+    lo = wave_pk_min_dpp(lo); hi = wave_pk_max_dpp(hi);
     if (NW > 1) {
-        if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
+        if ((tid & 63) == 0) { red[tid >> 6][0] = lo; red[tid >> 6][1] = hi; }
         lds_barrier();
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]);
-            miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
-        }
+        for (int i = 0; i < NW; ++i) { lo = pk_min16(lo, red[i][0]); hi = pk_max16(hi, red[i][1]); }
     }
+    minx = (int)(short)(lo & 0xffff); miny = lo >> 16; maxx = (int)(short)(hi & 0xffff); maxy = hi >> 16;
     // touched columns [minx, maxx + 1] clipped to the image; sheared rows [miny, maxy] as they are (a staged row that falls
     // outside the image is skipped and never read back)   (wave-uniform)
     minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx) + 1;
@@ -347,7 +361,7 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
                 f4 sl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < NC; ++c) sl[c] = S.q[it][c][k];
-                if (VALID) sl[3] = (float)(((S.mq[it] >> (8 * k)) & 0xffu) != 0u);
+                if (VALID) sl[3] = fminf((float)((S.mq[it] >> (8 * k)) & 0xffu), 1.0f);   // non-zero byte -> 1 (v_cvt_f32_ubyteK + v_min)
                 lds[S.slot[it] + k * B.cw] = sl;
             }
         }
@@ -1463,12 +1477,13 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
     p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
     p.rcp_wm1 = 1.0f / p.wm1; p.rcp_hm1 = 1.0f / p.hm1;
-    p.lds_bytes = kLdsBytes; p.shear = g_warp_shear;
+    p.lds_bytes = kLdsBytes;
+    p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;   // sheared rows stay within 16 bits (|slope| <= 16 rows per chunk column)
     p.add_is_flow = (addend != nullptr && addend == flow && addend_bs == flow_bs && c == 2) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
     // LDS-staged fast path: <= 3 channels, rows that are whole 16-byte groups, 16-byte aligned planes
-    const bool lds_ok = g_warp_path != 1 && c <= 3 && w >= 4 && (w % 4) == 0 && h >= 2 &&
+    const bool lds_ok = g_warp_path != 1 && c <= 3 && w >= 4 && (w % 4) == 0 && h >= 2 && w < 32760 && h < 32760 &&
                         aligned_to(flow, 16) && aligned_to(src, 16) && aligned_to(dst, 16) && (flow_bs % 4) == 0 &&
                         (src_bs % 4) == 0 && (!addend || (aligned_to(addend, 16) && (addend_bs % 4) == 0)) &&
                         (!src_mask || (aligned_to(src_mask, 4) && (src_mask_bs % 4) == 0)) &&
