@@ -1349,6 +1349,7 @@ __global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ pt
 // ------------------------------------------------------------------------------------------------
 // flow flags (ofl_flow_flags_f32)
 // ------------------------------------------------------------------------------------------------
+template <bool VEC>   // VEC: 4 pixels per thread and step (16-byte flow loads, one mask dword); needs hw % 4 == 0 and aligned planes
 __global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict__ flow, int64_t flow_bs,
                                                          const uint8_t* __restrict__ mask, int64_t mask_bs,
                                                          int32_t* __restrict__ flags, int64_t hw) {
@@ -1356,8 +1357,31 @@ __global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict
     const float* fu = flow + n * flow_bs;
     const uint8_t* mk = mask ? mask + n * mask_bs : nullptr;
     int f = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x)
-        f |= flag_bits(fu[i], fu[hw + i], mk ? (mk[i] != 0) : true);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC) {
+        const int64_t hw4 = hw >> 2;
+        for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < hw4; i0 += 4 * stride) {
+            f4 a[4], b[4]; uint32_t m4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                         // four independent 16-byte groups in flight
+                const int64_t i = i0 + r * stride;
+                if (i < hw4) {
+                    a[r] = reinterpret_cast<const f4*>(fu)[i]; b[r] = reinterpret_cast<const f4*>(fu + hw)[i];
+                    m4[r] = mk ? reinterpret_cast<const uint32_t*>(mk)[i] : 0x01010101u;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (i0 + r * stride < hw4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) f |= flag_bits(a[r][k], b[r][k], ((m4[r] >> (8 * k)) & 0xffu) != 0u);
+                }
+            }
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += stride)
+            f |= flag_bits(fu[i], fu[hw + i], mk ? (mk[i] != 0) : true);
+    }
     f = wave_or_flags(f);
     if ((threadIdx.x & 63) == 0 && f) atomicOr(&flags[n], f);
 }
@@ -1415,6 +1439,20 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
 }
 
 inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+
+void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, int64_t mask_bs, int32_t* flags, int32_t n,
+                       int64_t hw, hipStream_t st) {
+    const bool vec = (hw % 4) == 0 && aligned_to(flow, 16) && (flow_bs % 4) == 0 && (!mask || (aligned_to(mask, 4) && (mask_bs % 4) == 0));
+    if (vec) {
+        int64_t bx = (hw / 4 + 1023) / 1024;               // 4 groups of 4 pixels per thread and step
+        if (bx > 256) bx = 256;
+        hipLaunchKernelGGL(flow_flags_kernel<true>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw);
+    } else {
+        int64_t bx = (hw + 255) / 256;
+        if (bx > 512) bx = 512;
+        hipLaunchKernelGGL(flow_flags_kernel<false>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw);
+    }
+}
 
 template <int CT>
 int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
@@ -1492,10 +1530,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     if (lds_ok) {
         if (src_flags) {   // the staged path never reads `src` at its own pixel: a separate reduction supplies its flags
             const int64_t hw = (int64_t)h * w;
-            int64_t bx = (hw + 255) / 256;
-            if (bx > 512) bx = 512;
-            hipLaunchKernelGGL(flow_flags_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, src, src_bs, src_mask,
-                               src_mask_bs, src_flags, hw);
+            launch_flow_flags(src, src_bs, src_mask, src_mask_bs, src_flags, n, hw, st);
             p.src_flags = nullptr;
         }
         const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
@@ -1718,11 +1753,7 @@ __attribute__((visibility("default"))) int ofl_flow_flags_f32(const float* flow,
     int rc = check_dims(n, 2, h, w);
     if (rc) return rc;
     if (thr != kZeroThr) return OFL_E_ARG;  // the reference's DEFAULT_THRESHOLD is the only value on the path
-    const int64_t hw = (int64_t)h * w;
-    int64_t bx = (hw + 255) / 256;
-    if (bx > 512) bx = 512;
-    hipLaunchKernelGGL(flow_flags_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, flow,
-                       flow_bs, mask, mask_bs, flags, hw);
+    launch_flow_flags(flow, flow_bs, mask, mask_bs, flags, n, (int64_t)h * w, (hipStream_t)stream);
     return (int)hipGetLastError();
 }
 
