@@ -59,6 +59,9 @@ int ofl_version(void);
 /*   OFL_OPT_WARP_SHEAR: 1 = the LDS-staged warp kernel stages a y-sheared box (default), 0 = plain bounding box
  *   (speed only; the results are identical). */
 #define OFL_OPT_WARP_SHEAR 3
+/*   OFL_OPT_SPLAT_PASS_IMAGES: upper bound on the images ofl_splat_tiled_f32 handles per pass (0 = as many as keep the
+ *   record queues under ~1 GiB; tests use small values to exercise the multi-pass code on small inputs). */
+#define OFL_OPT_SPLAT_PASS_IMAGES 4
 int ofl_set_option(int32_t key, int32_t value);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,
@@ -159,13 +162,15 @@ int ofl_splat_finalize_f32(const float* accum,
  *                  (28 bytes x 1.5 records per pixel; the batch is processed in passes so that it stays under ~1 GiB);
  *                  contents irrelevant on entry; afterwards workspace[0] = 1 if the launch fell back to the two-pass
  *                  path, workspace[1] = number of tiles that left the exact path
- *   accum_fallback fp32[N * (1 + C + with_mask_chan) * H * W]      used (and zeroed in-stream) only when the record pool
+ *   accum_fallback fp32[ofl_splat_tiled_pass_images(n, h, w) * (1 + C + with_mask_chan) * H * W]  (one pass of the batch)
+ *                  used (and zeroed in-stream) only when the record pool
  *                  overflows (> 1.5 records per pixel on average) or a 32 x 16 source tile spreads over > 48 destination
  *                  tiles; the two-pass global-atomics path then runs inside the same call, decided on the device (no
  *                  host sync; tolerance instead of bit-exactness).  A fold of the flow (> 12 sources in one corner
  *                  class of one destination pixel) makes only ITS tile fall back to (LDS) float atomics.
  */
 int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w);
+int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w);   /* images handled per pass (<= n) */
 int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
                         const float* xs, const float* ys, int64_t xy_bs,
                         const float* data, int64_t data_bs, float data_sign,

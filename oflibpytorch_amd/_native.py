@@ -18,7 +18,7 @@ FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2,
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
-_SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints",
+_SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32")
 _lib = None
 
@@ -53,11 +53,13 @@ def load_library(path: str = None):
                                            i32, i32, i32, i32, i32, p]
     lib.ofl_flow_flags_f32.argtypes = [p, i64, p, i64, f32, p, i32, i32, i32, p]
     lib.ofl_splat_tiled_workspace_ints.argtypes = [i32, i32, i32]
+    lib.ofl_splat_tiled_pass_images.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                         p, i64, p, i32, i32, i32, i32, i32, p]
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
     lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
+    lib.ofl_splat_tiled_pass_images.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -77,6 +79,11 @@ _last_splat_stats = None   # device int32[4] of the most recent routed splat (te
 def set_warp_shear(on: bool):
     """LDS-staged warp kernel: True = y-sheared staging box (default), False = plain bounding box (speed only)."""
     _check(load_library().ofl_set_option(3, 1 if on else 0), "ofl_set_option")
+
+
+def set_splat_pass_images(k: int):
+    """Routed splat: at most k images per pass (0 = automatic, ~1 GiB of queues); tests use it to force several passes."""
+    _check(load_library().ofl_set_option(4, int(k)), "ofl_set_option")
 
 
 def set_warp_path(mode: int):
@@ -204,7 +211,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     if _splat_path != 1 and c <= 3 and w % 4 == 0 and w >= 4:
         # fused tiled path: LDS accumulation per destination tile; `accum` is only touched if the flow is too rough
         ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
-        accum = torch.empty((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
         rc = lib.ofl_splat_tiled_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
                                      float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
                                      _ptr(dst), _ptr(density), _ptr(warped), _ptr(valid), _ptr(mchan), _ptr(ws),

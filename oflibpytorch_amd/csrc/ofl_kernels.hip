@@ -1424,6 +1424,7 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
+int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = as many as fit ~1 GiB of queues
 
 template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
@@ -1490,6 +1491,7 @@ __attribute__((visibility("default"))) int ofl_version(void) { return 12; }
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
+    if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     return OFL_E_ARG;
 }
 
@@ -1634,8 +1636,11 @@ static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
     const int64_t tiles_img = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
     int64_t c = ((int64_t)1 << 28) / (3 * tiles_img + kSpRecFloats * splat_pool_records(1, h, w));
     if (c < 1) c = 1;
+    if (g_splat_pass_images > 0 && g_splat_pass_images < c) c = g_splat_pass_images;
     return c < n ? c : n;
 }
+
+__attribute__((visibility("default"))) int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w) { return splat_chunk_images(n, h, w); }
 
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w) {
     const int64_t tiles_img = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
@@ -1723,24 +1728,23 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
             default: rc = launch_splat_tile<3>(tp, grid, st); break;
         }
         if (rc) return rc;
-    }
-    tp.s = full;
-    // two-pass global-atomics path, armed only if a queue overflowed (rough flows); every kernel below exits at once otherwise
-    SplatParams fb = tp.s;
-    fb.accum = accum_fallback;
-    fb.run_if_set = tp.overflow;
-    const int planes = 1 + c + (with_mask_chan ? 1 : 0);
-    const int64_t n4 = (int64_t)n * planes * h * w / 4;
-    hipLaunchKernelGGL(zero_if_set_kernel, dim3(2048), dim3(256), 0, st, accum_fallback, n4, tp.overflow);
-    unsigned g2;
-    tile_grid(n, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
-    switch (c) {
-        case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
-                hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
-        case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
-                hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
-        default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
-                 hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
+        // two-pass global-atomics path for this pass's images, armed only if the launch was flagged (pool overflow / a
+        // source tile spread too wide); every kernel below exits at once otherwise
+        SplatParams fb = tp.s;
+        fb.accum = accum_fallback;
+        fb.run_if_set = tp.overflow;
+        const int planes = 1 + c + (with_mask_chan ? 1 : 0);
+        hipLaunchKernelGGL(zero_if_set_kernel, dim3(2048), dim3(256), 0, st, accum_fallback, nn * planes * hw / 4, tp.overflow);
+        unsigned g2;
+        tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
+        switch (c) {
+            case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
+                    hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
+            case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
+                    hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
+            default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
+                     hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
+        }
     }
     return (int)hipGetLastError();
 }

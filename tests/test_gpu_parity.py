@@ -314,6 +314,33 @@ def test_exact_splat_is_bit_identical_to_the_oracle(shape, sigma, dev):
         pass
 
 
+@pytest.mark.parametrize("rough", [False, True])
+def test_routed_splat_in_several_passes(rough, dev):
+    """n = 5 images, at most 2 per pass: the passes re-use the queues; with a rough flow the launch-level two-pass fallback
+    runs per pass.  Same results as one pass / as the two-pass path."""
+    from oflibpytorch_amd import _native
+    n, c, h, w = 5, 3, 160, 320
+    flow = _smooth(n, h, w, 2.0, 77, dev)
+    if rough:
+        flow = flow * 40          # source tiles spread over more than 48 destination tiles: the launch is flagged
+    g = torch.Generator().manual_seed(12)
+    data = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    wm = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    kw = dict(weight_mask=wm, chan_mask_a=wm, want_mask_chan=True, want_density=True, want_warped=True)
+    one = _native.splat_fwd(flow, data, **kw)
+    assert int(_native._last_splat_stats[0].item()) == int(rough)
+    _native.set_splat_pass_images(2)
+    try:
+        many = _native.splat_fwd(flow, data, **kw)
+    finally:
+        _native.set_splat_pass_images(0)
+    for a, b in zip(one, many):
+        if rough and a.dtype != torch.bool:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=3e-5, atol=3e-3)   # float atomics
+        else:
+            assert torch.equal(a, b)
+
+
 def test_tiled_splat_explicit_positions(dev):
     from oflibpytorch_amd import _native
     from oracle import oracle
