@@ -826,10 +826,14 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 //  tile).  The launch-level two-pass path only runs for input the pool cannot hold (> 1.5 records per pixel on average)
 //  or source tiles that spread over > 48 destination tiles.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSpNT = 128, kSpTW = 32, kSpTH = 16;
-constexpr int kSpNT2 = 256;       // threads of the tile kernel: 2 destination pixels per thread
+#ifndef OFL_SP_TH
+#define OFL_SP_TH 16
+#endif
+constexpr int kSpTW = 32, kSpTH = OFL_SP_TH;                 // source and destination tiles
+constexpr int kSpNT = kSpTW * kSpTH / 4;                     // route kernel: 4 source pixels per thread
+constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // tile kernel: 2 destination pixels per thread
 #ifndef OFL_SP_Q
-#define OFL_SP_Q 1024
+#define OFL_SP_Q (64 * OFL_SP_TH)
 #endif
 constexpr int kSpQ = OFL_SP_Q;    // records the tile kernel holds in LDS at a time (1024 measured faster than 768 + one more block per CU)
 constexpr int kSpRouteMax = 48;   // destination tiles one source tile may feed
