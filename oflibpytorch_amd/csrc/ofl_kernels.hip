@@ -116,19 +116,26 @@ __device__ __forceinline__ bool decode_tile(const WarpParams& p, int& tx, int& t
     return true;
 }
 
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+
+// global accesses of the fast paths: 16 / 8 bytes of floats at 4-byte alignment, 4 / 2 mask bytes at any alignment (one
+// instruction each on gfx950), so that image widths need not be multiples of 4
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4u*>(p); }
+__device__ __forceinline__ f2 ld2(const float* p) { return *reinterpret_cast<const f2u*>(p); }
+__device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4u*>(p) = v; }
+__device__ __forceinline__ void st2(float* p, f2 v) { *reinterpret_cast<f2u*>(p) = v; }
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return reinterpret_cast<const U16u*>(p)->v; }
+__device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { reinterpret_cast<U32u*>(p)->v = v; }
+__device__ __forceinline__ void st16(uint8_t* p, uint32_t v) { reinterpret_cast<U16u*>(p)->v = (uint16_t)v; }
+// a 4-pixel group that starts `d` pixels after (width - 4), the last position a whole group fits in a row (widths that are
+// not multiples of 4): read that last whole group and rotate; the pixels past the row end are never used
+__device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2], v[3], v[3]} : d == 2 ? (f4){v[2], v[3], v[3], v[3]} : (f4){v[3], v[3], v[3], v[3]}; }
 
 // ------------------------------------------------------------------------------------------------
 // backward warp, LDS-staged fast path (C <= 3, W % 4 == 0, 16-byte aligned planes)
@@ -342,9 +349,21 @@ __device__ __forceinline__ void lds_issue(const WarpParams& p, const float* __re
             const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h);
             const uint32_t g = on ? (uint32_t)(__mul24(y, p.w) + B.bx0) + c4 * 4u : 0u;
             S.slot[it] = on ? 1 + (int)(__umul24(r, (uint32_t)B.Pp) + c4) : -1;
+            // the last chunk of a row of an image whose width is not a multiple of 4 would read past the row end (and past
+            // the buffer on the last row): fetch the last whole group instead and rotate (block-uniform branch)
+            const int wrem = p.w & 3;
+            const bool edge = wrem != 0 && on && (int)(B.bx0 + (int)c4 * 4) > p.w - 4;
+            const uint32_t ge = edge ? g - (uint32_t)(4 - wrem) : g;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) S.q[it][c] = *reinterpret_cast<const f4*>(sb + c * hw + g);
-            S.mq[it] = (VALID && sm) ? *reinterpret_cast<const uint32_t*>(sm + g) : 0x01010101u;
+            for (int c = 0; c < NC; ++c) S.q[it][c] = ld4(sb + c * hw + ge);
+            S.mq[it] = (VALID && sm) ? ld32(sm + ge) : 0x01010101u;
+            if (wrem != 0) {
+                if (edge) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) S.q[it][c] = rot4(S.q[it][c], 4 - wrem);
+                    S.mq[it] >>= 8 * (4 - wrem);
+                }
+            }
         }
     }
 }
@@ -434,7 +453,7 @@ __device__ __forceinline__ void lds_load_addend(const WarpParams& p, int tx, int
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const uint32_t pix = (uint32_t)(min(ty * kLdsTH + ly, p.h - 1) * p.w + min(tx * (kLdsTWQ * 4) + lx * 4, p.w - 4));
 #pragma unroll
-    for (int c = 0; c < NC; ++c) a[c] = *reinterpret_cast<const f4*>(p.addend + n * p.addend_bs + c * hw + pix);
+    for (int c = 0; c < NC; ++c) a[c] = ld4(p.addend + n * p.addend_bs + c * hw + pix);
 }
 
 // step 4b: valid mask, epilogue (a_sign * addend + g_sign * G, rounding), 16-byte stores
@@ -452,7 +471,7 @@ __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, i
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
-            *reinterpret_cast<uint32_t*>(p.valid + (int64_t)n * hw + pix) = vo;
+            st32(p.valid + (int64_t)n * hw + pix, vo);
         }
         float* __restrict__ db = p.dst + (int64_t)n * NC * hw;
 #pragma unroll
@@ -463,7 +482,7 @@ __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, i
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], p.round_mode);
             }
-            *reinterpret_cast<f4*>(db + c * hw + pix) = o;
+            st4(db + c * hw + pix, o);
         }
     }
 }
@@ -487,12 +506,12 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
     const uint32_t pixA = (uint32_t)(min(tyA * kLdsTH + ly, h - 1) * w + xq);
     const uint32_t pixB = (uint32_t)(min(tyB * kLdsTH + ly, h - 1) * w + xq);
-    const f4 uA = *reinterpret_cast<const f4*>(fu + pixA), vA = *reinterpret_cast<const f4*>(fu + hw + pixA);
-    const f4 uB = *reinterpret_cast<const f4*>(fu + pixB), vB = *reinterpret_cast<const f4*>(fu + hw + pixB);
+    const f4 uA = ld4(fu + pixA), vA = ld4(fu + hw + pixA);
+    const f4 uB = ld4(fu + pixB), vB = ld4(fu + hw + pixB);
     uint32_t fmA = 0x01010101u, fmB = 0x01010101u;
     if ((VALID || p.flow_flags) && fm) {
-        fmA = *reinterpret_cast<const uint32_t*>(fm + pixA);
-        fmB = *reinterpret_cast<const uint32_t*>(fm + pixB);
+        fmA = ld32(fm + pixA);
+        fmB = ld32(fm + pixB);
     }
     if (p.flow_flags) {   // wave-uniform: finiteness / zero tests of the flow operand as a by-product
         int f = 0;
@@ -1526,13 +1545,9 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.add_is_flow = (addend != nullptr && addend == flow && addend_bs == flow_bs && c == 2) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
-    // LDS-staged fast path: <= 3 channels, rows that are whole 16-byte groups, 16-byte aligned planes
-    const bool lds_ok = g_warp_path != 1 && c <= 3 && w >= 4 && (w % 4) == 0 && h >= 2 && w < 32760 && h < 32760 &&
-                        aligned_to(flow, 16) && aligned_to(src, 16) && aligned_to(dst, 16) && (flow_bs % 4) == 0 &&
-                        (src_bs % 4) == 0 && (!addend || (aligned_to(addend, 16) && (addend_bs % 4) == 0)) &&
-                        (!src_mask || (aligned_to(src_mask, 4) && (src_mask_bs % 4) == 0)) &&
-                        (!flow_mask || (aligned_to(flow_mask, 4) && (flow_mask_bs % 4) == 0)) &&
-                        (!valid || aligned_to(valid, 4));
+    // LDS-staged fast path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit box coordinates (any width:
+    // 16-byte accesses at 4-byte alignment, mask bytes at any alignment)
+    const bool lds_ok = g_warp_path != 1 && c <= 3 && w >= 4 && h >= 2 && w < 32760 && h < 32760;
     if (lds_ok) {
         if (src_flags) {   // the staged path never reads `src` at its own pixel: a separate reduction supplies its flags
             const int64_t hw = (int64_t)h * w;

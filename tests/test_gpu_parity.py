@@ -90,7 +90,7 @@ def test_cpu_tensors_are_staged_through_the_gpu(dev):
 # ------------------------------------------------------------------------------------------------
 # y-sheared staging boxes (flows with a strong dv/dx): shear on == shear off == generic kernel == oracle, bit for bit
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1, 3, 160, 256), (2, 2, 96, 384), (1, 1, 70, 132)])
+@pytest.mark.parametrize("shape", [(1, 3, 160, 256), (2, 2, 96, 384), (1, 1, 70, 132), (1, 3, 90, 253), (2, 2, 64, 130)])
 @pytest.mark.parametrize("slope", [0.3, -0.8, 2.5, -7.0])
 def test_sheared_boxes_agree(shape, slope, dev):
     from oflibpytorch_amd import _native
@@ -143,7 +143,8 @@ def _smooth(n, h, w, sigma, seed, dev):
     return torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous().to(dev)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260)])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260),
+                                   (2, 3, 37, 50), (2, 2, 33, 47), (1, 1, 19, 6), (1, 3, 70, 129), (2, 2, 40, 5)])   # widths that are not multiples of 4
 @pytest.mark.parametrize("sigma", [0.0005, 3.0, 40.0])
 def test_lds_and_generic_paths_agree(shape, sigma, dev):
     import sys
