@@ -895,15 +895,22 @@ struct SpSrc { float x[4], y[4]; bool on[4]; bool zero[4]; bool wm[4]; };
 __device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4, int sy, bool inimg, uint32_t pix, uint32_t hw, SpSrc& q) {
     f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     uint32_t wm4 = 0x01010101u;
+    // the last group of a row of an image whose width is not a multiple of 4: fetch the last whole group and rotate
+    const int wrem = s.w & 3;
+    const bool edge = wrem != 0 && inimg && sx4 > s.w - 4;
+    const uint32_t pe = edge ? pix - (uint32_t)(4 - wrem) : pix;
     if (inimg) {
         if (s.flow) {
-            a = *reinterpret_cast<const f4*>(s.flow + n * s.flow_bs + pix);
-            b = *reinterpret_cast<const f4*>(s.flow + n * s.flow_bs + hw + pix);
+            a = ld4(s.flow + n * s.flow_bs + pe);
+            b = ld4(s.flow + n * s.flow_bs + hw + pe);
         } else {
-            a = *reinterpret_cast<const f4*>(s.xs + n * s.xy_bs + pix);
-            b = *reinterpret_cast<const f4*>(s.ys + n * s.xy_bs + pix);
+            a = ld4(s.xs + n * s.xy_bs + pe);
+            b = ld4(s.ys + n * s.xy_bs + pe);
         }
-        if (s.weight_mask) wm4 = *reinterpret_cast<const uint32_t*>(s.weight_mask + n * s.weight_mask_bs + pix);
+        if (s.weight_mask) wm4 = ld32(s.weight_mask + n * s.weight_mask_bs + pe);
+        if (wrem != 0) {
+            if (edge) { a = rot4(a, 4 - wrem); b = rot4(b, 4 - wrem); wm4 >>= 8 * (4 - wrem); }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -916,7 +923,7 @@ __device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4
             q.x[k] = a[k]; q.y[k] = b[k];
         }
         q.wm[k] = ((wm4 >> (8 * k)) & 0xffu) != 0u;
-        q.on[k] = inimg && q.wm[k] && !q.zero[k];
+        q.on[k] = inimg && (sx4 + k < s.w) && q.wm[k] && !q.zero[k];
     }
 }
 
@@ -999,14 +1006,25 @@ __global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p)
     f4 dat[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     uint32_t mc4 = 0x01010101u;
     if (inimg) {
-        const uint32_t pix = (uint32_t)(sy * w + sx4);
+        const int wrem = w & 3;
+        const bool edge = wrem != 0 && sx4 > w - 4;                   // row-end group: last whole group, rotated
+        const uint32_t pix = (uint32_t)(sy * w + sx4) - (edge ? (uint32_t)(4 - wrem) : 0u);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            if (c < nc) dat[c] = *reinterpret_cast<const f4*>(s.data + n * s.data_bs + c * hw + pix);
+            if (c < nc) dat[c] = ld4(s.data + n * s.data_bs + c * hw + pix);
+        uint32_t ma = 0x01010101u, mb = 0x01010101u;
         if (s.with_mask_chan) {
-            if (s.chan_mask_a) mc4 = nz_bytes(*reinterpret_cast<const uint32_t*>(s.chan_mask_a + n * s.chan_mask_a_bs + pix));
-            if (s.chan_mask_b) mc4 &= nz_bytes(*reinterpret_cast<const uint32_t*>(s.chan_mask_b + n * s.chan_mask_b_bs + pix));
+            if (s.chan_mask_a) ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + pix);
+            if (s.chan_mask_b) mb = ld32(s.chan_mask_b + n * s.chan_mask_b_bs + pix);
         }
+        if (wrem != 0) {
+            if (edge) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dat[c] = rot4(dat[c], 4 - wrem);
+                ma >>= 8 * (4 - wrem); mb >>= 8 * (4 - wrem);
+            }
+        }
+        mc4 = nz_bytes(ma) & nz_bytes(mb);
     }
     uint32_t* pk = reinterpret_cast<uint32_t*>(p.pool + 2 * p.pool_cap);
 #pragma unroll
@@ -1104,14 +1122,16 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
     const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
     // this thread's 2 destination pixels
     const int lx = tid & 15, ly = tid >> 4;
-    const int x2 = dx0 + lx * 2, y = dy0 + ly;
-    const bool inimg = (x2 < w) && (y < h);
-    const uint32_t pix = (uint32_t)(min(y, h - 1) * w + min(x2, w - 2));
+    const int x2 = min(dx0 + lx * 2, w - 2), y = dy0 + ly;           // (odd widths: the last pair re-computes pixel w - 2)
+    const int lx2 = x2 - dx0;                                        // tile-local column of the pair (may be lx * 2 - 1)
+    const bool solo = lx2 < 0;                                       // a tile that is one pixel wide: only the pair's second pixel is its own
+    const bool inimg = (dx0 + lx * 2 < w) && (y < h);
+    const uint32_t pix = (uint32_t)(min(y, h - 1) * w + x2);
     bool fill_ok[2] = {false, false};                    // un-occlude fill candidates (utils.py:1198-1203)
     if (s.occlude && s.flow && inimg) {
-        const f2 a = *reinterpret_cast<const f2*>(s.flow + n * s.flow_bs + pix), b = *reinterpret_cast<const f2*>(s.flow + n * s.flow_bs + hw + pix);
+        const f2 a = ld2(s.flow + n * s.flow_bs + pix), b = ld2(s.flow + n * s.flow_bs + hw + pix);
         uint32_t wm2 = 0x0101u;
-        if (s.weight_mask) wm2 = *reinterpret_cast<const uint16_t*>(s.weight_mask + n * s.weight_mask_bs + pix);
+        if (s.weight_mask) wm2 = ld16(s.weight_mask + n * s.weight_mask_bs + pix);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             fill_ok[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr) && (((wm2 >> (8 * k)) & 0xffu) != 0u);
@@ -1144,12 +1164,21 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
             }
         }
         float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
+        if (!solo) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) *reinterpret_cast<f2*>(dst + c * hw + pix) = out[c];
-        if (s.density) *reinterpret_cast<f2*>(s.density + (int64_t)n * hw + pix) = den2;
-        if (s.warped) *reinterpret_cast<uint16_t*>(s.warped + (int64_t)n * hw + pix) = (uint16_t)warped2;
-        if (MCH && s.valid) *reinterpret_cast<uint16_t*>(s.valid + (int64_t)n * hw + pix) = (uint16_t)valid2;
-        if (MCH && s.mask_chan) *reinterpret_cast<f2*>(s.mask_chan + (int64_t)n * hw + pix) = mch2;
+            for (int c = 0; c < NC; ++c) st2(dst + c * hw + pix, out[c]);
+            if (s.density) st2(s.density + (int64_t)n * hw + pix, den2);
+            if (s.warped) st16(s.warped + (int64_t)n * hw + pix, warped2);
+            if (MCH && s.valid) st16(s.valid + (int64_t)n * hw + pix, valid2);
+            if (MCH && s.mask_chan) st2(s.mask_chan + (int64_t)n * hw + pix, mch2);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dst[c * hw + pix + 1] = out[c][1];
+            if (s.density) s.density[(int64_t)n * hw + pix + 1] = den2[1];
+            if (s.warped) s.warped[(int64_t)n * hw + pix + 1] = (uint8_t)(warped2 >> 8);
+            if (MCH && s.valid) s.valid[(int64_t)n * hw + pix + 1] = (uint8_t)(valid2 >> 8);
+            if (MCH && s.mask_chan) s.mask_chan[(int64_t)n * hw + pix + 1] = mch2[1];
+        }
     };
     // one record's contribution to a corner class: the corner is not clamped (its weight was non-zero), so the
     // reference's weight is (x1 - x, x - x0) * 1 (utils.py:1110-1114); product rounded, then added
@@ -1258,7 +1287,7 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
         if (mine) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int d = ly * kSpTW + lx * 2 + k;
+                const int d = ly * kSpTW + max(lx2 + k, 0);                // (solo: pixel 0 is computed twice, its first copy is never stored)
                 const uint4 hd = *reinterpret_cast<const uint4*>(head + d * 4);
                 const uint32_t heads[4] = {hd.x, hd.y, hd.z, hd.w};
 #pragma unroll
@@ -1354,7 +1383,7 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
     float tot[2][1 + NCH];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int d = ly * kSpTW + lx * 2 + k;
+        const int d = ly * kSpTW + max(lx2 + k, 0);
 #pragma unroll
         for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
         if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];          // density - invalid weight
@@ -1684,15 +1713,9 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     int rc = fill_splat(tp.s, flow, flow_bs, data, data_bs, data_sign, weight_mask, weight_mask_bs, chan_mask_a,
                         chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, n, c, h, w, grid_unused);
     if (rc) return rc;
-    // eligibility of the routed path: <= 3 channels, rows of whole 16-byte groups, aligned planes, 16-bit coordinates
-    const bool ok = c <= 3 && w >= 4 && (w % 4) == 0 && w < 65536 && h < 32768 && aligned_to(data, 16) && aligned_to(dst, 16) &&
-                    (data_bs % 4) == 0 && (!flow || (aligned_to(flow, 16) && (flow_bs % 4) == 0)) &&
-                    (!xs || (aligned_to(xs, 16) && aligned_to(ys, 16) && (xy_bs % 4) == 0)) &&
-                    (!weight_mask || (aligned_to(weight_mask, 4) && (weight_mask_bs % 4) == 0)) &&
-                    (!chan_mask_a || (aligned_to(chan_mask_a, 4) && (chan_mask_a_bs % 4) == 0)) &&
-                    (!chan_mask_b || (aligned_to(chan_mask_b, 4) && (chan_mask_b_bs % 4) == 0)) &&
-                    (!density || aligned_to(density, 16)) && (!mask_chan || aligned_to(mask_chan, 16)) &&
-                    (!warped || aligned_to(warped, 4)) && (!valid || aligned_to(valid, 4));
+    // eligibility of the routed path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit coordinates
+    // (any width: 16 / 8-byte accesses at 4-byte alignment, mask bytes at any alignment)
+    const bool ok = c <= 3 && w >= 4 && w < 65536 && h < 32768;
     if (!ok) return OFL_E_UNSUPPORTED;
     if (workspace_ints < ofl_splat_tiled_workspace_ints(n, h, w)) return OFL_E_ARG;
     tp.s.flow_sign = flow_sign; tp.s.xs = xs; tp.s.ys = ys; tp.s.xy_bs = xy_bs;
