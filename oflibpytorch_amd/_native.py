@@ -208,7 +208,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     density = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_density else None
     warped = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_warped else None
     rc = -4
-    if _splat_path != 1 and c <= 3 and w >= 4:
+    if _splat_path != 1 and w >= 4:
         # fused tiled path: LDS accumulation per destination tile; `accum` is only touched if the flow is too rough
         ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
         accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)

@@ -91,6 +91,7 @@ struct WarpParams {
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;   // magic divisors by tiles_x and by tiles per image
     int32_t lds_bytes, shear;
     int32_t add_is_flow;             // mode 3: the addend is the flow operand itself (same planes): no second fetch
+    int64_t dst_bs;                  // LDS path: batch stride of dst (channels of the whole tensor * h * w)
 };
 
 constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
@@ -473,7 +474,7 @@ __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, i
                 vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
             st32(p.valid + (int64_t)n * hw + pix, vo);
         }
-        float* __restrict__ db = p.dst + (int64_t)n * NC * hw;
+        float* __restrict__ db = p.dst + (int64_t)n * p.dst_bs;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
@@ -673,6 +674,7 @@ struct SplatParams {
     int32_t with_mask_chan, occlude;
     float* accum;          // pass 1 out / pass 2 in
     float* dst; float* density; uint8_t* warped; uint8_t* valid; float* mask_chan;   // pass 2 out
+    int64_t dst_bs;        // batch stride of dst (channels of the whole output tensor * h * w)
     int32_t n, c, h, w;
     int32_t round_mode;
     int32_t tiles_x, tiles_y;
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
     const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
     const float* __restrict__ acc = p.accum + (int64_t)n * planes * hw;
-    float* __restrict__ dst = p.dst + (int64_t)n * C * hw;
+    float* __restrict__ dst = p.dst + (int64_t)n * p.dst_bs;
 
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
@@ -1163,7 +1165,7 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
                 valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
             }
         }
-        float* __restrict__ dst = s.dst + (int64_t)n * NC * hw;
+        float* __restrict__ dst = s.dst + (int64_t)n * s.dst_bs;
         if (!solo) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) st2(dst + c * hw + pix, out[c]);
@@ -1392,10 +1394,12 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
 }
 
 // zero the fallback accumulator only when the atomics path will run
-__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t n4, const int32_t* __restrict__ flag) {
+__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t count, const int32_t* __restrict__ flag) {
     if (*flag == 0) return;
+    const int64_t n4 = count >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
         reinterpret_cast<f4*>(ptr)[i] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) ptr[(n4 << 2) + threadIdx.x] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1572,23 +1576,36 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.lds_bytes = kLdsBytes;
     p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;   // sheared rows stay within 16 bits (|slope| <= 16 rows per chunk column)
     p.add_is_flow = (addend != nullptr && addend == flow && addend_bs == flow_bs && c == 2) ? 1 : 0;
+    p.dst_bs = (int64_t)c * h * w;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
     // LDS-staged fast path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit box coordinates (any width:
     // 16-byte accesses at 4-byte alignment, mask bytes at any alignment)
-    const bool lds_ok = g_warp_path != 1 && c <= 3 && w >= 4 && h >= 2 && w < 32760 && h < 32760;
+    const bool lds_ok = g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760;
     if (lds_ok) {
+        const int64_t hw = (int64_t)h * w;
         if (src_flags) {   // the staged path never reads `src` at its own pixel: a separate reduction supplies its flags
-            const int64_t hw = (int64_t)h * w;
             launch_flow_flags(src, src_bs, src_mask, src_mask_bs, src_flags, n, hw, st);
             p.src_flags = nullptr;
         }
         const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
-        switch (c) {
-            case 1: return launch_warp_lds<1>(p, g, st);
-            case 2: return launch_warp_lds<2>(p, g, st);
-            default: return launch_warp_lds<3>(p, g, st);
+        // more than 3 channels: groups of 3 (the staged box holds 3 channels + the mask channel); the valid mask and the
+        // flow flags come out of the first group
+        for (int32_t c0 = 0; c0 < c; c0 += 3) {
+            const int32_t nc = (c - c0) < 3 ? (c - c0) : 3;
+            WarpParams q = p;
+            q.c = nc;
+            q.src = src + c0 * hw; q.dst = dst + c0 * hw;                 // (batch strides stay: planes of one image are contiguous)
+            if (addend) q.addend = addend + c0 * hw;
+            if (c0 > 0) { q.valid = nullptr; q.flow_flags = nullptr; q.src_mask = nullptr; }
+            switch (nc) {
+                case 1: rc = launch_warp_lds<1>(q, g, st); break;
+                case 2: rc = launch_warp_lds<2>(q, g, st); break;
+                default: rc = launch_warp_lds<3>(q, g, st); break;
+            }
+            if (rc) return rc;
         }
+        return OFL_OK;
     }
     const unsigned grid = warp_geometry(p, kTileW, kTileH);
     switch (c) {
@@ -1615,6 +1632,7 @@ static int fill_splat(SplatParams& p, const float* flow, int64_t flow_bs, const 
     p.chan_mask_b = chan_mask_b; p.chan_mask_b_bs = chan_mask_b_bs;
     p.with_mask_chan = with_mask_chan; p.occlude = occlude;
     p.n = n; p.c = c; p.h = h; p.w = w;
+    p.dst_bs = (int64_t)c * h * w;
     tile_grid(n, h, w, p.tiles_x, p.tiles_y, p.total_tiles, p.per_xcd, grid);
     return OFL_OK;
 }
@@ -1715,7 +1733,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     if (rc) return rc;
     // eligibility of the routed path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit coordinates
     // (any width: 16 / 8-byte accesses at 4-byte alignment, mask bytes at any alignment)
-    const bool ok = c <= 3 && w >= 4 && w < 65536 && h < 32768;
+    const bool ok = w >= 4 && w < 65536 && h < 32768;
     if (!ok) return OFL_E_UNSUPPORTED;
     if (workspace_ints < ofl_splat_tiled_workspace_ints(n, h, w)) return OFL_E_ARG;
     tp.s.flow_sign = flow_sign; tp.s.xs = xs; tp.s.ys = ys; tp.s.xy_bs = xy_bs;
@@ -1736,8 +1754,15 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(tp.overflow, 0, 4 * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
-    const SplatParams full = tp.s;
+    const SplatParams all = tp.s;
     const int64_t hw = (int64_t)h * w;
+    // more than 3 channels: groups of 3 (a record holds 3 data channels); density and masks come out of the first group
+    for (int32_t c0 = 0; c0 < c; c0 += 3) {
+    SplatParams full = all;
+    full.c = (c - c0) < 3 ? (c - c0) : 3;
+    full.data = all.data + c0 * hw; full.dst = all.dst + c0 * hw;
+    if (c0 > 0) { full.with_mask_chan = 0; full.density = nullptr; full.warped = nullptr; full.valid = nullptr; full.mask_chan = nullptr; }
+    const int32_t cg = full.c;
     for (int64_t n0 = 0; n0 < n; n0 += chunk) {          // same stream: the queues of a pass are re-used by the next one
         const int64_t nn = (n - n0) < chunk ? (n - n0) : chunk;
         SplatParams& q = tp.s;
@@ -1749,7 +1774,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
         if (q.weight_mask) q.weight_mask = full.weight_mask + n0 * full.weight_mask_bs;
         if (q.chan_mask_a) q.chan_mask_a = full.chan_mask_a + n0 * full.chan_mask_a_bs;
         if (q.chan_mask_b) q.chan_mask_b = full.chan_mask_b + n0 * full.chan_mask_b_bs;
-        q.dst = full.dst + n0 * c * hw;
+        q.dst = full.dst + n0 * all.dst_bs;
         if (q.density) q.density = full.density + n0 * hw;
         if (q.warped) q.warped = full.warped + n0 * hw;
         if (q.valid) q.valid = full.valid + n0 * hw;
@@ -1764,7 +1789,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
         hipLaunchKernelGGL(splat_route_kernel<true>, dim3(grid), dim3(kSpNT), 0, st, tp);
         rc = (int)hipGetLastError();
         if (rc) return rc;
-        switch (c) {
+        switch (cg) {
             case 1: rc = launch_splat_tile<1>(tp, grid, st); break;
             case 2: rc = launch_splat_tile<2>(tp, grid, st); break;
             default: rc = launch_splat_tile<3>(tp, grid, st); break;
@@ -1775,11 +1800,11 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
         SplatParams fb = tp.s;
         fb.accum = accum_fallback;
         fb.run_if_set = tp.overflow;
-        const int planes = 1 + c + (with_mask_chan ? 1 : 0);
-        hipLaunchKernelGGL(zero_if_set_kernel, dim3(2048), dim3(256), 0, st, accum_fallback, nn * planes * hw / 4, tp.overflow);
+        const int planes = 1 + cg + (fb.with_mask_chan ? 1 : 0);
+        hipLaunchKernelGGL(zero_if_set_kernel, dim3(2048), dim3(256), 0, st, accum_fallback, nn * planes * hw, tp.overflow);
         unsigned g2;
         tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
-        switch (c) {
+        switch (cg) {
             case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
                     hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
             case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
@@ -1787,6 +1812,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
             default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
                      hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
         }
+    }
     }
     return (int)hipGetLastError();
 }

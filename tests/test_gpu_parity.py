@@ -144,7 +144,8 @@ def _smooth(n, h, w, sigma, seed, dev):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260),
-                                   (2, 3, 37, 50), (2, 2, 33, 47), (1, 1, 19, 6), (1, 3, 70, 129), (2, 2, 40, 5)])   # widths that are not multiples of 4
+                                   (2, 3, 37, 50), (2, 2, 33, 47), (1, 1, 19, 6), (1, 3, 70, 129), (2, 2, 40, 5),    # widths that are not multiples of 4
+                                   (2, 4, 40, 64), (1, 7, 33, 45), (2, 6, 20, 36)])                               # more than 3 channels: groups of 3
 @pytest.mark.parametrize("sigma", [0.0005, 3.0, 40.0])
 def test_lds_and_generic_paths_agree(shape, sigma, dev):
     import sys
@@ -223,7 +224,7 @@ def test_exact_division_corner_cases(dev):
 # ------------------------------------------------------------------------------------------------
 # forward splat: the fused tiled kernel vs the two-pass atomics path vs the oracle
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (3, 3, 130, 260), (2, 3, 45, 97), (1, 2, 30, 66)])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (3, 3, 130, 260), (2, 3, 45, 97), (1, 2, 30, 66), (2, 5, 40, 52)])
 @pytest.mark.parametrize("sigma", [0.0, 3.0, 60.0])
 def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev):
     from oflibpytorch_amd import _native
@@ -281,7 +282,8 @@ def test_tiled_splat_matches_two_pass_and_oracle(shape, sigma, dev):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 70, 132), (2, 1, 48, 64), (1, 3, 130, 260),
-                                   (2, 3, 37, 50), (1, 2, 33, 47), (2, 1, 40, 65), (1, 3, 70, 129), (1, 3, 20, 5)])   # any width
+                                   (2, 3, 37, 50), (1, 2, 33, 47), (2, 1, 40, 65), (1, 3, 70, 129), (1, 3, 20, 5),    # any width
+                                   (2, 4, 40, 64), (1, 7, 33, 45)])                                                # > 3 channels: groups of 3
 @pytest.mark.parametrize("sigma", [0.7, 1.5])
 def test_exact_splat_is_bit_identical_to_the_oracle(shape, sigma, dev):
     """The exact tile path sums each destination pixel's contributions per corner class in raster order of the sources,
