@@ -858,7 +858,10 @@ constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // tile kernel: 2 d
 #endif
 constexpr int kSpQ = OFL_SP_Q;    // records the tile kernel holds in LDS at a time (1024 measured faster than 768 + one more block per CU)
 constexpr int kSpRouteMax = 48;   // destination tiles one source tile may feed
-constexpr int kSpLong = 12;       // longest list (contributions to one corner class of one destination pixel) summed in raster order
+#ifndef OFL_SP_LONG
+#define OFL_SP_LONG 12
+#endif
+constexpr int kSpLong = OFL_SP_LONG;   // longest list (contributions to one corner class of one destination pixel) summed in raster order
 
 __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-zero -> 0x01
     uint32_t r = 0;
