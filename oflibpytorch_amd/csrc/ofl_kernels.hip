@@ -409,7 +409,7 @@ __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw
         const bool y0 = INTERIOR || (uint32_t)yi < (uint32_t)h, y1 = INTERIOR || (uint32_t)(yi + 1) < (uint32_t)h;
         const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
         f4 tv[4];
-        if (INTERIOR || B.fits) {
+        if (INTERIOR || __builtin_expect(B.fits, 1)) {
             const int xl0 = xi - B.bx0, xl1 = xl0 + 1;
             const int cp0 = __mul24(xl0 & 3, cw16) + ((xl0 & ~3) << 2), cp1 = __mul24(xl1 & 3, cw16) + ((xl1 & ~3) << 2);
             const int yr = yi - B.miny;   // row in the sheared box, per tap column
@@ -417,7 +417,32 @@ __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw
             const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r1 + cp1 : 0, ok[2] ? r0 + P16 + cp0 : 0, ok[3] ? r1 + P16 + cp1 : 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+        } else if (NC == 3) {
+            // box too large for the LDS: gather from global memory, west + east tap of a row in ONE 8-byte load (the pair
+            // starts at the column clamped to [0, w - 2]; each tap picks its element, invalid taps are zeroed)
+            const int xc = min(max(xi, 0), w - 2);
+            const int ew = xi - xc, ee = xi + 1 - xc;                  // element of the pair a valid west / east tap reads
+            const int yr[2] = {min(max(yi, 0), h - 1), min(max(yi + 1, 0), h - 1)};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t og = (uint32_t)(yr[r] * w + xc);
+                f4 tw = {0.f, 0.f, 0.f, 0.f}, te = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const f2 pr = ld2(sb + c * hw + og);
+                    tw[c] = ew == 1 ? pr[1] : pr[0]; te[c] = ee == 1 ? pr[1] : pr[0];
+                }
+                if (VALID) {
+                    const uint32_t m2 = sm ? ld16(sm + og) : 0x0101u;
+                    tw[3] = ((ew == 1 ? m2 >> 8 : m2) & 0xffu) != 0u ? 1.0f : 0.0f;
+                    te[3] = ((ee == 1 ? m2 >> 8 : m2) & 0xffu) != 0u ? 1.0f : 0.0f;
+                }
+                tv[2 * r] = ok[2 * r] ? tw : (f4){0.f, 0.f, 0.f, 0.f};
+                tv[2 * r + 1] = ok[2 * r + 1] ? te : (f4){0.f, 0.f, 0.f, 0.f};
+            }
         } else {
+            // (flows: the pair-load variant above cost the 2-channel kernels 5 % on their staged path -- register
+            // allocation -- so they keep one load per tap)
             const int cx[4] = {xi, xi + 1, xi, xi + 1}, cy[4] = {yi, yi, yi + 1, yi + 1};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
