@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Randomised cross-checks on the GPU (not part of the pytest tiers; run by hand: python tools/fuzz_gpu.py --seconds 120).
+
+  warp : LDS-staged kernel == generic direct-gather kernel, bit for bit (values, valid mask, flag words), over random
+         shapes (any width >= 4, 1-7 channels), flow kinds (smooth, rough, huge, shear, zero), masks, signs, addends,
+         rounding modes, batch broadcasts;
+  splat: routed exact path == CPU oracle bit for bit on fold-free flows, == two-pass path within tolerance otherwise,
+         identical from run to run, masks always identical.
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from oflibpytorch_amd import _native
+from oracle import oracle
+
+
+def rand_flow(rng, g, n, h, w, dev):
+    kind = rng.choice(["smooth", "rough", "huge", "shear", "zero", "const"])
+    if kind == "zero":
+        f = torch.zeros(n, 2, h, w)
+    elif kind == "const":
+        f = torch.zeros(n, 2, h, w) + torch.tensor([rng.uniform(-9, 9), rng.uniform(-9, 9)]).view(1, 2, 1, 1)
+    else:
+        lat = rng.choice([3, 6, 12, 40])
+        sig = {"smooth": rng.uniform(0.2, 3), "rough": rng.uniform(3, 20), "huge": rng.uniform(50, 400), "shear": rng.uniform(0.2, 2)}[kind]
+        lo = torch.randn(n, 2, max(h // lat, 2), max(w // lat, 2), generator=g) * sig
+        f = torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True)
+        if kind == "shear":
+            xs = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w) - w / 2
+            ys = torch.arange(h, dtype=torch.float32).view(1, 1, h, 1) - h / 2
+            f = f + torch.cat([rng.uniform(-1, 1) * ys.expand(n, 1, h, w), rng.uniform(-8, 8) * xs.expand(n, 1, h, w)], 1)
+    return kind, f.contiguous().to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(a.seed)
+    g = torch.Generator().manual_seed(a.seed)
+    t0 = time.time()
+    nw = ns = 0
+    while time.time() - t0 < a.seconds:
+        n, c = int(rng.integers(1, 4)), int(rng.integers(1, 8))
+        h, w = int(rng.integers(2, 180)), int(rng.integers(4, 300))
+        kind, flow = rand_flow(rng, g, n, h, w, dev)
+        src = (torch.rand(n, c, h, w, generator=g) * 300 - 100).to(dev)
+        sm = (torch.rand(n, h, w, generator=g) > rng.uniform(0, 0.4)).to(dev)
+        fm = (torch.rand(n, h, w, generator=g) > rng.uniform(0, 0.4)).to(dev)
+        # ---- warp
+        kw = dict(flow_sign=float(rng.choice([1.0, -1.0])))
+        if rng.random() < 0.7:
+            kw.update(src_mask=sm if rng.random() < 0.7 else None, flow_mask=fm if rng.random() < 0.7 else None, want_valid=True)
+        if rng.random() < 0.4:
+            kw.update(addend=flow if (c == 2 and rng.random() < 0.5) else torch.randn(n, c, h, w, generator=g).to(dev),
+                      a_sign=float(rng.choice([1.0, -1.0])), g_sign=float(rng.choice([1.0, -1.0])))
+        elif rng.random() < 0.3:
+            kw.update(round_mode=int(rng.integers(1, 3)))
+        if rng.random() < 0.3:
+            kw.update(want_flags=True, want_src_flags=(c == 2))
+        outs = []
+        for path in (0, 1):
+            _native.set_warp_path(path)
+            try:
+                outs.append(_native.warp_bwd(flow, src, **kw))
+            finally:
+                _native.set_warp_path(0)
+        for x, y in zip(*outs):
+            assert (x is None) == (y is None)
+            if x is not None and not torch.equal(x, y):
+                bad = (x != y) & ~(torch.isnan(x.float()) & torch.isnan(y.float()))
+                if bad.any():
+                    raise SystemExit("WARP MISMATCH shape %s kind %s kw %s: %d values" % ((n, c, h, w), kind, {k: (v if not torch.is_tensor(v) else 'T') for k, v in kw.items()}, int(bad.sum())))
+        nw += 1
+        # ---- splat
+        data = src
+        skw = dict(weight_mask=sm if rng.random() < 0.6 else None, occlude=bool(rng.random() < 0.6), want_density=True, want_warped=True,
+                   flow_sign=float(rng.choice([1.0, -1.0])), data_sign=float(rng.choice([1.0, -1.0])))
+        if rng.random() < 0.5:
+            skw.update(chan_mask_a=fm, want_mask_chan=True)
+        r1 = _native.splat_fwd(flow, data, **skw)
+        st = _native._last_splat_stats.cpu().tolist()
+        r2 = _native.splat_fwd(flow, data, **skw)
+        _native.set_splat_path(1)
+        try:
+            r3 = _native.splat_fwd(flow, data, **skw)
+        finally:
+            _native.set_splat_path(0)
+        scale = 300.0
+        for x, y, z in zip(r1, r2, r3):
+            if x is None:
+                continue
+            if st[0] == 0 and st[1] == 0:
+                assert torch.equal(x, y), "splat not deterministic %s %s" % ((n, c, h, w), kind)
+            if x.dtype == torch.bool:
+                assert torch.equal(x, z), "splat masks differ between routed and two-pass %s %s" % ((n, c, h, w), kind)
+            else:
+                np.testing.assert_allclose(x.cpu().numpy(), z.cpu().numpy(), rtol=5e-5, atol=5e-5 * scale,
+                                           err_msg="routed vs two-pass %s %s %s" % ((n, c, h, w), kind, st))
+        if st[0] == 0 and st[1] == 0 and n * h * w < 40000:      # exact path everywhere: bit-identical to the oracle
+            f = flow.cpu().numpy() * np.float32(skw["flow_sign"])
+            d = data.cpu().numpy() * np.float32(skw["data_sign"])
+            mc = skw["chan_mask_a"].cpu().numpy() if "chan_mask_a" in skw else np.ones((n, h, w), bool)
+            dd = np.concatenate([d, mc[:, None].astype(np.float32)], 1)
+            m = skw["weight_mask"].cpu().numpy() if skw.get("weight_mask") is not None else None
+            ref, rwarped, rden = oracle.apply_s_flow(f, dd, m, skw["occlude"], return_density=True)
+            if not np.array_equal(r1[0].cpu().numpy(), ref[:, :c]):
+                raise SystemExit("SPLAT NOT EXACT shape %s kind %s" % ((n, c, h, w), kind))
+            assert np.array_equal(r1[2].cpu().numpy(), rden) and np.array_equal(r1[3].cpu().numpy(), rwarped)
+            if "chan_mask_a" in skw:
+                assert np.array_equal(r1[1].cpu().numpy(), ref[:, c])
+        ns += 1
+    print("fuzz ok: %d warp cases, %d splat cases in %.0f s" % (nw, ns, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
