@@ -73,7 +73,8 @@ def set_splat_path(mode: int):
     _splat_path = int(mode)
 
 
-_last_splat_stats = None   # device int32[4] of the most recent routed splat (tests / tools: how exact was it)
+collect_splat_stats = False   # tests / tools set this to read _last_splat_stats after a routed splat
+_last_splat_stats = None      # device int32[4] of the most recent routed splat: how exact was it
 
 
 def set_warp_shear(on: bool):
@@ -218,8 +219,9 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
                                      ws.numel(), _ptr(accum), n, c, h, w, int(round_mode), st)
         if rc not in (0, -4):
             _check(rc, "ofl_splat_tiled_f32")
-        global _last_splat_stats
-        _last_splat_stats = ws[:4]          # [launch fell back to global atomics, tiles that fell back to LDS atomics, -, -]
+        if collect_splat_stats:             # (a copy: a view would keep the whole workspace alive between calls)
+            global _last_splat_stats
+            _last_splat_stats = ws[:4].clone()   # [launch fell back to global atomics, tiles that left the exact path, -, -]
     if rc == -4:   # not eligible (alignment / channels): the general two-pass path
         accum = torch.zeros((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
         _check(lib.ofl_splat_fwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,

@@ -60,6 +60,7 @@ def test_apply_s_full_frame(frames, dev):
     import oflibpytorch_amd as ofl
     from oflibpytorch_amd import _native
     from oracle import oracle
+    _native.collect_splat_stats = True
     t, n = frames
     warped, valid = ofl.Flow(t["fs"], 's', t["m1"]).apply(t["img"], target_mask=t["tm"], return_valid_area=True)
     assert _native._last_splat_stats.cpu().tolist()[:2] == [0, 0]

@@ -323,6 +323,7 @@ def test_routed_splat_in_several_passes(rough, dev):
     """n = 5 images, at most 2 per pass: the passes re-use the queues; with a rough flow the launch-level two-pass fallback
     runs per pass.  Same results as one pass / as the two-pass path."""
     from oflibpytorch_amd import _native
+    _native.collect_splat_stats = True
     n, c, h, w = 5, 3, 160, 320
     flow = _smooth(n, h, w, 2.0, 77, dev)
     if rough:

@@ -50,6 +50,7 @@ def main():
             rows.append(("combine_with mode %d '%s'" % (mode, ref), 27, timeit(lambda: A.combine_with(B, mode), a.iters)))
     print("B=%d %dx%d fp32, %d iters" % (n, h, w, a.iters))
     from oflibpytorch_amd import _native
+_native.collect_splat_stats = True
     if _native._last_splat_stats is not None:
         st = _native._last_splat_stats.cpu().tolist()
         print("last routed splat: launch-level fallback %d, tiles on the LDS-atomics fallback %d" % (st[0], st[1]))

@@ -8,6 +8,7 @@ import torch
 import bench
 import oflibpytorch_amd as ofl
 from oflibpytorch_amd import _native
+_native.collect_splat_stats = True
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)

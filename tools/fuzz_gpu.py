@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from oflibpytorch_amd import _native
+_native.collect_splat_stats = True
 from oracle import oracle
 
 
