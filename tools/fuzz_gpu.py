@@ -43,6 +43,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", action="store_true", help="frames up to 1100 x 2000 (fewer cases)")
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     rng = np.random.default_rng(a.seed)
@@ -51,7 +52,9 @@ def main():
     nw = ns = 0
     while time.time() - t0 < a.seconds:
         n, c = int(rng.integers(1, 4)), int(rng.integers(1, 8))
-        h, w = int(rng.integers(2, 180)), int(rng.integers(4, 300))
+        h, w = (int(rng.integers(200, 1100)), int(rng.integers(300, 2000))) if a.big else (int(rng.integers(2, 180)), int(rng.integers(4, 300)))
+        if a.big:
+            n, c = int(rng.integers(1, 3)), int(rng.integers(1, 5))
         kind, flow = rand_flow(rng, g, n, h, w, dev)
         src = (torch.rand(n, c, h, w, generator=g) * 300 - 100).to(dev)
         sm = (torch.rand(n, h, w, generator=g) > rng.uniform(0, 0.4)).to(dev)
