@@ -160,6 +160,19 @@ def main():
     barrier()
     el2 = time.perf_counter() - t1
 
+    # measured device-copy ceiling: a 1 GiB fp32 copy on the same stream, read + write bytes / time
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+
     if rank == 0:
         if args.traffic_bytes is None and (n, h, w) == (64, 1080, 1920):
             tj = os.path.join(ROOT, "profiles", "r1_traffic.json")      # PMC passes are separate runs (tools/profile_bench.sh)
@@ -187,7 +200,8 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": args.traffic_bytes,
                          "algorithmic_bytes_per_launch": BYTES_APPLY * px,
-                         "avg_launch_ms": round(t_apply, 4)},
+                         "avg_launch_ms": round(t_apply, 4),
+                         "device_copy_GBs": round(copy_gbs, 1), "frac_of_device_copy": round(ach / copy_gbs, 4)},
             "kernels": {"apply_ms": round(t_apply, 4), "apply_GBs": round(ach, 1),
                         "combine3_ms": round(t_comb, 4),
                         "combine3_GBs": round(BYTES_COMBINE * px / (t_comb * 1e-3) / 1e9, 1),
