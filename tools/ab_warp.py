@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--sigma", type=float, default=8.0)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--only", type=int, default=-1, help="run only with shear on (1) or off (0)")
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 n, h, w = args.batch, 1080, 1920
@@ -44,6 +45,8 @@ def set_shear(on):
 
 for rep in range(args.reps):
     for name, fn in (("shear on ", lambda: set_shear(True)), ("shear off", lambda: set_shear(False))):
+        if args.only >= 0 and (name.strip() == "shear on") != bool(args.only):
+            continue
         fn()
         a, c = time_ops()
         px = n * h * w
