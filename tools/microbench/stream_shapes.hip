@@ -125,6 +125,32 @@ __global__ __launch_bounds__(256) void stream_wo(const P p) {
     for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(p.dst + (long)n * 3 * hw + c * hw + pix) = make_float4(1.f, 2.f, 3.f, (float)pix);
 }
 
+
+// reads of the full mix (22 B/px) but only the mask (MODE 1) or the mask + one channel (MODE 2) stored
+template <int TW, int WAVEW, int MODE>
+__global__ __launch_bounds__(256) void stream_partial(const P p) {
+    const long tile = tile_of<0>(p, blockIdx.x);
+    if (tile >= p.total) return;
+    const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, n = tile / ((long)p.tiles_x * p.tiles_y);
+    constexpr int TH = 1024 / TW, WL = WAVEW / 4, WROWS = 64 / WL, WPR = TW / WAVEW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lx = (lane % WL) + (wv % WPR) * WL, ly = (lane / WL) + (wv / WPR) * WROWS;
+    const int w = p.w, h = p.h, hw = h * w;
+    const int x4 = tx * TW + lx * 4, y = ty * TH + ly;
+    if (x4 >= w || y >= h) return;
+    const int pix = y * w + x4;
+    const float4 u = *reinterpret_cast<const float4*>(p.flow + (long)n * 2 * hw + pix);
+    const float4 v = *reinterpret_cast<const float4*>(p.flow + (long)n * 2 * hw + hw + pix);
+    const uchar4 a = *reinterpret_cast<const uchar4*>(p.smask + (long)n * hw + pix);
+    const uchar4 b = *reinterpret_cast<const uchar4*>(p.fmask + (long)n * hw + pix);
+    float4 q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = *reinterpret_cast<const float4*>(p.src + (long)n * 3 * hw + c * hw + pix);
+    const float s = q[0].x + q[1].y + q[2].z + u.x;
+    *reinterpret_cast<uchar4*>(p.valid + (long)n * hw + pix) = make_uchar4(a.x && b.x && (v.x != 12345.f) && (s != 1.2345e-30f), a.y && b.y, a.z && b.z, a.w && b.w);
+    if (MODE == 2) { q[0].x += u.x; *reinterpret_cast<float4*>(p.dst + (long)n * 3 * hw + pix) = q[0]; }
+}
+
 template <typename F>
 static float time_it(F launch, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -179,6 +205,11 @@ int main(int argc, char** argv) {
 #define RUNRO(name, TW, WAVEW) { unsigned g = grid_for(TW, 1024 / TW); \
         report(name " read-only 22 B/px", time_it([&] { hipLaunchKernelGGL((stream_ro<TW, WAVEW>), dim3(g), dim3(256), 0, 0, p); }, it), 22.0); \
         report(name " write-only 13 B/px", time_it([&] { hipLaunchKernelGGL((stream_wo<TW, WAVEW>), dim3(g), dim3(256), 0, 0, p); }, it), 13.0); }
+#define RUNPT(name, TW, WAVEW, MODE, BPP) { unsigned g = grid_for(TW, 1024 / TW); \
+        report(name, time_it([&] { hipLaunchKernelGGL((stream_partial<TW, WAVEW, MODE>), dim3(g), dim3(256), 0, 0, p); }, it), BPP); }
+    RUNPT("tile 32x32: read 22 B/px, store mask only (23 B/px)", 32, 32, 1, 23.0)
+    RUNPT("tile 32x32: read 22 B/px, store mask + 1 channel (27 B/px)", 32, 32, 2, 27.0)
+    RUNPT("tile 128x8: read 22 B/px, store mask only (23 B/px)", 128, 128, 1, 23.0)
     RUNRO("tile 32x32 wave 32x8", 32, 32)
     RUNRO("tile 128x8 wave 128x2", 128, 128)
     return 0;
