@@ -12,6 +12,7 @@
 // C ABI: include/oflib_hip.h (reference call sites cited there).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "oflib_hip.h"
 
@@ -1116,25 +1117,54 @@ __device__ __forceinline__ void sp_corners(float xv, float yv, float wmax, float
     ix[0] = (int)x0s - dx0; ix[1] = (int)x1s - dx0; iy[0] = (int)y0s - dy0; iy[1] = (int)y1s - dy0;
 }
 
-#ifndef OFL_SP_ABL
-#define OFL_SP_ABL 0   // timing ablations of the tile kernel (tools only): 1 no list building, 2 no list walking, 4 no data columns
+#ifndef OFL_SP_MINB
+#define OFL_SP_MINB 4   // blocks per CU the tile kernel's register budget is sized for (LDS allows 4; measured +9 % over 3)
 #endif
+// One record of the cell whose column is DC (-1, 0, +1) cells from the pair's middle cell and whose row serves corner
+// row KY, added to the sums of the destination pixels that read it: pixel 0 of the pair as its x-corner 1 (DC = -1) or
+// 0 (DC = 0), pixel 1 as its x-corner 1 (DC = 0) or 0 (DC = +1).  The corner is not clamped (the destination is inside
+// the image), so the reference's weight is (x1 - x | x - x0) * 1 (utils.py:1110-1114); product rounded, then added.
+template <int NCH, int DC, int KY>
+__device__ __forceinline__ void sp_use(const float* rec, uint32_t i, float (&a)[2][2][1 + NCH]) {
+    const float xv = rec[i], yv = rec[kSpQ + i];
+    const float x0 = floorf(xv), y0 = floorf(yv);
+    const float wyk = (KY ? yv - y0 : (y0 + 1.0f) - yv) * 1.0f;
+    float d[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) d[c] = rec[(3 + c) * kSpQ + i];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int kx = k - DC;                     // pixel k sits DC .. DC + 1 columns right of the cell: x-corner k - DC
+        if (kx < 0 || kx > 1) continue;
+        const float wxk = (kx ? xv - x0 : (x0 + 1.0f) - xv) * 1.0f;
+        const float wgt = wyk * wxk;
+        a[k][kx][0] += wgt;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) a[k][kx][1 + c] += wgt * d[c];
+    }
+}
+
 template <int NC, bool MCH>
-__global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p) {
+__global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const TiledParams p) {
     constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0), NREC = 3 + NCH, kRounds = kSpQ / kSpNT2;
-    constexpr uint32_t kEnd = 0xffffu;
-    // LDS: records [x | y | key | data ... | mask channel][kSpQ] | list heads [kPx][4] | list links [kSpQ][4]
-    // (the float-atomics fallback re-uses heads + links as accumulator planes)
-    __shared__ __attribute__((aligned(16))) unsigned char raw[kSpQ * 4 * NREC + kPx * 4 * 4 + kSpQ * 4 * 2];
+    constexpr uint32_t kEnd = 0xffffu, kLongCell = 0xfffeu;
+    // A CELL is a unit square of the destination grid: the records whose end point has floor(x, y) = (cx, cy).  The four
+    // corner classes of a destination pixel (X, Y) are the cells (X - kx, Y - ky), so one list per cell serves them all:
+    // (kSpTW + 1) x (kSpTH + 1) cells per tile, the first column / row being the cells left of / above the tile.
+    constexpr int kCW = kSpTW + 1, kCH = kSpTH + 1, kCells = kCW * kCH, kCellsP = (kCells + 63) / 64 * 64;
+    constexpr int kCellRounds = (kCellsP + kSpNT2 - 1) / kSpNT2;
+    // LDS: records [x | y | key | data ... | mask channel][kSpQ] | cell list heads | sorted cell slots | list links
+    // (the float-atomics fallback re-uses the record area as accumulator planes)
+    __shared__ __attribute__((aligned(16))) unsigned char raw[kSpQ * 4 * NREC + kCellsP * 4 + kCellsP * 8 + kSpQ * 2];
     __shared__ int qcount;
-    static_assert(kPx * 16 + kSpQ * 8 >= (1 + NCH) * kPx * 4, "fallback planes must fit the list area");
+    static_assert(kSpQ * NREC >= (1 + NCH) * kPx, "fallback planes must fit the record area");
     float* rec = reinterpret_cast<float*>(raw);                       // rec[a * kSpQ + i]
     const float* rx = rec; const float* ry = rec + kSpQ;
     const uint32_t* rkey = reinterpret_cast<const uint32_t*>(rec + 2 * kSpQ);
-    const float* rdat = rec + 3 * kSpQ;                               // [NCH][kSpQ]
-    uint32_t* head = reinterpret_cast<uint32_t*>(rec + NREC * kSpQ);  // [kPx][4]: newest record of the list, kEnd = empty
-    uint16_t* link = reinterpret_cast<uint16_t*>(head + kPx * 4);     // [kSpQ][4]: next record of the same list
-    float* acc = reinterpret_cast<float*>(head);                      // fallback: [1 + NCH][kPx]
+    uint32_t* head = reinterpret_cast<uint32_t*>(rec + NREC * kSpQ);  // [kCellsP]: newest record of the cell, kEnd = empty
+    uint2* slots = reinterpret_cast<uint2*>(head + kCellsP);          // [kCellsP]: up to 4 records in raster order, 16 bits each
+    uint16_t* link = reinterpret_cast<uint16_t*>(slots + kCellsP);    // [kSpQ]: next record of the same cell
+    float* acc = rec;                                                 // fallback: [1 + NCH][kPx]
     int tx, ty, n;
     if (!sp_decode(p, tx, ty, n)) return;
     const SplatParams& s = p.s;
@@ -1210,18 +1240,6 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
             if (MCH && s.mask_chan) s.mask_chan[(int64_t)n * hw + pix + 1] = mch2[1];
         }
     };
-    // one record's contribution to a corner class: the corner is not clamped (its weight was non-zero), so the
-    // reference's weight is (x1 - x, x - x0) * 1 (utils.py:1110-1114); product rounded, then added
-    auto add_record = [&](uint32_t i, int kx, int ky, float (&a)[1 + NCH]) {
-        const float xv = rx[i], yv = ry[i];
-        const float x0 = floorf(xv), y0 = floorf(yv);
-        const float wxk = (kx ? xv - x0 : (x0 + 1.0f) - xv) * 1.0f, wyk = (ky ? yv - y0 : (y0 + 1.0f) - yv) * 1.0f;
-        const float wgt = wyk * wxk;
-        a[0] += wgt;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) a[1 + c] += wgt * rdat[c * kSpQ + i];
-    };
-
     // bands of destination rows: 1 when the whole queue fits the LDS records
     int nb = 1;
     if (qlen > kSpQ) {                                    // a band of r rows sees about (r + 1) / 16 of the records
@@ -1234,48 +1252,40 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
     for (int band = 0; band < nb; ++band) {
         const int r0 = band * rows, r1 = r0 + rows;
 #pragma unroll
-        for (int i = 0; i < kPx * 4 / kSpNT2; ++i) head[tid + i * kSpNT2] = kEnd;
+        for (int i = 0; i < kCellRounds; ++i)
+            if (tid + i * kSpNT2 < kCellsP) head[tid + i * kSpNT2] = kEnd;
         int nrec = qlen;
         if (nb == 1) {
             // ---- A (whole queue): coalesced 16-byte copy into LDS (the queue is padded to whole groups of 4 records)
             static_assert(kSpQ <= kSpNT2 * 4, "one 16-byte group per thread");
             if (tid * 4 < qlen) {
 #pragma unroll
-                for (int a = 0; a < ((OFL_SP_ABL & 4) ? 3 : NREC); ++a)
+                for (int a = 0; a < NREC; ++a)
                     *reinterpret_cast<f4*>(rec + a * kSpQ + tid * 4) = *reinterpret_cast<const f4*>(gq + a * p.pool_cap + tid * 4);
             }
         } else {
             // ---- A (band): compact the records with a corner row inside the band
             if (tid == 0) qcount = 0;
             __syncthreads();
-            for (int base = 0; base < qlen; base += 2 * kSpNT2) {     // two groups of records in flight
-                float col[2][NREC];
-                bool hit[2];
+            for (int base = 0; base < qlen; base += kSpNT2) {
+                float col[NREC];
+                const int i = base + tid;
+                bool hit = i < qlen;
+                if (hit) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int i = base + u * kSpNT2 + tid;
-                    hit[u] = i < qlen;
-                    if (hit[u]) {
-#pragma unroll
-                        for (int a = 0; a < NREC; ++a) col[u][a] = gq[a * p.pool_cap + i];
-                    }
+                    for (int a = 0; a < NREC; ++a) col[a] = gq[a * p.pool_cap + i];
+                    const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(col[1]), -2.0f, (float)h) - dy0;
+                    hit = (y0 >= r0 - 1) && (y0 < r1);
                 }
+                const unsigned long long m = __ballot(hit);
+                if (m != 0ull) {                                 // wave-uniform
+                    int bpos = 0;
+                    if (lane == 0) bpos = atomicAdd(&qcount, __popcll(m));
+                    bpos = __builtin_amdgcn_readfirstlane(bpos);
+                    const int pos = bpos + __popcll(m & ((1ull << lane) - 1ull));
+                    if (hit && pos < kSpQ) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (hit[u]) {
-                        const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(col[u][1]), -2.0f, (float)h) - dy0;
-                        hit[u] = (y0 >= r0 - 1) && (y0 < r1);
-                    }
-                    const unsigned long long m = __ballot(hit[u]);
-                    if (m != 0ull) {                             // wave-uniform
-                        int bpos = 0;
-                        if (lane == 0) bpos = atomicAdd(&qcount, __popcll(m));
-                        bpos = __builtin_amdgcn_readfirstlane(bpos);
-                        const int pos = bpos + __popcll(m & ((1ull << lane) - 1ull));
-                        if (hit[u] && pos < kSpQ) {
-#pragma unroll
-                            for (int a = 0; a < NREC; ++a) rec[a * kSpQ + pos] = col[u][a];
-                        }
+                        for (int a = 0; a < NREC; ++a) rec[a * kSpQ + pos] = col[a];
                     }
                 }
             }
@@ -1284,97 +1294,128 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_kernel(const TiledParams p)
             if (nrec > kSpQ) { over = true; nrec = 0; }     // block-uniform
         }
         __syncthreads();                                     // records and list heads are in place
-        // ---- B: every (record, corner) joins the list of its (destination pixel, corner class)
+        // ---- B: every record joins the list of its cell (cell rows r0 .. r1 serve the destination rows of the band)
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
             const int i = tid + r * kSpNT2;
-            if (i < nrec && !(OFL_SP_ABL & 1)) {
-                float wx[2], wy[2]; int ix[2], iy[2];
-                sp_corners(rx[i], ry[i], wmax, hmax, dx0, dy0, wx, wy, ix, iy);
-#pragma unroll
-                for (int ky = 0; ky < 2; ++ky) {
-#pragma unroll
-                    for (int kx = 0; kx < 2; ++kx) {
-                        const int xl = ix[kx], yl = iy[ky];
-                        // a zero weight adds +0 to a non-negative sum: skipping it changes nothing (finite data)
-                        if (wy[ky] * wx[kx] == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || yl < r0 || yl >= r1) continue;
-                        const int cls = ky * 2 + kx;
-                        link[i * 4 + cls] = (uint16_t)atomicExch(&head[(yl * kSpTW + xl) * 4 + cls], (uint32_t)i);
-                    }
-                }
+            if (i < nrec) {
+                const int cx = (int)__builtin_amdgcn_fmed3f(floorf(rx[i]), -2.0f, (float)w) - dx0 + 1;
+                const int cy = (int)__builtin_amdgcn_fmed3f(floorf(ry[i]), -2.0f, (float)h) - dy0 + 1;
+                if ((uint32_t)cx < (uint32_t)kCW && cy >= r0 && cy <= r1)
+                    link[i] = (uint16_t)atomicExch(&head[cy * kCW + cx], (uint32_t)i);
             }
         }
         over = __syncthreads_or((int)over) != 0;
         if (over) break;
-        // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize
-        // Within a corner class the reference adds the contributions in raster order of the source pixels = ascending
-        // key.  One or two contributions need no ordering (a two-term sum is commutative), three or four are sorted in
-        // registers, up to kSpLong by repeated minimum search; a longer list (a fold of the flow) sends the tile to the
-        // float-atomics fallback.
-        const bool mine = inimg && ly >= r0 && ly < r1;
+        // ---- S: every cell's records in raster order of their source pixels (ascending key) -- the order in which the
+        // reference's scatter_add_ adds them within a corner class.  Up to four are sorted in registers and written as
+        // one 8-byte slot group; a longer list (a compression of the flow, up to kSpLong records) is sorted too, its links
+        // rewritten in order, and walked by its readers; beyond that -- a fold -- the tile takes the float-atomics fallback.
         bool toolong = false;
-        float tot[2][1 + NCH];
-        if (mine) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int d = ly * kSpTW + max(lx2 + k, 0);                // (solo: pixel 0 is computed twice, its first copy is never stored)
-                const uint4 hd = *reinterpret_cast<const uint4*>(head + d * 4);
-                const uint32_t heads[4] = {hd.x, hd.y, hd.z, hd.w};
+        for (int r = 0; r < kCellRounds; ++r) {
+            const int c = tid + r * kSpNT2;
+            if (c < kCells) {
+                uint32_t e[4];
+                e[0] = head[c];
+                e[1] = e[0] != kEnd ? (uint32_t)link[e[0]] : kEnd;
+                e[2] = e[1] != kEnd ? (uint32_t)link[e[1]] : kEnd;
+                e[3] = e[2] != kEnd ? (uint32_t)link[e[2]] : kEnd;
+                const uint32_t e4 = e[3] != kEnd ? (uint32_t)link[e[3]] : kEnd;
+                if (e4 != kEnd) {
+                    // a longer list: sorted in registers (bubble network over kSpLong slots), links rewritten in order
+                    uint32_t le[kSpLong], lk[kSpLong];
+                    uint32_t cur = e[0];
 #pragma unroll
-                for (int cls = 0; cls < 4; ++cls) {
-                    const int kx = cls & 1, ky = cls >> 1;
-                    float a[1 + NCH];
+                    for (int j = 0; j < kSpLong; ++j) {
+                        le[j] = cur;
+                        lk[j] = cur != kEnd ? rkey[cur] : 0xffffffffu;
+                        cur = cur != kEnd ? (uint32_t)link[cur] : kEnd;
+                    }
+                    if (cur != kEnd) {
+                        toolong = true;                                // a fold of the flow: the tile leaves the exact path
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < 1 + NCH; ++c) a[c] = 0.0f;
-                    const uint32_t e0 = (OFL_SP_ABL & 2) ? kEnd : heads[cls];
-                    if (e0 != kEnd) {
-                        const uint32_t e1 = link[e0 * 4 + cls];
-                        if (e1 == kEnd) {                                  // one contribution (the usual case)
-                            add_record(e0, kx, ky, a);
-                        } else {
-                            const uint32_t e2 = link[e1 * 4 + cls];
-                            if (e2 == kEnd) {                              // two: order-free
-                                add_record(e0, kx, ky, a); add_record(e1, kx, ky, a);
-                            } else {
-                                const uint32_t e3 = link[e2 * 4 + cls];
-                                const uint32_t e4 = e3 == kEnd ? kEnd : (uint32_t)link[e3 * 4 + cls];
-                                if (e4 == kEnd) {                          // three or four: sorting network on the keys
-                                    uint32_t e[4] = {e0, e1, e2, e3};
-                                    uint32_t key[4] = {rkey[e0], rkey[e1], rkey[e2], e3 == kEnd ? 0xffffffffu : rkey[e3 & 1023u]};
+                        for (int i = 0; i < kSpLong - 1; ++i)
+#pragma unroll
+                            for (int j = 0; j < kSpLong - 1 - i; ++j) {
+                                const bool sw = lk[j] > lk[j + 1];
+                                const uint32_t tk = sw ? lk[j + 1] : lk[j], te = sw ? le[j + 1] : le[j];
+                                lk[j + 1] = sw ? lk[j] : lk[j + 1]; le[j + 1] = sw ? le[j] : le[j + 1]; lk[j] = tk; le[j] = te;
+                            }
+                        head[c] = le[0];
+#pragma unroll
+                        for (int j = 0; j < kSpLong; ++j)
+                            if (le[j] != kEnd) link[le[j]] = (uint16_t)(j + 1 < kSpLong ? le[j + 1 < kSpLong ? j + 1 : j] : kEnd);
+                    }
+                    e[0] = kLongCell;
+                } else if (e[1] != kEnd) {
+                    uint32_t key[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) key[j] = e[j] != kEnd ? rkey[e[j]] : 0xffffffffu;
 #define OFL_CSWAP(a_, b_) { const bool sw = key[a_] > key[b_]; const uint32_t tk = sw ? key[b_] : key[a_], te = sw ? e[b_] : e[a_]; \
                             key[b_] = sw ? key[a_] : key[b_]; e[b_] = sw ? e[a_] : e[b_]; key[a_] = tk; e[a_] = te; }
-                                    OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
+                    OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
 #undef OFL_CSWAP
-                                    add_record(e[0], kx, ky, a); add_record(e[1], kx, ky, a); add_record(e[2], kx, ky, a);
-                                    if (e[3] != kEnd) add_record(e[3], kx, ky, a);
-                                } else {                                   // longer: bounded minimum search
-                                    int len = 5;
-                                    for (uint32_t e = link[e4 * 4 + cls]; e != kEnd && len <= kSpLong; e = link[e * 4 + cls]) ++len;
-                                    if (len > kSpLong) {
-                                        toolong = true;
-                                    } else {
-                                        int last = -1;                     // keys are < 2^31 (16-bit rows and columns < 2^15)
-                                        for (int t = 0; t < len; ++t) {
-                                            uint32_t best = kEnd; int bkey = 0x7fffffff;
-                                            for (uint32_t e = e0; e != kEnd; e = link[e * 4 + cls]) {
-                                                const int kk = (int)rkey[e];
-                                                if (kk > last && kk < bkey) { bkey = kk; best = e; }
-                                            }
-                                            add_record(best, kx, ky, a);
-                                            last = bkey;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = cls == 0 ? a[c] : tot[k][c] + a[c];   // ((c0 + c1) + c2) + c3
                 }
+                slots[c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
             }
         }
         over = __syncthreads_or((int)toolong) != 0;
         if (over) break;
+        // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.
+        // The pair reads 3 x 2 cells; every record of a cell is fetched once and added to each corner-class sum it
+        // belongs to (sp_use).
+        const bool mine = inimg && ly >= r0 && ly < r1;
+        float tot[2][1 + NCH];
+        if (mine) {
+            float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
+            auto clear = [&]() {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+                        for (int c = 0; c < 1 + NCH; ++c) a[k][kx][c] = 0.0f;
+            };
+            const int cm = max(lx2 + 1, 0);                            // cell column of pixel 1's x-corner 1 = of pixel 0's x-corner 0
+            auto cell = [&](auto dc_, auto ky_) {
+                constexpr int DC = decltype(dc_)::value, KY = decltype(ky_)::value;
+                const int c = (ly + 1 - KY) * kCW + max(cm + DC, 0);   // (solo: pixel 0's own cells do not exist; it is never stored)
+                const uint2 sl = slots[c];
+                const uint32_t e0 = sl.x & 0xffffu, e1 = sl.x >> 16, e2 = sl.y & 0xffffu, e3 = sl.y >> 16;
+                if (e0 == kEnd) return;
+                if (e0 != kLongCell) {
+                    sp_use<NCH, DC, KY>(rec, e0, a);
+                    if (e1 != kEnd) {
+                        sp_use<NCH, DC, KY>(rec, e1, a);
+                        if (e2 != kEnd) {
+                            sp_use<NCH, DC, KY>(rec, e2, a);
+                            if (e3 != kEnd) sp_use<NCH, DC, KY>(rec, e3, a);
+                        }
+                    }
+                } else {                                               // phase S left the list in raster order
+                    for (uint32_t e = head[c]; e != kEnd; e = link[e]) sp_use<NCH, DC, KY>(rec, e, a);
+                }
+            };
+            using std::integral_constant;
+            clear();                                                   // corner row 0: classes 0, 1
+            cell(integral_constant<int, -1>{}, integral_constant<int, 0>{});
+            cell(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+            cell(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = a[k][0][c] + a[k][1][c];
+            clear();                                                   // corner row 1: classes 2, 3
+            cell(integral_constant<int, -1>{}, integral_constant<int, 1>{});
+            cell(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+            cell(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
+        }
         if (mine) finalize(tot);
         if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
     }

@@ -110,3 +110,40 @@ def test_batch_of_64_repeats_its_two_frames(frames, dev):
     small = ofl.Flow(t["fs"], 's', t["m1"]).apply(t["img"], target_mask=t["tm"], return_valid_area=True)
     for b, s in zip(big, small):
         assert torch.equal(b, rep(s))
+
+
+def test_config5_4k_fp16_switch_ref_then_mode1(dev):
+    """BASELINE.json configs[4]: 2160 x 3840 flows stored in fp16, ``switch_ref`` 's' -> 't', then ``combine_with`` mode 1
+    in 't'.  The reference turns every flow into fp32 on entry (utils.py:95,118), so the oracle gets the same fp16 values
+    as exact fp32 numbers; both steps are bit-exact while the splat stays on its routed exact path."""
+    import bench
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    _native.collect_splat_stats = True
+    h, w = 2160, 3840
+    f1 = bench.smooth_flow(1, h, w, 2.0, 7000, dev).half()
+    f2 = bench.smooth_flow(1, h, w, 8.0, 5000, dev).half()
+    m1 = torch.ones(1, h, w, dtype=torch.bool, device=dev)
+    m1[:, 300:500, 1000:2500] = False
+    m2 = torch.ones(1, h, w, dtype=torch.bool, device=dev)
+    m2[:, 1500:1550] = False
+    a = ofl.Flow(f1, 's', m1).switch_ref()
+    assert a.ref == 't' and a.vecs.dtype == torch.float32
+    exact = _native._last_splat_stats.cpu().tolist()[:2] == [0, 0]
+    n1, n2 = f1.float().cpu().numpy(), f2.float().cpu().numpy()
+    ev, em, _ = oracle.switch_ref(n1, 's', m1.cpu().numpy())
+    assert np.array_equal(a.mask.cpu().numpy(), em)
+    if exact:
+        assert np.array_equal(a.vecs.cpu().numpy(), ev)
+    else:
+        np.testing.assert_allclose(a.vecs.cpu().numpy(), ev, rtol=2e-5, atol=2e-5 * 30)
+    # mode 1 on the oracle's own intermediate, so that the second step is pinned by itself
+    b = ofl.Flow(torch.from_numpy(ev).to(dev), 't', torch.from_numpy(em).to(dev)).combine_with(ofl.Flow(f2, 't', m2), 1)
+    st = _native._last_splat_stats.cpu().tolist()[:2]
+    cv, cm, _ = oracle.combine_with(ev, em, n2, m2.cpu().numpy(), 1, 't')
+    assert np.array_equal(b.mask.cpu().numpy(), cm)
+    if st == [0, 0]:
+        assert np.array_equal(b.vecs.cpu().numpy(), cv)
+    else:
+        np.testing.assert_allclose(b.vecs.cpu().numpy(), cv, rtol=2e-5, atol=2e-5 * 60)
