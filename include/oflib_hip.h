@@ -156,7 +156,7 @@ int ofl_splat_finalize_f32(const float* accum,
  * ((c0 + c1) + c2) + c3 across the classes -- the order of the reference's four scatter_add_ passes and corner sum
  * (utils.py:1133-1143): results are BIT-IDENTICAL to the reference's (and from run to run), not just within a tolerance.
  * Normalise / masks / un-occlude fill happen in the same kernel; no float atomics, no accumulator in HBM.
- * Needs 4 <= W < 65536, H < 32768 (any width: 16-byte accesses at 4-byte alignment; more than 3 channels are
+ * Needs 4 <= W < 32768, H < 32768 (any width: 16-byte accesses at 4-byte alignment; more than 3 channels are
  * processed in groups of 3), else it returns OFL_E_UNSUPPORTED and the caller
  * uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
  *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  queue lengths / offsets + the packed record pool

@@ -1065,11 +1065,12 @@ __global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p)
             if (pr[k][j] != 0xffffffffu) {
                 const int pos = lbase[pr[k][j] >> 12] + (int)(pr[k][j] & 0xfffu);
                 p.pool[pos] = q.x[k]; p.pool[p.pool_cap + pos] = q.y[k];
-                pk[pos] = ((uint32_t)sy << 16) | (uint32_t)(sx4 + k);
+                // key: raster position of the source pixel (15 bits each, checked by ofl_splat_tiled_f32) with the mask-channel bit below it --
+                // two records never share a position, so ordering by the whole word is raster order
+                pk[pos] = ((((uint32_t)sy << 15) | (uint32_t)(sx4 + k)) << 1) | ((mc4 >> (8 * k)) & 1u);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     if (c < nc) p.pool[(3 + c) * p.pool_cap + pos] = s.data_sign * dat[c][k];
-                if (s.with_mask_chan) p.pool[(3 + nc) * p.pool_cap + pos] = ((mc4 >> (8 * k)) & 1u) ? 1.0f : 0.0f;
             }
         }
     }
@@ -1124,14 +1125,15 @@ __device__ __forceinline__ void sp_corners(float xv, float yv, float wmax, float
 // row KY, added to the sums of the destination pixels that read it: pixel 0 of the pair as its x-corner 1 (DC = -1) or
 // 0 (DC = 0), pixel 1 as its x-corner 1 (DC = 0) or 0 (DC = +1).  The corner is not clamped (the destination is inside
 // the image), so the reference's weight is (x1 - x | x - x0) * 1 (utils.py:1110-1114); product rounded, then added.
-template <int NCH, int DC, int KY>
+template <int NC, int NCH, int DC, int KY>
 __device__ __forceinline__ void sp_use(const float* rec, uint32_t i, float (&a)[2][2][1 + NCH]) {
     const float xv = rec[i], yv = rec[kSpQ + i];
     const float x0 = floorf(xv), y0 = floorf(yv);
     const float wyk = (KY ? yv - y0 : (y0 + 1.0f) - yv) * 1.0f;
     float d[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) d[c] = rec[(3 + c) * kSpQ + i];
+    for (int c = 0; c < NC; ++c) d[c] = rec[(3 + c) * kSpQ + i];
+    if (NCH > NC) d[NC] = (float)(__float_as_uint(rec[2 * kSpQ + i]) & 1u);   // the mask channel rides in the key
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int kx = k - DC;                     // pixel k sits DC .. DC + 1 columns right of the cell: x-corner k - DC
@@ -1146,14 +1148,14 @@ __device__ __forceinline__ void sp_use(const float* rec, uint32_t i, float (&a)[
 
 template <int NC, bool MCH>
 __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const TiledParams p) {
-    constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0), NREC = 3 + NCH, kRounds = kSpQ / kSpNT2;
+    constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0), NREC = 3 + NC, kRounds = kSpQ / kSpNT2;
     constexpr uint32_t kEnd = 0xffffu, kLongCell = 0xfffeu;
     // A CELL is a unit square of the destination grid: the records whose end point has floor(x, y) = (cx, cy).  The four
     // corner classes of a destination pixel (X, Y) are the cells (X - kx, Y - ky), so one list per cell serves them all:
     // (kSpTW + 1) x (kSpTH + 1) cells per tile, the first column / row being the cells left of / above the tile.
     constexpr int kCW = kSpTW + 1, kCH = kSpTH + 1, kCells = kCW * kCH, kCellsP = (kCells + 63) / 64 * 64;
     constexpr int kCellRounds = (kCellsP + kSpNT2 - 1) / kSpNT2;
-    // LDS: records [x | y | key | data ... | mask channel][kSpQ] | cell list heads | sorted cell slots | list links
+    // LDS: records [x | y | key + mask-channel bit | data ...][kSpQ] | cell list heads | sorted cell slots | list links
     // (the float-atomics fallback re-uses the record area as accumulator planes)
     __shared__ __attribute__((aligned(16))) unsigned char raw[kSpQ * 4 * NREC + kCellsP * 4 + kCellsP * 8 + kSpQ * 2];
     __shared__ int qcount;
@@ -1386,16 +1388,16 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
                 const uint32_t e0 = sl.x & 0xffffu, e1 = sl.x >> 16, e2 = sl.y & 0xffffu, e3 = sl.y >> 16;
                 if (e0 == kEnd) return;
                 if (e0 != kLongCell) {
-                    sp_use<NCH, DC, KY>(rec, e0, a);
+                    sp_use<NC, NCH, DC, KY>(rec, e0, a);
                     if (e1 != kEnd) {
-                        sp_use<NCH, DC, KY>(rec, e1, a);
+                        sp_use<NC, NCH, DC, KY>(rec, e1, a);
                         if (e2 != kEnd) {
-                            sp_use<NCH, DC, KY>(rec, e2, a);
-                            if (e3 != kEnd) sp_use<NCH, DC, KY>(rec, e3, a);
+                            sp_use<NC, NCH, DC, KY>(rec, e2, a);
+                            if (e3 != kEnd) sp_use<NC, NCH, DC, KY>(rec, e3, a);
                         }
                     }
                 } else {                                               // phase S left the list in raster order
-                    for (uint32_t e = head[c]; e != kEnd; e = link[e]) sp_use<NCH, DC, KY>(rec, e, a);
+                    for (uint32_t e = head[c]; e != kEnd; e = link[e]) sp_use<NC, NCH, DC, KY>(rec, e, a);
                 }
             };
             using std::integral_constant;
@@ -1431,7 +1433,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
         float dd[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) dd[c] = gq[(3 + c) * p.pool_cap + i];
-        const bool invalid = MCH ? (gq[(3 + NC) * p.pool_cap + i] == 0.0f) : false;
+        const bool invalid = MCH ? ((__float_as_uint(gq[2 * p.pool_cap + i]) & 1u) == 0u) : false;
         float wx[2], wy[2]; int ix[2], iy[2];
         sp_corners(gq[i], gq[p.pool_cap + i], wmax, hmax, dx0, dy0, wx, wy, ix, iy);
 #pragma unroll
@@ -1761,7 +1763,7 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 }
 
 
-constexpr int kSpRecFloats = 7;   // floats per record: x, y, key, up to 3 data channels, mask channel
+constexpr int kSpRecFloats = 6;   // floats per record: x, y, key (+ mask-channel bit), up to 3 data channels
 // records the pool of one pass holds: 1.5 per pixel (smooth flows need ~1.1), and the images per pass (<= ~1 GiB)
 static int64_t splat_pool_records(int64_t images, int32_t h, int32_t w) {
     const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
@@ -1802,7 +1804,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     if (rc) return rc;
     // eligibility of the routed path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit coordinates
     // (any width: 16 / 8-byte accesses at 4-byte alignment, mask bytes at any alignment)
-    const bool ok = w >= 4 && w < 65536 && h < 32768;
+    const bool ok = w >= 4 && w < 32768 && h < 32768;   // 15-bit rows and columns in the record key
     if (!ok) return OFL_E_UNSUPPORTED;
     if (workspace_ints < ofl_splat_tiled_workspace_ints(n, h, w)) return OFL_E_ARG;
     tp.s.flow_sign = flow_sign; tp.s.xs = xs; tp.s.ys = ys; tp.s.xy_bs = xy_bs;
