@@ -885,9 +885,9 @@ constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // tile kernel: 2 d
 constexpr int kSpQ = OFL_SP_Q;    // records the tile kernel holds in LDS at a time (1024 measured faster than 768 + one more block per CU)
 constexpr int kSpRouteMax = 48;   // destination tiles one source tile may feed
 #ifndef OFL_SP_LONG
-#define OFL_SP_LONG 12
+#define OFL_SP_LONG 64
 #endif
-constexpr int kSpLong = OFL_SP_LONG;   // longest list (contributions to one corner class of one destination pixel) summed in raster order
+constexpr int kSpLong = OFL_SP_LONG;   // longest cell list (source pixels whose end points share one unit cell) that is summed in raster order
 
 __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-zero -> 0x01
     uint32_t r = 0;
@@ -1311,8 +1311,8 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
         if (over) break;
         // ---- S: every cell's records in raster order of their source pixels (ascending key) -- the order in which the
         // reference's scatter_add_ adds them within a corner class.  Up to four are sorted in registers and written as
-        // one 8-byte slot group; a longer list (a compression of the flow, up to kSpLong records) is sorted too, its links
-        // rewritten in order, and walked by its readers; beyond that -- a fold -- the tile takes the float-atomics fallback.
+        // one 8-byte slot group; a longer list (a compression or fold of the flow) is sorted as a list and walked by its
+        // readers.
         bool toolong = false;
 #pragma unroll
         for (int r = 0; r < kCellRounds; ++r) {
@@ -1325,30 +1325,28 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
                 e[3] = e[2] != kEnd ? (uint32_t)link[e[2]] : kEnd;
                 const uint32_t e4 = e[3] != kEnd ? (uint32_t)link[e[3]] : kEnd;
                 if (e4 != kEnd) {
-                    // a longer list: sorted in registers (bubble network over kSpLong slots), links rewritten in order
-                    uint32_t le[kSpLong], lk[kSpLong];
-                    uint32_t cur = e[0];
-#pragma unroll
-                    for (int j = 0; j < kSpLong; ++j) {
-                        le[j] = cur;
-                        lk[j] = cur != kEnd ? rkey[cur] : 0xffffffffu;
-                        cur = cur != kEnd ? (uint32_t)link[cur] : kEnd;
-                    }
-                    if (cur != kEnd) {
-                        toolong = true;                                // a fold of the flow: the tile leaves the exact path
+                    // a longer list: insertion sort of the linked list itself.  Records were pushed in roughly ascending
+                    // key order, so the list runs roughly descending and most nodes go straight to the front of the
+                    // sorted list.  The limit is on the LENGTH (the same in every run, unlike the order the atomics leave):
+                    // beyond it the tile takes the float-atomics fallback.
+                    int len = 5;
+                    for (uint32_t e = link[e4]; e != kEnd && len <= kSpLong; e = link[e]) ++len;
+                    if (len > kSpLong) {
+                        toolong = true;
                     } else {
-#pragma unroll
-                        for (int i = 0; i < kSpLong - 1; ++i)
-#pragma unroll
-                            for (int j = 0; j < kSpLong - 1 - i; ++j) {
-                                const bool sw = lk[j] > lk[j + 1];
-                                const uint32_t tk = sw ? lk[j + 1] : lk[j], te = sw ? le[j + 1] : le[j];
-                                lk[j + 1] = sw ? lk[j] : lk[j + 1]; le[j + 1] = sw ? le[j] : le[j + 1]; lk[j] = tk; le[j] = te;
+                        uint32_t sorted = kEnd, cur = e[0];
+                        while (cur != kEnd) {
+                            const uint32_t nxt = link[cur], k = rkey[cur];
+                            if (sorted == kEnd || rkey[sorted] > k) {
+                                link[cur] = (uint16_t)sorted; sorted = cur;
+                            } else {
+                                uint32_t q = sorted, qn = link[q];
+                                while (qn != kEnd && rkey[qn] < k) { q = qn; qn = link[q]; }
+                                link[cur] = (uint16_t)qn; link[q] = (uint16_t)cur;
                             }
-                        head[c] = le[0];
-#pragma unroll
-                        for (int j = 0; j < kSpLong; ++j)
-                            if (le[j] != kEnd) link[le[j]] = (uint16_t)(j + 1 < kSpLong ? le[j + 1 < kSpLong ? j + 1 : j] : kEnd);
+                            cur = nxt;
+                        }
+                        head[c] = sorted;
                     }
                     e[0] = kLongCell;
                 } else if (e[1] != kEnd) {
