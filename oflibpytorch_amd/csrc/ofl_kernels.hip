@@ -128,6 +128,8 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U16u { uint16_t v; };
 __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4u*>(p); }
+// read-once operands (the flow of a warp): non-temporal, so that they do not push the gathered image's halo out of L2
+__device__ __forceinline__ f4 ld4nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p)); }
 __device__ __forceinline__ f2 ld2(const float* p) { return *reinterpret_cast<const f2u*>(p); }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4u*>(p) = v; }
 __device__ __forceinline__ void st2(float* p, f2 v) { *reinterpret_cast<f2u*>(p) = v; }
@@ -533,8 +535,8 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
     const uint32_t pixA = (uint32_t)(min(tyA * kLdsTH + ly, h - 1) * w + xq);
     const uint32_t pixB = (uint32_t)(min(tyB * kLdsTH + ly, h - 1) * w + xq);
-    const f4 uA = ld4(fu + pixA), vA = ld4(fu + hw + pixA);
-    const f4 uB = ld4(fu + pixB), vB = ld4(fu + hw + pixB);
+    const f4 uA = ld4nt(fu + pixA), vA = ld4nt(fu + hw + pixA);
+    const f4 uB = ld4nt(fu + pixB), vB = ld4nt(fu + hw + pixB);
     uint32_t fmA = 0x01010101u, fmB = 0x01010101u;
     if ((VALID || p.flow_flags) && fm) {
         fmA = ld32(fm + pixA);
