@@ -60,7 +60,7 @@ int ofl_version(void);
  *   (speed only; the results are identical). */
 #define OFL_OPT_WARP_SHEAR 3
 /*   OFL_OPT_SPLAT_PASS_IMAGES: upper bound on the images ofl_splat_tiled_f32 handles per pass (0 = as many as keep the
- *   record queues under ~1 GiB; tests use small values to exercise the multi-pass code on small inputs). */
+ *   record queues under ~4 GiB; tests use small values to exercise the multi-pass code on small inputs). */
 #define OFL_OPT_SPLAT_PASS_IMAGES 4
 int ofl_set_option(int32_t key, int32_t value);
 
@@ -160,15 +160,16 @@ int ofl_splat_finalize_f32(const float* accum,
  * processed in groups of 3), else it returns OFL_E_UNSUPPORTED and the caller
  * uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
  *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  queue lengths / offsets + the packed record pool
- *                  (28 bytes x 1.5 records per pixel; the batch is processed in passes so that it stays under ~1 GiB);
+ *                  (24 bytes x 1.5 records per pixel; the batch is processed in equal passes so that it stays under ~4 GiB);
  *                  contents irrelevant on entry; afterwards workspace[0] = 1 if the launch fell back to the two-pass
  *                  path, workspace[1] = number of tiles that left the exact path
  *   accum_fallback fp32[ofl_splat_tiled_pass_images(n, h, w) * (1 + C + with_mask_chan) * H * W]  (one pass of the batch)
  *                  used (and zeroed in-stream) only when the record pool
  *                  overflows (> 1.5 records per pixel on average) or a 32 x 16 source tile spreads over > 48 destination
  *                  tiles; the two-pass global-atomics path then runs inside the same call, decided on the device (no
- *                  host sync; tolerance instead of bit-exactness).  A fold of the flow (> 12 sources in one corner
- *                  class of one destination pixel) makes only ITS tile fall back to (LDS) float atomics.
+ *                  host sync; tolerance instead of bit-exactness).  A heavy fold of the flow (> 64 source pixels
+ *                  ending in one unit cell, or more records for one tile than four bands of its rows can hold) makes
+ *                  only ITS tile fall back to (LDS) float atomics.
  */
 int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w);
 int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w);   /* images handled per pass (<= n) */

@@ -83,7 +83,7 @@ def set_warp_shear(on: bool):
 
 
 def set_splat_pass_images(k: int):
-    """Routed splat: at most k images per pass (0 = automatic, ~1 GiB of queues); tests use it to force several passes."""
+    """Routed splat: at most k images per pass (0 = automatic, ~4 GiB of queues); tests use it to force several passes."""
     _check(load_library().ofl_set_option(4, int(k)), "ofl_set_option")
 
 
