@@ -221,7 +221,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
             _check(rc, "ofl_splat_tiled_f32")
         if collect_splat_stats:             # (a copy: a view would keep the whole workspace alive between calls)
             global _last_splat_stats
-            _last_splat_stats = ws[:4].clone()   # [launch fell back to global atomics, tiles that left the exact path, -, -]
+            _last_splat_stats = ws[:8].clone()   # [launch fell back to global atomics, tiles that left the exact path, -, -]
     if rc == -4:   # not eligible (alignment / channels): the general two-pass path
         accum = torch.zeros((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
         _check(lib.ofl_splat_fwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
