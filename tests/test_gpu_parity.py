@@ -318,6 +318,62 @@ def test_exact_splat_is_bit_identical_to_the_oracle(shape, sigma, dev):
         pass
 
 
+@pytest.mark.parametrize("patch", [(12, 0.5), (16, 0.3), (20, 0.2)])
+def test_compressing_flows_stay_exact(patch, dev):
+    """Patches of the image that the flow shrinks put many source pixels into one unit cell of the destination grid (here 4
+    to ~30 per cell, beyond the four sorted slots of a cell): their lists are sorted as lists and still summed in the
+    reference's order -- bit-identical values, no tile leaves the exact path."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    _native.collect_splat_stats = True
+    n, c, h, w = 2, 3, 96, 160
+    size, sc = patch
+    flow = _smooth(n, h, w, 0.4, 5, torch.device('cpu'))
+    for (y0, x0) in ((10, 20), (50, 100), (70, 30)):
+        xs = torch.arange(size, dtype=torch.float32).view(1, 1, size) - size / 2 + 0.3
+        ys = torch.arange(size, dtype=torch.float32).view(1, size, 1) - size / 2 + 0.7
+        flow[:, 0, y0:y0 + size, x0:x0 + size] += (sc - 1.0) * xs
+        flow[:, 1, y0:y0 + size, x0:x0 + size] += (sc - 1.0) * ys
+    flow = flow.contiguous().to(dev)
+    g = torch.Generator().manual_seed(3)
+    data = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    wm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    ca = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    kw = dict(weight_mask=wm, chan_mask_a=ca, want_mask_chan=True, want_density=True, want_warped=True)
+    out = _native.splat_fwd(flow, data, **kw)
+    assert _native._last_splat_stats.cpu().tolist()[:2] == [0, 0]
+    dd = np.concatenate([data.cpu().numpy(), ca.cpu().numpy()[:, None].astype(np.float32)], 1)
+    ref, rwarped, rden = oracle.apply_s_flow(flow.cpu().numpy(), dd, wm.cpu().numpy(), True, return_density=True)
+    assert rden.max() > 3.5                                   # the case does exercise long cell lists
+    assert np.array_equal(out[0].cpu().numpy(), ref[:, :c])
+    assert np.array_equal(out[1].cpu().numpy(), ref[:, c])
+    assert np.array_equal(out[2].cpu().numpy(), rden)
+    assert np.array_equal(out[3].cpu().numpy(), rwarped)
+
+
+def test_a_fold_beyond_the_list_limit_falls_back_per_tile(dev):
+    """Every source pixel of a 64-row band ends in ONE row of cells (> 64 per cell): those tiles take the float-atomics
+    fallback (counted), masks stay bit-exact, values within the stated tolerance; the choice is the same in every run."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    _native.collect_splat_stats = True
+    n, c, h, w = 1, 2, 128, 96
+    ys = torch.arange(h, dtype=torch.float32).view(1, 1, h, 1)
+    v = torch.where((ys >= 32) & (ys < 112), 60.4 - ys, torch.zeros_like(ys)).expand(n, 1, h, w)
+    flow = torch.cat([torch.full((n, 1, h, w), 0.3), v], 1).contiguous().to(dev)
+    g = torch.Generator().manual_seed(4)
+    data = (torch.rand(n, c, h, w, generator=g) * 10).to(dev)
+    outs, stats = [], []
+    for rep in range(2):
+        outs.append(_native.splat_fwd(flow, data, want_density=True, want_warped=True, occlude=False))
+        stats.append(_native._last_splat_stats.cpu().tolist()[:2])
+    assert stats[0] == stats[1] and stats[0][0] == 0 and stats[0][1] > 0
+    ref, rwarped, rden = oracle.apply_s_flow(flow.cpu().numpy(), data.cpu().numpy(), None, False, return_density=True)
+    assert np.array_equal(outs[0][3].cpu().numpy(), rwarped)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref, rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), rden, rtol=2e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("rough", [False, True])
 def test_routed_splat_in_several_passes(rough, dev):
     """n = 5 images, at most 2 per pass: the passes re-use the queues; with a rough flow the launch-level two-pass fallback
