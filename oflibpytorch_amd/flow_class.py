@@ -50,7 +50,8 @@ class Flow(object):
         self.device = device
 
     @classmethod
-    def _wrap(cls, vecs: torch.Tensor, ref: str, mask, device=None, flags: torch.Tensor = None) -> FlowAlias:
+    def _wrap(cls, vecs: torch.Tensor, ref: str, mask, device=None, flags: torch.Tensor = None,
+              like: FlowAlias = None) -> FlowAlias:
         """Internal: wrap tensors that are valid by construction (kernel outputs, views of validated flows).
         `flags` is the device-side flag word a kernel produced as a by-product, read lazily."""
         obj = cls.__new__(cls)
@@ -61,7 +62,19 @@ class Flow(object):
             obj._vecs = obj._vecs.to(obj._device)
         if obj._mask is not None and obj._mask.device != obj._device:
             obj._mask = obj._mask.to(obj._device)
+        if like is not None:
+            obj._inherit_flags(like)
         return obj
+
+    def _inherit_flags(self, src: FlowAlias):
+        """`self` holds the vectors of `src` or their exact negation, under the same mask: every flag (finiteness, the
+        symmetric zero / threshold tests) carries over, no reduction needed."""
+        if src._flags_known() and (self._mask is src._mask):
+            key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+            self._flag_cache = (key, src._flag_cache[1])
+
+    def _negated(self, ref: str) -> FlowAlias:
+        return Flow._wrap(self._vecs * -1.0, ref, self._mask, self._device, like=self)
 
     @classmethod
     def _deferred(cls, flow_vectors, ref: str = None, mask=None, device=None) -> FlowAlias:
@@ -332,6 +345,8 @@ class Flow(object):
         """flow_class.py:533-580"""
         o = self._scalar_or_field(other, "multiplying", "Multiplier")
         if isinstance(o, float):
+            if o == -1.0 or o == 1.0:
+                return Flow._wrap(self._vecs * o, self._ref, self._mask, self._device, like=self)
             return Flow._wrap(self._vecs * o, self._ref, self._mask, self._device) if np.isfinite(o) \
                 else Flow(self._vecs * o, self._ref, self._mask, self._device)
         return self._result_of(self._vecs * o)
@@ -464,9 +479,13 @@ class Flow(object):
             warped = warped[0, 0] if return_2d else warped[0]
         return (warped, valid) if return_valid_area else warped
 
-    def _warp(self, t: torch.Tensor, tmask, need_valid: bool, consider_mask: bool, round_mode: int = 0):
+    def _warp(self, t: torch.Tensor, tmask, need_valid: bool, consider_mask: bool, round_mode: int = 0,
+              flow_sign: float = 1.0, data_sign: float = 1.0):
         """Core of `apply`: t [Nt,C,H,W] any dtype, tmask [Nt,H,W] bool or None (all True).
-        Returns (warped fp32 [N,C,H,W], valid bool [N,H,W] | None) on self.device."""
+        Returns (warped fp32 [N,C,H,W], valid bool [N,H,W] | None) on self.device.
+        `flow_sign` / `data_sign` = -1 (forward flows only) restate `(-self)` as the warper / `-t` as the target inside the
+        kernel (exact negations; finiteness and zero tests do not depend on the sign), so that switch_ref / invert need
+        no negated copy and no second flag reduction."""
         if self._ref == 's' and not get_pure_pytorch():
             _griddata_unavailable("Flow.apply(ref='s')")
         self._require_finite("Error applying flow to a target: ")
@@ -474,6 +493,8 @@ class Flow(object):
             # apply_flow's early exit (utils.py:497-498): every |component| < 1e-3 -> the target (and its mask
             # channel) pass through unchanged; batch broadcasting as in flow_class.py:895-898, 922-934
             warped = t.to(torch.float).to(self._device)
+            if data_sign != 1.0:
+                warped = warped * data_sign
             valid = None
             if need_valid:
                 valid = torch.ones((t.shape[0],) + tuple(t.shape[2:]), dtype=torch.bool, device=self._device) \
@@ -496,7 +517,8 @@ class Flow(object):
         else:
             warped, valid, _, _ = _native.splat_fwd(self._vecs, t, weight_mask=self._mask if consider_mask else None,
                                                     chan_mask_a=tmask, chan_mask_b=self._mask,
-                                                    want_valid=need_valid, occlude=True, round_mode=round_mode)
+                                                    want_valid=need_valid, occlude=True, round_mode=round_mode,
+                                                    flow_sign=flow_sign, data_sign=data_sign)
         return warped.to(self._device), (None if valid is None else valid.to(self._device))
 
     # ------------------------------------------------------------------------------------------
@@ -505,7 +527,7 @@ class Flow(object):
     def switch_ref(self, mode: str = None) -> FlowAlias:
         mode = 'valid' if mode is None else mode
         if mode == 'invalid':
-            return Flow._wrap(self._vecs, 't' if self._ref == 's' else 's', self._mask, self._device)
+            return Flow._wrap(self._vecs, 't' if self._ref == 's' else 's', self._mask, self._device, like=self)
         if mode != 'valid':
             raise ValueError("Error switching flow reference: Mode not recognised, should be 'valid' or 'invalid'")
         if self._all_zero(_native.FLAG_NZ_MASKED):                                   # flow_class.py:1046
@@ -514,18 +536,26 @@ class Flow(object):
             out = self.apply(self)                                                    # one splat: P(f, f||[m], m)
             out._ref = 't'
             return out
-        as_s = self.switch_ref(mode='invalid')
-        return (-as_s).apply(as_s)                                                    # one splat: P(-f, f||[m], m)
+        # (-as_s).apply(as_s) with as_s = this flow read as 's' (flow_class.py:1060-1062): one splat P(-f, f||[m], m),
+        # the negation folded into the kernel's end points
+        warped, valid = self.switch_ref(mode='invalid')._warp(self._vecs, self._mask, True, True, flow_sign=-1.0)
+        return Flow._wrap(warped, 's', valid, self._device)
 
     def invert(self, ref: str = None) -> FlowAlias:
         ref = self._ref if ref is None else get_valid_ref(ref)
         if self._ref == 's':
-            if ref == 's':
-                return self.apply(-self)
-            return Flow._wrap(self._vecs * -1.0, 't', self._mask, self._device)
+            if ref == 's':                                      # self.apply(-self): P(f, -f||[m], m)
+                warped, valid = self._warp(self._vecs, self._mask, True, True, data_sign=-1.0)
+                return Flow._wrap(warped, 's', valid, self._device)
+            return self._negated('t')
         if ref == 's':
-            return Flow._wrap(self._vecs * -1.0, 's', self._mask, self._device)
-        return self.invert('s').switch_ref()
+            return self._negated('s')
+        # self.invert('s').switch_ref(): with g = -f read as 's', g.apply(g) = P(-f, -f||[m], m)   (flow_class.py:1084-1086)
+        if self._all_zero(_native.FLAG_NZ_MASKED):              # switch_ref's early exit (:1046) on g
+            return self._negated('t')
+        warped, valid = Flow._wrap(self._vecs, 's', self._mask, self._device, like=self)._warp(
+            self._vecs, self._mask, True, True, flow_sign=-1.0, data_sign=-1.0)
+        return Flow._wrap(warped, 't', valid, self._device)
 
     # ------------------------------------------------------------------------------------------
     # valid areas (flow_class.py:1088-1172)
