@@ -653,13 +653,29 @@ class Flow(object):
         if mode == 1:
             if ref == 's':                                                           # :1759-1760
                 flow_inv_t = flow.invert('t')
-                return flow - (flow_inv_t + flow_inv_t.apply(self.switch_ref())).apply(self)
+                # flow - (flow_inv_t + flow_inv_t.apply(self.switch_ref())).apply(self): the inner sum is the fused mode-3
+                # launch, the outer difference the epilogue of the second gather
+                return flow._minus_applied(self.switch_ref()._combine3(flow_inv_t), self)
             return self.invert().apply(flow - self)                                  # :1763
         if ref == 's':                                                               # mode 2, :1768
             return self.apply(flow - self)
         if not get_pure_pytorch():
             _griddata_unavailable("combine_with(mode=2, ref='t')")
-        return flow - flow.apply(self.invert().apply(self))                          # :1773
+        return flow._minus_applied(flow, self.invert().apply(self))                  # :1773  flow - flow.apply(...)
+
+    def _minus_applied(self, warper: FlowAlias, target: FlowAlias) -> FlowAlias:
+        """self - warper.apply(target) for a 't'-referenced `warper` and a flow `target`: one launch, the subtraction is
+        the gather's epilogue (1 * self + (-1) * G: the same fp32 operation as the reference's `-`); masks AND as in
+        flow_class.py:490-531 / 921-934.  The thresholded early exit of `apply` takes the plain path."""
+        if warper._ref != 't' or warper._all_zero(_native.FLAG_NZ_THR) or self.shape[0] != warper.shape[0] \
+                or target.shape[0] != warper.shape[0]:
+            return self - warper.apply(target)
+        warper._require_finite("Error applying flow to a target: ")
+        vecs, valid, _, _ = _native.warp_bwd(warper._vecs, target._vecs, src_mask=target._mask, flow_mask=warper._mask,
+                                             want_valid=True, addend=self._vecs, a_sign=1.0, g_sign=-1.0)
+        if self._mask is not None and self._mask is not warper._mask:
+            valid = valid & self._mask
+        return Flow._wrap(vecs, self._ref, valid, self._device)
 
     def _combine3(self, flow: FlowAlias, speculative: bool = False) -> FlowAlias:
         """mode 3: 't'  f3 = f2 + G(f2, f1),  m3 = m2 & theta(G(f2, [m1]))           (flow_class.py:1808)
