@@ -163,6 +163,9 @@ int ofl_splat_finalize_f32(const float* accum,
  *                  (24 bytes x 1.5 records per pixel; the batch is processed in equal passes so that it stays under ~4 GiB);
  *                  contents irrelevant on entry; afterwards workspace[0] = 1 if the launch fell back to the two-pass
  *                  path, workspace[1] = number of tiles that left the exact path
+ *   dst_flags      optional int32[N] (C == 2 only, else OFL_E_ARG; zeroed in-stream): the flag word (see
+ *                  ofl_flow_flags_f32) of the OUTPUT read as a flow under its `valid` mask -- a by-product that spares
+ *                  the caller the validation pass (utils.py:98, flow_class.py:1226-1244) over an intermediate flow
  *   accum_fallback fp32[ofl_splat_tiled_pass_images(n, h, w) * (1 + C + with_mask_chan) * H * W]  (one pass of the batch)
  *                  used (and zeroed in-stream) only when the record pool
  *                  overflows (> 1.5 records per pixel on average) or a 32 x 16 source tile spreads over > 48 destination
@@ -181,6 +184,7 @@ int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
                         const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
                         int32_t with_mask_chan, int32_t occlude,
                         float* dst, float* density, uint8_t* warped, uint8_t* valid, float* mask_chan,
+                        int32_t* dst_flags,
                         int32_t* workspace, int64_t workspace_ints, float* accum_fallback,
                         int32_t n, int32_t c, int32_t h, int32_t w,
                         int32_t round_mode, void* stream);

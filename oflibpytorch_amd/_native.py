@@ -55,7 +55,7 @@ def load_library(path: str = None):
     lib.ofl_splat_tiled_workspace_ints.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_pass_images.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
-                                        p, i64, p, i32, i32, i32, i32, i32, p]
+                                        p, p, i64, p, i32, i32, i32, i32, i32, p]
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
     lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
@@ -178,15 +178,18 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
               chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False,
-              round_mode=ROUND_NONE, want_mask_chan=False):
-    """P-family kernels (ofl_splat_fwd_f32 + ofl_splat_finalize_f32).
+              round_mode=ROUND_NONE, want_mask_chan=False, want_dst_flags=False):
+    """P-family kernels (ofl_splat_tiled_f32, or ofl_splat_fwd_f32 + ofl_splat_finalize_f32).
 
     Either flow [Nf,2,H,W] (endpoints computed in-kernel) or explicit positions xs, ys [N,H,W].
     Returns (dst [N,C,H,W], valid | None, density | None, warped | None) on the HIP device; with
     `want_mask_chan` the valid slot holds the warped mask channel itself (fp32) instead of its threshold.
+    `want_dst_flags` (2-channel data): a fifth result, the device flag words int32[N] of dst read as a flow under `valid`.
     """
     lib, dev = load_library(), device()
     c, h, w = data.shape[1:]
+    if want_dst_flags and c != 2:
+        raise ValueError("oflibpytorch_amd: output flags are defined for 2-channel data only")
     n = max(data.shape[0], 1 if flow is None else flow.shape[0], 1 if xs is None else xs.shape[0],
             1 if weight_mask is None else weight_mask.shape[0], 1 if chan_mask_a is None else chan_mask_a.shape[0],
             1 if chan_mask_b is None else chan_mask_b.shape[0])
@@ -208,6 +211,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     mchan = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_mask_chan else None
     density = torch.empty((n, h, w), dtype=torch.float32, device=dev) if want_density else None
     warped = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_warped else None
+    dflags = torch.empty((n,), dtype=torch.int32, device=dev) if want_dst_flags else None
     rc = -4
     if _splat_path != 1 and w >= 4:
         # fused tiled path: LDS accumulation per destination tile; `accum` is only touched if the flow is too rough
@@ -215,8 +219,8 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
         accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
         rc = lib.ofl_splat_tiled_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
                                      float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
-                                     _ptr(dst), _ptr(density), _ptr(warped), _ptr(valid), _ptr(mchan), _ptr(ws),
-                                     ws.numel(), _ptr(accum), n, c, h, w, int(round_mode), st)
+                                     _ptr(dst), _ptr(density), _ptr(warped), _ptr(valid), _ptr(mchan), _ptr(dflags),
+                                     _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, int(round_mode), st)
         if rc not in (0, -4):
             _check(rc, "ofl_splat_tiled_f32")
         if collect_splat_stats:             # (a copy: a view would keep the whole workspace alive between calls)
@@ -231,4 +235,8 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
                                           _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ, _ptr(dst), _ptr(density),
                                           _ptr(warped), _ptr(valid), _ptr(mchan), n, c, h, w, int(round_mode), st),
                "ofl_splat_finalize_f32")
+        if want_dst_flags:
+            dflags = flow_flags(dst, valid)
+    if want_dst_flags:
+        return dst, (mchan if want_mask_chan else valid), density, warped, dflags
     return dst, (mchan if want_mask_chan else valid), density, warped

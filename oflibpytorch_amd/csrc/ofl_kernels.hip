@@ -64,6 +64,15 @@ __device__ __forceinline__ int wave_or_flags(int f) {
     return r;
 }
 
+// OR a wave's flag word into a per-image word that thousands of waves share: same-address atomics serialise in L2
+// (~8 ns each), and the word saturates after the first few tiles -- so look first (a load served by L2, never by the
+// CU's own L1) and only send the atomic when it would change something.
+__device__ __forceinline__ void flag_or(int32_t* addr, int f) {
+    if (f == 0) return;
+    const int cur = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((cur | f) != cur) atomicOr(addr, f);
+}
+
 // XCD-aware block -> logical tile id: hardware deals blocks round-robin over the 8 XCDs, so block b
 // and b+8 share an L2.  Give every XCD one contiguous range of logical tiles (speed only).
 __device__ __forceinline__ int64_t logical_block(int64_t per_xcd) {
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
             if (inB) f |= flag_bits(uB[k], vB[k], ((fmB >> (8 * k)) & 0xffu) != 0u);
         }
         f = wave_or_flags(f);
-        if ((tid & 63) == 0 && f) atomicOr(&p.flow_flags[n], f);
+        if ((tid & 63) == 0) flag_or(&p.flow_flags[n], f);
     }
     f4* lds = reinterpret_cast<f4*>(smem);
     LdsCoords TA, TB;
@@ -681,10 +690,10 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const WarpParams p) {
 
     if (FLAGS) {
         fflags = wave_or_flags(fflags);
-        if (lane == 0 && fflags) atomicOr(&p.flow_flags[n], fflags);
+        if (lane == 0) flag_or(&p.flow_flags[n], fflags);
         if (p.src_flags) {
             sflags = wave_or_flags(sflags);
-            if (lane == 0 && sflags) atomicOr(&p.src_flags[n], sflags);
+            if (lane == 0) flag_or(&p.src_flags[n], sflags);
         }
     }
 }
@@ -708,6 +717,7 @@ struct SplatParams {
     int32_t tiles_x, tiles_y;
     int64_t total_tiles, per_xcd;
     const int32_t* run_if_set;   // optional device flag: the atomics path runs only when *run_if_set != 0
+    int32_t* dst_flags;          // optional int32[N] (2-channel data only): flag word of the OUTPUT read as a flow under `valid`
 };
 
 template <int CT>
@@ -813,6 +823,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
     const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
     const float* __restrict__ acc = p.accum + (int64_t)n * planes * hw;
     float* __restrict__ dst = p.dst + (int64_t)n * p.dst_bs;
+    int dflags = 0;
 
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
@@ -829,23 +840,33 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
             const bool wm = wmk ? (wmk[pix] != 0) : true;
             fill = zero && wm;
         }
+        float uv[2] = {0.0f, 0.0f};
 #pragma unroll
         for (int ch = 0; ch < (CT ? CT : 1); ++ch)
             for (int cc = ch; cc < C; cc += (CT ? C : 1)) {
                 float val = fill ? p.data_sign * db[(int64_t)cc * hw + pix] : acc[(int64_t)(1 + cc) * hw + pix] / dcl;
-                dst[(int64_t)cc * hw + pix] = apply_round(val, p.round_mode);
+                val = apply_round(val, p.round_mode);
+                dst[(int64_t)cc * hw + pix] = val;
+                if (cc < 2) uv[cc] = val;
             }
         if (p.density) p.density[(int64_t)n * hw + pix] = den;
         if (p.warped) p.warped[(int64_t)n * hw + pix] = (uint8_t)warped;
+        bool vld = true;
         if (p.valid || p.mask_chan) {
             float mch;
             if (fill)
                 mch = ((cma ? cma[pix] != 0 : true) && (cmb ? cmb[pix] != 0 : true)) ? 1.0f : 0.0f;
             else
                 mch = (den - acc[(int64_t)(1 + C) * hw + pix]) / dcl;
-            if (p.valid) p.valid[(int64_t)n * hw + pix] = (uint8_t)(mch > kValidThr);
+            vld = mch > kValidThr;
+            if (p.valid) p.valid[(int64_t)n * hw + pix] = (uint8_t)vld;
             if (p.mask_chan) p.mask_chan[(int64_t)n * hw + pix] = mch;
         }
+        if (p.dst_flags) dflags |= flag_bits(uv[0], uv[1], vld);
+    }
+    if (p.dst_flags) {                                   // (block-uniform)
+        dflags = wave_or_flags(dflags);
+        if (lane == 0) flag_or(&p.dst_flags[n], dflags);
     }
 }
 
@@ -1200,6 +1221,13 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
         for (int k = 0; k < 2; ++k)
             fill_ok[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr) && (((wm2 >> (8 * k)) & 0xffu) != 0u);
     }
+    int dflags = 0;
+    auto flush_flags = [&]() {                            // (every thread of the block gets here)
+        if (NC == 2 && s.dst_flags) {
+            dflags = wave_or_flags(dflags);
+            if (lane == 0) flag_or(&s.dst_flags[n], dflags);
+        }
+    };
     // normalise, masks, un-occlude fill, store (tot: density, channels, mask channel)
     auto finalize = [&](const float (&tot)[2][1 + NCH]) {
         f2 den2, out[NC], mch2;
@@ -1226,6 +1254,11 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
                 mch2[k] = mv;
                 valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
             }
+        }
+        if (NC == 2 && s.dst_flags) {                     // the output read as a flow under its valid mask (by-product)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (k == 1 || !solo) dflags |= flag_bits(out[0][k], out[NC - 1][k], MCH ? ((valid2 >> (8 * k)) & 1u) != 0u : true);
         }
         float* __restrict__ dst = s.dst + (int64_t)n * s.dst_bs;
         if (!solo) {
@@ -1421,7 +1454,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
         if (mine) finalize(tot);
         if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
     }
-    if (!over) return;
+    if (!over) { flush_flags(); return; }
     // ---- fallback for this tile (a band of destination rows that more than kSpQ records touch): LDS float atomics,
     // records streamed from the queue (plane 0 density, then the data channels; the mask channel accumulates the INVALID
     // weight so that an all-valid pixel is exactly 1 in any order)
@@ -1452,16 +1485,19 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
         }
     }
     __syncthreads();
-    if (!inimg) return;
-    float tot[2][1 + NCH];
+    dflags = 0;                                           // (bands finalized before the tile left the exact path are overwritten)
+    if (inimg) {
+        float tot[2][1 + NCH];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int d = ly * kSpTW + max(lx2 + k, 0);
+        for (int k = 0; k < 2; ++k) {
+            const int d = ly * kSpTW + max(lx2 + k, 0);
 #pragma unroll
-        for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
-        if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];          // density - invalid weight
+            for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
+            if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];      // density - invalid weight
+        }
+        finalize(tot);
     }
-    finalize(tot);
+    flush_flags();
 }
 
 // zero the fallback accumulator only when the atomics path will run
@@ -1510,7 +1546,7 @@ __global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict
             f |= flag_bits(fu[i], fu[hw + i], mk ? (mk[i] != 0) : true);
     }
     f = wave_or_flags(f);
-    if ((threadIdx.x & 63) == 0 && f) atomicOr(&flags[n], f);
+    if ((threadIdx.x & 63) == 0) flag_or(&flags[n], f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1795,12 +1831,13 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     const float* data, int64_t data_bs, float data_sign, const uint8_t* weight_mask, int64_t weight_mask_bs,
     const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
     int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
-    float* mask_chan, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n, int32_t c,
-    int32_t h, int32_t w, int32_t round_mode, void* stream) {
+    float* mask_chan, int32_t* dst_flags, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n,
+    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream) {
     if (!data || !dst || !workspace || !accum_fallback) return OFL_E_NULL;
     if (!flow && !(xs && ys)) return OFL_E_NULL;
     if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     if ((valid || mask_chan) && !with_mask_chan) return OFL_E_ARG;
+    if (dst_flags && c != 2) return OFL_E_ARG;
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
     TiledParams tp = {};
     unsigned grid_unused;
@@ -1814,6 +1851,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     if (workspace_ints < ofl_splat_tiled_workspace_ints(n, h, w)) return OFL_E_ARG;
     tp.s.flow_sign = flow_sign; tp.s.xs = xs; tp.s.ys = ys; tp.s.xy_bs = xy_bs;
     tp.s.dst = dst; tp.s.density = density; tp.s.warped = warped; tp.s.valid = valid; tp.s.mask_chan = mask_chan;
+    tp.s.dst_flags = dst_flags;
     tp.s.round_mode = round_mode;
     tp.tiles_x = (w + kSpTW - 1) / kSpTW; tp.tiles_y = (h + kSpTH - 1) / kSpTH;
     tp.tiles_img = (uint32_t)(tp.tiles_x * tp.tiles_y);
@@ -1830,6 +1868,10 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(tp.overflow, 0, 4 * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
+    if (dst_flags) {
+        e = hipMemsetAsync(dst_flags, 0, (size_t)n * sizeof(int32_t), st);
+        if (e != hipSuccess) return (int)e;
+    }
     const SplatParams all = tp.s;
     const int64_t hw = (int64_t)h * w;
     // more than 3 channels: groups of 3 (a record holds 3 data channels); density and masks come out of the first group
@@ -1855,6 +1897,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
         if (q.warped) q.warped = full.warped + n0 * hw;
         if (q.valid) q.valid = full.valid + n0 * hw;
         if (q.mask_chan) q.mask_chan = full.mask_chan + n0 * hw;
+        if (q.dst_flags) q.dst_flags = full.dst_flags + n0;
         tp.total = (int64_t)tp.tiles_img * nn;
         tp.per_xcd = (tp.total + kXcds - 1) / kXcds;
         e = hipMemsetAsync(tp.counts, 0, (size_t)ctiles * 3 * sizeof(int32_t), st);      // counts | offsets | cursor

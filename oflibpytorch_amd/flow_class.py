@@ -57,11 +57,13 @@ class Flow(object):
         obj = cls.__new__(cls)
         obj._vecs, obj._ref, obj._mask = vecs, ref, mask
         obj._device = vecs.device if device is None else device
-        obj._flag_cache, obj._pending_flags = None, flags
+        obj._flag_cache, obj._pending_flags = None, None
         if obj._vecs.device != obj._device:
             obj._vecs = obj._vecs.to(obj._device)
         if obj._mask is not None and obj._mask.device != obj._device:
             obj._mask = obj._mask.to(obj._device)
+        if flags is not None:
+            obj._set_pending_flags(flags)
         if like is not None:
             obj._inherit_flags(like)
         return obj
@@ -460,16 +462,17 @@ class Flow(object):
         rm = _native.ROUND_NONE
         if not return_flow and not return_dtype.is_floating_point:
             rm = _native.ROUND_U8 if return_dtype == torch.uint8 else _native.ROUND_RINT
-        warped, valid = flow._warp(t, tmask, need_valid, consider_mask, rm)
+        warped, valid, dflags = flow._warp(t, tmask, need_valid, consider_mask, rm)
 
         if padding is not None and cut:
             win = (slice(padding[0], padding[0] + self.shape[1]), slice(padding[2], padding[2] + self.shape[2]))
             warped = warped[..., win[0], win[1]]
             if valid is not None:
                 valid = valid[..., win[0], win[1]]
+            dflags = None                                # (they describe the whole padded frame)
 
         if return_flow:
-            return Flow._wrap(warped, target._ref, valid, self._device)
+            return Flow._wrap(warped, target._ref, valid, self._device, flags=dflags)
         if not return_dtype.is_floating_point:
             if not get_pure_pytorch():
                 warped = warped.to(return_dtype)         # PURE_PYTORCH keeps the rounded values as floats (:943-949)
@@ -509,17 +512,23 @@ class Flow(object):
                 warped = torch.round(warped)
                 if round_mode == _native.ROUND_U8:
                     warped = torch.clamp(warped, 0, 255)
-            return warped, valid
+            return warped, valid, None
+        dflags = None
         if self._ref == 't':
             warped, valid, _, _ = _native.warp_bwd(self._vecs, t, src_mask=tmask,
                                                    flow_mask=self._mask if need_valid else None,
                                                    want_valid=need_valid, round_mode=round_mode)
         else:
-            warped, valid, _, _ = _native.splat_fwd(self._vecs, t, weight_mask=self._mask if consider_mask else None,
-                                                    chan_mask_a=tmask, chan_mask_b=self._mask,
-                                                    want_valid=need_valid, occlude=True, round_mode=round_mode,
-                                                    flow_sign=flow_sign, data_sign=data_sign)
-        return warped.to(self._device), (None if valid is None else valid.to(self._device))
+            # a warped FLOW (2 channels, with its valid mask) brings its flag word along: the splat produces it as a
+            # by-product, so that using the result as a warper needs no validation pass of its own
+            want_f = need_valid and t.shape[1] == 2 and round_mode == 0
+            res = _native.splat_fwd(self._vecs, t, weight_mask=self._mask if consider_mask else None,
+                                    chan_mask_a=tmask, chan_mask_b=self._mask,
+                                    want_valid=need_valid, occlude=True, round_mode=round_mode,
+                                    flow_sign=flow_sign, data_sign=data_sign, want_dst_flags=want_f)
+            warped, valid = res[0], res[1]
+            dflags = res[4] if want_f else None
+        return warped.to(self._device), (None if valid is None else valid.to(self._device)), dflags
 
     # ------------------------------------------------------------------------------------------
     # switch_ref / invert (flow_class.py:1022-1086)
@@ -538,24 +547,24 @@ class Flow(object):
             return out
         # (-as_s).apply(as_s) with as_s = this flow read as 's' (flow_class.py:1060-1062): one splat P(-f, f||[m], m),
         # the negation folded into the kernel's end points
-        warped, valid = self.switch_ref(mode='invalid')._warp(self._vecs, self._mask, True, True, flow_sign=-1.0)
-        return Flow._wrap(warped, 's', valid, self._device)
+        warped, valid, dflags = self.switch_ref(mode='invalid')._warp(self._vecs, self._mask, True, True, flow_sign=-1.0)
+        return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
 
     def invert(self, ref: str = None) -> FlowAlias:
         ref = self._ref if ref is None else get_valid_ref(ref)
         if self._ref == 's':
             if ref == 's':                                      # self.apply(-self): P(f, -f||[m], m)
-                warped, valid = self._warp(self._vecs, self._mask, True, True, data_sign=-1.0)
-                return Flow._wrap(warped, 's', valid, self._device)
+                warped, valid, dflags = self._warp(self._vecs, self._mask, True, True, data_sign=-1.0)
+                return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
             return self._negated('t')
         if ref == 's':
             return self._negated('s')
         # self.invert('s').switch_ref(): with g = -f read as 's', g.apply(g) = P(-f, -f||[m], m)   (flow_class.py:1084-1086)
         if self._all_zero(_native.FLAG_NZ_MASKED):              # switch_ref's early exit (:1046) on g
             return self._negated('t')
-        warped, valid = Flow._wrap(self._vecs, 's', self._mask, self._device, like=self)._warp(
+        warped, valid, dflags = Flow._wrap(self._vecs, 's', self._mask, self._device, like=self)._warp(
             self._vecs, self._mask, True, True, flow_sign=-1.0, data_sign=-1.0)
-        return Flow._wrap(warped, 't', valid, self._device)
+        return Flow._wrap(warped, 't', valid, self._device, flags=dflags)
 
     # ------------------------------------------------------------------------------------------
     # valid areas (flow_class.py:1088-1172)

@@ -75,7 +75,7 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
               chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False, round_mode=0,
-              want_mask_chan=False):
+              want_mask_chan=False, want_dst_flags=False):
     d = _np(data, np.float32) * np.float32(data_sign)
     n = max(d.shape[0], 1 if flow is None else flow.shape[0], 1 if xs is None else xs.shape[0],
             1 if weight_mask is None else weight_mask.shape[0], 1 if chan_mask_a is None else chan_mask_a.shape[0],
@@ -98,5 +98,8 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     valid = torch.tensor(oracle.theta(out[:, c])) if want_valid else None
     if want_mask_chan:
         valid = torch.tensor(out[:, c].copy())
-    return (torch.tensor(_round(out[:, :c], round_mode)), valid,
-            torch.tensor(den) if want_density else None, torch.tensor(warped) if want_warped else None)
+    res = (torch.tensor(_round(out[:, :c], round_mode)), valid,
+           torch.tensor(den) if want_density else None, torch.tensor(warped) if want_warped else None)
+    if want_dst_flags:
+        res = res + (flow_flags(res[0], valid if want_valid and not want_mask_chan else None),)
+    return res

@@ -374,6 +374,41 @@ def test_a_fold_beyond_the_list_limit_falls_back_per_tile(dev):
     np.testing.assert_allclose(outs[0][2].cpu().numpy(), rden, rtol=2e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind", ["smooth", "zero", "tiny", "masked_out", "rough_two_pass", "general_path"])
+def test_splat_output_flags_equal_a_flag_pass_over_the_output(kind, dev):
+    """The routed splat returns the flag word of its OUTPUT (read as a flow under its valid mask) as a by-product; it
+    must equal what ofl_flow_flags_f32 computes from the stored tensors -- on the exact path, on the per-tile and
+    launch-level fallbacks and on the general two-pass path."""
+    from oflibpytorch_amd import _native
+    n, h, w = 3, 70, 132
+    flow = _smooth(n, h, w, 1.5, 9, dev)
+    data = _smooth(n, h, w, 3.0, 10, dev)
+    g = torch.Generator().manual_seed(5)
+    wm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    ca = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    if kind == "zero":
+        data = torch.zeros_like(data)
+    elif kind == "tiny":
+        data = data * 1e-5                                   # non-zero, but below the 1e-3 threshold
+    elif kind == "masked_out":
+        data[1] = 0
+        ca[0] = False                                        # nothing valid in image 0, all-zero vectors in image 1
+    elif kind == "rough_two_pass":
+        flow = _smooth(n, h, w, 400.0, 9, dev)               # source tiles spread too wide: launch-level fallback
+    try:
+        if kind == "general_path":
+            _native.set_splat_path(1)
+        out = _native.splat_fwd(flow, data, weight_mask=wm, chan_mask_a=ca, want_valid=True, want_dst_flags=True)
+    finally:
+        _native.set_splat_path(0)
+    expect = _native.flow_flags(out[0], out[1])
+    assert out[4].cpu().tolist() == expect.cpu().tolist()
+    if kind == "zero":
+        assert all((f & _native.FLAG_NZ) == 0 for f in out[4].cpu().tolist())
+    if kind == "tiny":
+        assert all((f & _native.FLAG_NZ) != 0 and (f & _native.FLAG_NZ_THR) == 0 for f in out[4].cpu().tolist())
+
+
 @pytest.mark.parametrize("rough", [False, True])
 def test_routed_splat_in_several_passes(rough, dev):
     """n = 5 images, at most 2 per pass: the passes re-use the queues; with a rough flow the launch-level two-pass fallback
