@@ -89,6 +89,8 @@ int ofl_set_option(int32_t key, int32_t value);
  *           ofl_flow_flags_f32) of the `flow` operand (with flow_mask) and, when C == 2 and
  *           src is itself a flow field, of `src` (with src_mask), OR-ed in as a by-product of the
  *           same pass.  The caller zeroes them beforehand.
+ * dst_flags: optional int32[N] (C == 2 and `valid` wanted, else OFL_E_ARG; zeroed in-stream): the flag word of the
+ *           OUTPUT read as a flow under `valid` -- spares the validation pass over an intermediate flow.
  */
 int ofl_warp_bwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
                      const float* src, int64_t src_bs,
@@ -96,7 +98,7 @@ int ofl_warp_bwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
                      const uint8_t* flow_mask, int64_t flow_mask_bs,
                      const float* addend, int64_t addend_bs, float a_sign, float g_sign,
                      float* dst, uint8_t* valid,
-                     int32_t* flow_flags, int32_t* src_flags,
+                     int32_t* flow_flags, int32_t* src_flags, int32_t* dst_flags,
                      int32_t n, int32_t c, int32_t h, int32_t w,
                      int32_t round_mode, void* stream);
 

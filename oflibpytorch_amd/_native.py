@@ -45,7 +45,7 @@ def load_library(path: str = None):
     p, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
     lib.ofl_version.argtypes = []
     lib.ofl_set_option.argtypes = [i32, i32]
-    lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p,
+    lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p, p,
                                      i32, i32, i32, i32, i32, p]
     lib.ofl_splat_fwd_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p,
                                       i32, i32, i32, i32, p]
@@ -150,12 +150,14 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
 
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
-             a_sign=1.0, g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False):
+             a_sign=1.0, g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False,
+             want_dst_flags=False):
     """G-family kernel (include/oflib_hip.h: ofl_warp_bwd_f32).
 
     flow [Nf,2,H,W], src [Ns,C,H,W], masks [*,H,W] bool or None, addend [*,C,H,W] or None.
     Returns (dst [N,C,H,W] fp32, valid [N,H,W] bool | None, flow_flags int32[N] | None, src_flags | None),
-    all on the HIP device, N = max batch.
+    all on the HIP device, N = max batch; with `want_dst_flags` (2 channels, valid wanted) a fifth result: the flag
+    words int32[N] of dst read as a flow under `valid`.
     """
     lib, dev = load_library(), device()
     c, h, w = src.shape[1:]
@@ -170,9 +172,12 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
     valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
     ff = torch.zeros(n, dtype=torch.int32, device=dev) if want_flags else None
     sf = torch.zeros(n, dtype=torch.int32, device=dev) if (want_flags and want_src_flags) else None
+    df = torch.empty(n, dtype=torch.int32, device=dev) if want_dst_flags else None
     _check(lib.ofl_warp_bwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(s), sbs, _ptr(sm), smbs, _ptr(fm), fmbs,
                                 _ptr(ad), adbs, float(a_sign), float(g_sign), _ptr(dst), _ptr(valid), _ptr(ff),
-                                _ptr(sf), n, c, h, w, int(round_mode), _stream(dev)), "ofl_warp_bwd_f32")
+                                _ptr(sf), _ptr(df), n, c, h, w, int(round_mode), _stream(dev)), "ofl_warp_bwd_f32")
+    if want_dst_flags:
+        return dst, valid, ff, sf, df
     return dst, valid, ff, sf
 
 

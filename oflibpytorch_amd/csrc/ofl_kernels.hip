@@ -91,6 +91,7 @@ struct WarpParams {
     const float* addend; int64_t addend_bs;
     float* dst; uint8_t* valid;
     int32_t* flow_flags; int32_t* src_flags;
+    int32_t* dst_flags;              // optional (LDS path, 2 channels): flag word of the output read as a flow under `valid`
     int32_t n, c, h, w;
     float flow_sign, a_sign, g_sign;
     int32_t round_mode;
@@ -495,23 +496,25 @@ __device__ __forceinline__ void lds_load_addend(const WarpParams& p, int tx, int
 }
 
 // step 4b: valid mask, epilogue (a_sign * addend + g_sign * G, rounding), 16-byte stores
-template <int NC, bool VALID, bool ADD>
+template <int NC, bool VALID, bool ADD, bool DF = false>
 __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, int n, uint32_t hw, uint32_t fmask4,
-                                          const f4 (&outv)[4], const f4 (&addend)[NC]) {
+                                          const f4 (&outv)[4], const f4 (&addend)[NC], int* dflags = nullptr) {
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const int w = p.w, h = p.h;
     const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
     const bool inb = (x4 < w) && (y < h);
     const uint32_t pix = (uint32_t)(min(y, h - 1) * w + min(x4, w - 4));
     if (inb) {
+        uint32_t vo = 0x01010101u;
         if (VALID) {
-            uint32_t vo = 0;
+            vo = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
             st32(p.valid + (int64_t)n * hw + pix, vo);
         }
         float* __restrict__ db = p.dst + (int64_t)n * p.dst_bs;
+        f4 o01[2];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
@@ -521,11 +524,16 @@ __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, i
                 for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], p.round_mode);
             }
             st4(db + c * hw + pix, o);
+            if (DF && c < 2) o01[c] = o;
+        }
+        if (DF && NC == 2) {                               // flag word of the OUTPUT read as a flow under `valid` (by-product)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *dflags |= flag_bits(o01[0][k], o01[NC - 1][k], ((vo >> (8 * k)) & 0xffu) != 0u);
         }
     }
 }
 
-template <int NC, bool VALID, bool ADD>
+template <int NC, bool VALID, bool ADD, bool DF = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParams p) {
     constexpr int NW = kLdsNT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -583,14 +591,19 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     lds_gather<NC, VALID>(p, hw, sb, sm, TA, BA, smem, outv);
     if (EARLY && haveB) { if (reuse) { aB[0] = uB; aB[NC - 1] = vB; } else lds_load_addend<NC>(p, tx, tyB, n, hw, aB); }
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyA, n, hw, aA);
-    lds_store<NC, VALID, ADD>(p, tx, tyA, n, hw, fmA, outv, aA);
-    if (!haveB) return;
+    int dflags = 0;
+    lds_store<NC, VALID, ADD, DF>(p, tx, tyA, n, hw, fmA, outv, aA, &dflags);
+    if (!haveB) {
+        if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
+        return;
+    }
     lds_barrier();
     lds_write<NC, VALID>(lds, BB, S);
     lds_barrier();
     lds_gather<NC, VALID>(p, hw, sb, sm, TB, BB, smem, outv);
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
-    lds_store<NC, VALID, ADD>(p, tx, tyB, n, hw, fmB, outv, aB);
+    lds_store<NC, VALID, ADD, DF>(p, tx, tyB, n, hw, fmB, outv, aB, &dflags);
+    if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
 }
 
 // CT = compile-time channel count (0: run-time p.c)
@@ -1592,6 +1605,11 @@ int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 
 template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     const bool valid = p.valid != nullptr, add = p.addend != nullptr;
+    if (NC == 2 && p.dst_flags) {                          // (host: only with a valid mask)
+        if (add) hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, true, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+        else hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+        return (int)hipGetLastError();
+    }
 #define OFL_LAUNCH_L(V, A)                                                                                       \
     if (valid == V && add == A) {                                                                                \
         hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, V, A>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);          \
@@ -1662,19 +1680,20 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
     const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
     const float* addend, int64_t addend_bs, float a_sign, float g_sign, float* dst, uint8_t* valid,
-    int32_t* flow_flags, int32_t* src_flags, int32_t n, int32_t c, int32_t h, int32_t w, int32_t round_mode,
-    void* stream) {
+    int32_t* flow_flags, int32_t* src_flags, int32_t* dst_flags, int32_t n, int32_t c, int32_t h, int32_t w,
+    int32_t round_mode, void* stream) {
     if (!flow || !src || !dst) return OFL_E_NULL;
     int rc = check_dims(n, c, h, w);
     if (rc) return rc;
     if (src_flags && (c != 2 || !flow_flags)) return OFL_E_ARG;
+    if (dst_flags && (c != 2 || !valid)) return OFL_E_ARG;
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
     if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     WarpParams p;
     p.flow = flow; p.flow_bs = flow_bs; p.src = src; p.src_bs = src_bs;
     p.src_mask = src_mask; p.src_mask_bs = src_mask_bs; p.flow_mask = flow_mask; p.flow_mask_bs = flow_mask_bs;
     p.addend = addend; p.addend_bs = addend_bs; p.dst = dst; p.valid = valid;
-    p.flow_flags = flow_flags; p.src_flags = src_flags;
+    p.flow_flags = flow_flags; p.src_flags = src_flags; p.dst_flags = nullptr;
     p.n = n; p.c = c; p.h = h; p.w = w;
     p.flow_sign = flow_sign; p.a_sign = a_sign; p.g_sign = g_sign; p.round_mode = round_mode;
     p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
@@ -1686,6 +1705,10 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.dst_bs = (int64_t)c * h * w;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
+    if (dst_flags) {
+        hipError_t e = hipMemsetAsync(dst_flags, 0, (size_t)n * sizeof(int32_t), st);
+        if (e != hipSuccess) return (int)e;
+    }
     // LDS-staged fast path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit box coordinates (any width:
     // 16-byte accesses at 4-byte alignment, mask bytes at any alignment)
     const bool lds_ok = g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760;
@@ -1695,6 +1718,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
             launch_flow_flags(src, src_bs, src_mask, src_mask_bs, src_flags, n, hw, st);
             p.src_flags = nullptr;
         }
+        p.dst_flags = dst_flags;                                             // a by-product of the staged kernel (c == 2: one group)
         const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
         // more than 3 channels: groups of 3 (the staged box holds 3 channels + the mask channel); the valid mask and the
         // flow flags come out of the first group
@@ -1716,12 +1740,15 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     }
     const unsigned grid = warp_geometry(p, kTileW, kTileH);
     switch (c) {
-        case 1: return launch_warp<1>(p, grid, st);
-        case 2: return launch_warp<2>(p, grid, st);
-        case 3: return launch_warp<3>(p, grid, st);
-        case 4: return launch_warp<4>(p, grid, st);
-        default: return launch_warp<0>(p, grid, st);
+        case 1: rc = launch_warp<1>(p, grid, st); break;
+        case 2: rc = launch_warp<2>(p, grid, st); break;
+        case 3: rc = launch_warp<3>(p, grid, st); break;
+        case 4: rc = launch_warp<4>(p, grid, st); break;
+        default: rc = launch_warp<0>(p, grid, st); break;
     }
+    if (rc == OFL_OK && dst_flags)                                            // generic kernel: a reduction over the output
+        launch_flow_flags(dst, (int64_t)2 * h * w, valid, (int64_t)h * w, dst_flags, n, (int64_t)h * w, st);
+    return rc;
 }
 
 static int fill_splat(SplatParams& p, const float* flow, int64_t flow_bs, const float* data, int64_t data_bs,

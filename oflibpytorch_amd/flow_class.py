@@ -664,7 +664,7 @@ class Flow(object):
                 flow_inv_t = flow.invert('t')
                 # flow - (flow_inv_t + flow_inv_t.apply(self.switch_ref())).apply(self): the inner sum is the fused mode-3
                 # launch, the outer difference the epilogue of the second gather
-                return flow._minus_applied(self.switch_ref()._combine3(flow_inv_t), self)
+                return flow._minus_applied(self.switch_ref()._combine3(flow_inv_t, result_is_warper=True), self)
             return self.invert().apply(flow - self)                                  # :1763
         if ref == 's':                                                               # mode 2, :1768
             return self.apply(flow - self)
@@ -686,7 +686,7 @@ class Flow(object):
             valid = valid & self._mask
         return Flow._wrap(vecs, self._ref, valid, self._device)
 
-    def _combine3(self, flow: FlowAlias, speculative: bool = False) -> FlowAlias:
+    def _combine3(self, flow: FlowAlias, speculative: bool = False, result_is_warper: bool = False) -> FlowAlias:
         """mode 3: 't'  f3 = f2 + G(f2, f1),  m3 = m2 & theta(G(f2, [m1]))           (flow_class.py:1808)
                    's'  f3 = f1 + G(-f1, f2), m3 = m1 & theta(G(-f1, [m2]))          (flow_class.py:1804)"""
         if self._ref == 't':
@@ -696,12 +696,14 @@ class Flow(object):
         if not speculative and warper._all_zero(_native.FLAG_NZ_THR):
             # apply_flow's thresholded early exit inside .apply (utils.py:497): the gather is the identity
             return warper + Flow._wrap(src._vecs, src._ref, src._and_masks(warper._mask), self._device)
-        vecs, valid, wf, sf = _native.warp_bwd(warper._vecs, src._vecs, flow_sign=sign, src_mask=src._mask,
-                                               flow_mask=warper._mask, want_valid=True, addend=warper._vecs,
-                                               want_flags=speculative, want_src_flags=speculative)
+        # (`result_is_warper`: the result will warp something next, so its own flag word is worth the ~5 % it costs here)
+        res = _native.warp_bwd(warper._vecs, src._vecs, flow_sign=sign, src_mask=src._mask,
+                               flow_mask=warper._mask, want_valid=True, addend=warper._vecs,
+                               want_flags=speculative, want_src_flags=speculative, want_dst_flags=result_is_warper)
+        vecs, valid, wf, sf = res[:4]
         if speculative:
             if not warper._flags_known():
                 warper._set_pending_flags(wf)
             if not src._flags_known():
                 src._set_pending_flags(sf)
-        return Flow._wrap(vecs, self._ref, valid, self._device)
+        return Flow._wrap(vecs, self._ref, valid, self._device, flags=res[4] if result_is_warper else None)

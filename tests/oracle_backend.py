@@ -45,7 +45,7 @@ def flow_flags(vecs, mask=None):
 
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
-             a_sign=1.0, g_sign=1.0, round_mode=0, want_flags=False, want_src_flags=False):
+             a_sign=1.0, g_sign=1.0, round_mode=0, want_flags=False, want_src_flags=False, want_dst_flags=False):
     f = _np(flow, np.float32) * np.float32(flow_sign)
     s = _np(src, np.float32)
     n = max(f.shape[0], s.shape[0], 1 if src_mask is None else src_mask.shape[0],
@@ -70,7 +70,10 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
         ff = flow_flags(flow.expand(n, -1, -1, -1), None if flow_mask is None else flow_mask.expand(n, -1, -1))
         if want_src_flags:
             sf = flow_flags(src.expand(n, -1, -1, -1), None if src_mask is None else src_mask.expand(n, -1, -1))
-    return torch.tensor(_round(out, round_mode)), valid, ff, sf
+    res = (torch.tensor(_round(out, round_mode)), valid, ff, sf)
+    if want_dst_flags:
+        res = res + (flow_flags(res[0], valid),)
+    return res
 
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,

@@ -374,6 +374,36 @@ def test_a_fold_beyond_the_list_limit_falls_back_per_tile(dev):
     np.testing.assert_allclose(outs[0][2].cpu().numpy(), rden, rtol=2e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(3, 70, 132), (2, 33, 47), (1, 16, 4), (2, 9, 3)])
+@pytest.mark.parametrize("kind", ["sum", "cancel", "tiny", "generic"])
+def test_warp_output_flags_equal_a_flag_pass_over_the_output(shape, kind, dev):
+    """ofl_warp_bwd_f32's dst_flags (the flag word of a + g * G read as a flow under `valid`) against ofl_flow_flags_f32
+    over the stored output: staged kernel, generic kernel (narrow frames / forced), cancelling and sub-threshold sums."""
+    from oflibpytorch_amd import _native
+    n, h, w = shape
+    flow = _smooth(n, h, w, 1.5, 9, dev)
+    src = _smooth(n, h, w, 3.0, 10, dev)
+    g = torch.Generator().manual_seed(6)
+    sm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    fm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    kw = dict(src_mask=sm, flow_mask=fm, want_valid=True, want_dst_flags=True)
+    if kind == "sum":
+        kw.update(addend=flow)
+    elif kind == "cancel":                                   # src - G(0, src): zero wherever the zero-flow gather is an exact identity
+        src = flow
+        flow = torch.zeros_like(flow)
+        kw.update(addend=src, a_sign=1.0, g_sign=-1.0)
+    elif kind == "tiny":
+        src = src * 1e-5
+    try:
+        if kind == "generic":
+            _native.set_warp_path(1)
+        out = _native.warp_bwd(flow, src, **kw)
+    finally:
+        _native.set_warp_path(0)
+    assert out[4].cpu().tolist() == _native.flow_flags(out[0], out[1]).cpu().tolist()
+
+
 @pytest.mark.parametrize("kind", ["smooth", "zero", "tiny", "masked_out", "rough_two_pass", "general_path"])
 def test_splat_output_flags_equal_a_flag_pass_over_the_output(kind, dev):
     """The routed splat returns the flag word of its OUTPUT (read as a flow under its valid mask) as a by-product; it
