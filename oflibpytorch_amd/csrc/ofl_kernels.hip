@@ -888,26 +888,30 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 // forward splat, routed fast path (ofl_splat_tiled_f32): sort by destination tile, then exact per-tile accumulation
 //
 //  route kernel (run twice: COUNT, then WRITE): one block per 32 x 16 SOURCE tile.  End points of its pixels; every pixel
-//     goes, as a 12-byte record (end point x, y, raster key), to the queue of each DESTINATION tile one of its four
-//     corners falls into (1.1 queues per pixel on smooth flows).  Ranks come from LDS integer atomics per local
-//     destination tile, then ONE global atomic per (source tile, destination tile).  The COUNT run only sizes the
-//     queues; a one-block scan turns the lengths into offsets into one packed record pool; the WRITE run fills it.
+//     goes, as a record of 12 + 4 C bytes (end point x, y | raster key with the mask-channel bit below it | data x
+//     data_sign), to the queue of each DESTINATION tile one of its four corners falls into (1.1 queues per pixel on
+//     smooth flows).  Ranks come from LDS integer atomics per local destination tile, then ONE global atomic per
+//     (source tile, destination tile).  The COUNT run only sizes the queues; a one-block scan turns the lengths into
+//     offsets into one packed record pool; the WRITE run fills it.
 //  tile kernel : one block per 32 x 16 DESTINATION tile.
-//     A  its queue (end point, key, data x data_sign, mask channel: written by the route kernel) -> LDS, 16-byte loads;
-//     B  every (record, corner) with a non-zero weight inside the tile is pushed on the list of its (destination pixel,
-//        corner class): one LDS atomic exchange on the list head;
-//     C  each thread sums the lists of its own 2 destination pixels in registers: per corner class in raster order of
-//        the source pixels (1-2 contributions need no ordering, 3-4 are sorted in registers, up to 12 by repeated
-//        minimum search), then ((c0 + c1) + c2) + c3 -- exactly the order of the reference's four scatter_add_ passes
-//        and its corner sum (utils.py:1133-1143), products rounded before they are added: BIT-IDENTICAL to the
-//        reference, and run to run; normalise, threshold, un-occlude, store.
+//     A  its queue -> LDS, 16-byte loads;
+//     B  every record is pushed on the list of its CELL (the unit square floor(x), floor(y) of its end point): one LDS
+//        atomic exchange.  The four corner classes of destination pixel (X, Y) are the cells (X - kx, Y - ky), so one
+//        list per cell serves them all;
+//     S  every cell is put in raster order of its source pixels once: up to 4 records by a sorting network in registers
+//        (written as four 16-bit slots), 5 .. 64 by an insertion sort of the list itself;
+//     C  each thread sums its own 2 destination pixels in registers: its 3 x 2 cells, every record fetched once and
+//        added, in list order, to each corner-class sum it belongs to, then ((c0 + c1) + c2) + c3 -- exactly the order
+//        of the reference's four scatter_add_ passes and its corner sum (utils.py:1133-1143), products rounded before
+//        they are added: BIT-IDENTICAL to the reference, and run to run; normalise, threshold, un-occlude, store (and,
+//        for flows, the output's flag word as a by-product).
 //     A queue longer than the LDS records (1024) is processed in 2 or 4 bands of destination rows, each band compacting
 //     the records that touch it.
 //  No float atomics, no accumulator in HBM.
-//  Only a fold of the flow (> 12 sources in one corner class of one destination pixel, or > ~3000 records for one tile)
-//  makes THAT tile fall back to LDS float atomics over the same queue (tolerance instead of bit-exactness for that
-//  tile).  The launch-level two-pass path only runs for input the pool cannot hold (> 1.5 records per pixel on average)
-//  or source tiles that spread over > 48 destination tiles.
+//  Only a heavy fold of the flow (> 64 sources in one cell, or more records for one tile than four bands hold) makes
+//  THAT tile fall back to LDS float atomics over the same queue (tolerance instead of bit-exactness for that tile).
+//  The launch-level two-pass path only runs for input the pool cannot hold (> 1.5 records per pixel on average) or
+//  source tiles that spread over > 48 destination tiles.
 // ------------------------------------------------------------------------------------------------
 #ifndef OFL_SP_TH
 #define OFL_SP_TH 16
