@@ -77,6 +77,9 @@ def main():
                 outs.append(_native.warp_bwd(flow, src, **kw))
             finally:
                 _native.set_warp_path(0)
+        if c == 2 and kw.get("want_valid") and not kw.get("round_mode"):
+            rf = _native.warp_bwd(flow, src, want_dst_flags=True, **kw)
+            assert rf[4].cpu().tolist() == _native.flow_flags(rf[0], rf[1]).cpu().tolist(), "warp dst_flags %s %s" % ((n, c, h, w), kind)
         for x, y in zip(*outs):
             assert (x is None) == (y is None)
             if x is not None and not torch.equal(x, y):
@@ -92,6 +95,9 @@ def main():
             skw.update(chan_mask_a=fm, want_mask_chan=True)
         r1 = _native.splat_fwd(flow, data, **skw)
         st = _native._last_splat_stats.cpu().tolist()
+        if c == 2 and "chan_mask_a" not in skw:              # the output's flag word as a by-product == a flag pass over it
+            rf = _native.splat_fwd(flow, data, want_valid=True, want_dst_flags=True, **{k: v for k, v in skw.items() if k not in ("want_density", "want_warped")})
+            assert rf[4].cpu().tolist() == _native.flow_flags(rf[0], rf[1]).cpu().tolist(), "splat dst_flags %s %s" % ((n, c, h, w), kind)
         r2 = _native.splat_fwd(flow, data, **skw)
         _native.set_splat_path(1)
         try:
