@@ -161,17 +161,17 @@ int ofl_splat_finalize_f32(const float* accum,
  * Needs 4 <= W < 32768, H < 32768 (any width: 16-byte accesses at 4-byte alignment; more than 3 channels are
  * processed in groups of 3), else it returns OFL_E_UNSUPPORTED and the caller
  * uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
- *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  queue lengths / offsets + the packed record pool
- *                  (24 bytes x 1.5 records per pixel; the batch is processed in equal passes so that it stays under ~4 GiB);
+ *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  queue lengths, block table and the record queues
+ *                  (fixed addresses: 1024 records of 24 bytes per destination tile + one spare block of 1024 per two
+ *                  tiles, ~72 B/px; the batch is processed in equal passes so that it stays under ~4 GiB);
  *                  contents irrelevant on entry; afterwards workspace[0] = 1 if the launch fell back to the two-pass
- *                  path, workspace[1] = number of tiles that left the exact path
+ *                  path, workspace[1] = number of tiles that left the exact path, workspace[4] = blocks drawn
  *   dst_flags      optional int32[N] (C == 2 only, else OFL_E_ARG; zeroed in-stream): the flag word (see
  *                  ofl_flow_flags_f32) of the OUTPUT read as a flow under its `valid` mask -- a by-product that spares
  *                  the caller the validation pass (utils.py:98, flow_class.py:1226-1244) over an intermediate flow
  *   accum_fallback fp32[ofl_splat_tiled_pass_images(n, h, w) * (1 + C + with_mask_chan) * H * W]  (one pass of the batch)
- *                  used (and zeroed in-stream) only when the record pool
- *                  overflows (> 1.5 records per pixel on average) or a 32 x 16 source tile spreads over > 48 destination
- *                  tiles; the two-pass global-atomics path then runs inside the same call, decided on the device (no
+ *                  used (and zeroed in-stream) only when a queue overflows (> 9216 records for one tile, or the
+ *                  spare blocks run out) or a 32 x 16 source tile spreads over > 48 destination tiles; the two-pass global-atomics path then runs inside the same call, decided on the device (no
  *                  host sync; tolerance instead of bit-exactness).  A heavy fold of the flow (> 64 source pixels
  *                  ending in one unit cell, or more records for one tile than four bands of its rows can hold) makes
  *                  only ITS tile fall back to (LDS) float atomics.

@@ -887,12 +887,12 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 // ------------------------------------------------------------------------------------------------
 // forward splat, routed fast path (ofl_splat_tiled_f32): sort by destination tile, then exact per-tile accumulation
 //
-//  route kernel (run twice: COUNT, then WRITE): one block per 32 x 16 SOURCE tile.  End points of its pixels; every pixel
-//     goes, as a record of 12 + 4 C bytes (end point x, y | raster key with the mask-channel bit below it | data x
-//     data_sign), to the queue of each DESTINATION tile one of its four corners falls into (1.1 queues per pixel on
-//     smooth flows).  Ranks come from LDS integer atomics per local destination tile, then ONE global atomic per
-//     (source tile, destination tile).  The COUNT run only sizes the queues; a one-block scan turns the lengths into
-//     offsets into one packed record pool; the WRITE run fills it.
+//  route kernel: one block per 32 x 16 SOURCE tile.  End points of its pixels; every pixel goes, as a record of
+//     12 + 4 C bytes (end point x, y | raster key with the mask-channel bit below it | data x data_sign), to the queue
+//     of each DESTINATION tile one of its four corners falls into (1.1 queues per pixel on smooth flows).  Ranks come
+//     from LDS integer atomics per local destination tile, then ONE global atomic per (source tile, destination tile) on
+//     the queue's length.  Queues have fixed addresses -- no sizing pass, no scan: 1024 records per tile, then blocks
+//     of 1024 drawn from a shared pool on demand (one compare-and-swap per slot of 1024 queue positions).
 //  tile kernel : one block per 32 x 16 DESTINATION tile.
 //     A  its queue -> LDS, 16-byte loads;
 //     B  every record is pushed on the list of its CELL (the unit square floor(x), floor(y) of its end point): one LDS
@@ -910,8 +910,8 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 //  No float atomics, no accumulator in HBM.
 //  Only a heavy fold of the flow (> 64 sources in one cell, or more records for one tile than four bands hold) makes
 //  THAT tile fall back to LDS float atomics over the same queue (tolerance instead of bit-exactness for that tile).
-//  The launch-level two-pass path only runs for input the pool cannot hold (> 1.5 records per pixel on average) or
-//  source tiles that spread over > 48 destination tiles.
+//  The launch-level two-pass path only runs for input the queues cannot hold (> 9216 records for one tile, or more
+//  blocks drawn than the one per two tiles provisioned) or source tiles that spread over > 48 destination tiles.
 // ------------------------------------------------------------------------------------------------
 #ifndef OFL_SP_TH
 #define OFL_SP_TH 16
@@ -924,6 +924,11 @@ constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // tile kernel: 2 d
 #endif
 constexpr int kSpQ = OFL_SP_Q;    // records the tile kernel holds in LDS at a time (1024 measured faster than 768 + one more block per CU)
 constexpr int kSpRouteMax = 48;   // destination tiles one source tile may feed
+// Queues have fixed addresses (no sizing pass): every destination tile owns kSpPrim records; the records beyond them go to
+// blocks of kSpPrim records drawn from a shared pool on demand, one per slot of kSpPrim queue positions (up to kSpSlots
+// per tile; one block per 2 tiles is provisioned).  More than (1 + kSpSlots) * kSpPrim records for a tile (18 per
+// pixel), or more draws than blocks, send the launch to the two-pass path.
+constexpr int kSpPrim = OFL_SP_Q, kSpSlots = 8, kSpSecDiv = 2;
 #ifndef OFL_SP_LONG
 #define OFL_SP_LONG 64
 #endif
@@ -938,11 +943,12 @@ __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-ze
 
 struct TiledParams {
     SplatParams s;
-    int32_t* counts;       // [n * tiles] queue lengths
-    int32_t* offsets;      // [n * tiles] queue starts in the pool (exclusive scan of counts)
-    int32_t* cursor;       // [n * tiles] fill level during the WRITE run
-    float* pool;           // [3 + C + mask channel][pool_cap]: end point x | end point y | raster key (bits) | data ... | mask channel
-    int64_t pool_cap;
+    int32_t* cursor;       // [n * tiles] records routed to the tile so far (its queue length once the route kernel is done)
+    int32_t* sec;          // [n * tiles][kSpSlots] block that holds queue positions kSpPrim * (1 + slot) .. of the tile, -1 = none
+    float* prim;           // [n * tiles][3 + C][kSpPrim]: end point x | end point y | raster key + mask-channel bit | data ...
+    float* secp;           // [nsec][3 + C][kSpPrim]: the blocks
+    int32_t nsec;
+    int32_t* sec_count;    // [1] secondary blocks drawn in this pass
     int32_t* overflow;     // [4]: launch falls back | tiles that left the exact path | - | -
     int32_t tiles_x, tiles_y;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;
@@ -998,11 +1004,10 @@ __device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4
     }
 }
 
-template <bool WRITE>
 __global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p) {
     __shared__ int red[kSpNT / 64][4];
-    __shared__ int lcount[kSpRouteMax], lbase[kSpRouteMax];
-    if (WRITE && *p.overflow != 0) return;
+    __shared__ int lcount[kSpRouteMax], lbase[kSpRouteMax], lsec[kSpRouteMax], lsec1[kSpRouteMax], lslot[kSpRouteMax], ltile[kSpRouteMax];
+    if (*p.overflow != 0) return;
     int tx, ty, n;
     if (!sp_decode(p, tx, ty, n)) return;
     const SplatParams& s = p.s;
@@ -1066,11 +1071,33 @@ __global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p)
     }
     __syncthreads();
     if (tid < nt && lcount[tid]) {
-        const int64_t d = (int64_t)n * p.tiles_img + (miny + tid / ntx) * p.tiles_x + (minx + tid % ntx);
-        if (WRITE) lbase[tid] = p.offsets[d] + atomicAdd(&p.cursor[d], lcount[tid]);
-        else atomicAdd(&p.counts[d], lcount[tid]);
+        const int d = n * (int)p.tiles_img + (miny + tid / ntx) * p.tiles_x + (minx + tid % ntx);
+        const int cnt = lcount[tid];
+        const int start = atomicAdd(&p.cursor[d], cnt);          // this block's records are start .. start + cnt - 1 of the queue
+        int b0 = -1, b1 = -1, s0 = 0;
+        if (start + cnt > kSpPrim) {                             // some of them go to blocks beyond the primary region
+            if (start + cnt > (1 + kSpSlots) * kSpPrim) {
+                atomicOr(p.overflow, 1);
+            } else {
+                s0 = (max(start, kSpPrim) - kSpPrim) / kSpPrim;
+                const int s1 = (start + cnt - 1 - kSpPrim) / kSpPrim;        // (cnt <= 512: at most two slots)
+                auto claim = [&](int slot) -> int {              // the block of this slot: draw one if nobody has yet
+                    int32_t* e = &p.sec[(int64_t)d * kSpSlots + slot];
+                    int cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur < 0) {
+                        const int mine = atomicAdd(p.sec_count, 1);
+                        if (mine >= p.nsec) { atomicOr(p.overflow, 1); return -1; }
+                        const int prev = atomicCAS(e, -1, mine);             // (a lost race only leaks the block drawn)
+                        cur = prev < 0 ? mine : prev;
+                    }
+                    return cur;
+                };
+                b0 = claim(s0);
+                b1 = s1 != s0 ? claim(s1) : b0;
+            }
+        }
+        lbase[tid] = start; lsec[tid] = b0; lsec1[tid] = b1; lslot[tid] = s0; ltile[tid] = d;
     }
-    if (!WRITE) return;
     __syncthreads();
     // the records carry the pixel's data (x data_sign) and mask channel: the tile kernel reads everything coalesced
     const int nc = s.c;
@@ -1097,54 +1124,31 @@ __global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p)
         }
         mc4 = nz_bytes(ma) & nz_bytes(mb);
     }
-    uint32_t* pk = reinterpret_cast<uint32_t*>(p.pool + 2 * p.pool_cap);
+    const int ncol = 3 + nc;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (pr[k][j] != 0xffffffffu) {
-                const int pos = lbase[pr[k][j] >> 12] + (int)(pr[k][j] & 0xfffu);
-                p.pool[pos] = q.x[k]; p.pool[p.pool_cap + pos] = q.y[k];
+                const int lt = (int)(pr[k][j] >> 12), idx = lbase[lt] + (int)(pr[k][j] & 0xfffu);
+                float* rp; int cs;                               // column a of this record: rp[a * cs]
+                if (idx < kSpPrim) {
+                    rp = p.prim + ((int64_t)ltile[lt] * ncol) * kSpPrim + idx; cs = kSpPrim;
+                } else {
+                    const int o = idx - kSpPrim, sb = (o / kSpPrim == lslot[lt]) ? lsec[lt] : lsec1[lt];
+                    if (sb < 0) continue;                                 // (the launch is flagged: the two-pass path redoes it)
+                    rp = p.secp + ((int64_t)sb * ncol) * kSpPrim + (o % kSpPrim); cs = kSpPrim;
+                }
+                rp[0] = q.x[k]; rp[cs] = q.y[k];
                 // key: raster position of the source pixel (15 bits each, checked by ofl_splat_tiled_f32) with the mask-channel bit below it --
                 // two records never share a position, so ordering by the whole word is raster order
-                pk[pos] = ((((uint32_t)sy << 15) | (uint32_t)(sx4 + k)) << 1) | ((mc4 >> (8 * k)) & 1u);
+                rp[2 * cs] = __uint_as_float(((((uint32_t)sy << 15) | (uint32_t)(sx4 + k)) << 1) | ((mc4 >> (8 * k)) & 1u));
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (c < nc) p.pool[(3 + c) * p.pool_cap + pos] = s.data_sign * dat[c][k];
+                    if (c < nc) rp[(3 + c) * cs] = s.data_sign * dat[c][k];
             }
         }
     }
-}
-
-// queue lengths -> queue offsets (exclusive scan, one block, 4096 coalesced elements per step); a pool too small for the
-// records flags the launch
-__global__ __launch_bounds__(1024) void splat_scan_kernel(const TiledParams p) {
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < p.total; base += 4096) {
-        const int64_t i0 = base + tid * 4;
-        int v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < p.total) ? ((p.counts[i0 + k] + 3) & ~3) : 0;   // queues start on 16-byte boundaries
-        const int mine = v[0] + v[1] + v[2] + v[3];
-        int inc = mine;                                   // inclusive scan over the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-        if (lane == 63) wsum[wv] = inc;
-        __syncthreads();
-        int before = carry;
-        for (int i = 0; i < wv; ++i) before += wsum[i];
-        int run = before + inc - mine;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { if (i0 + k < p.total) p.offsets[i0 + k] = run; run += v[k]; }
-        __syncthreads();
-        if (tid == 1023) carry = run;
-        __syncthreads();
-    }
-    if (tid == 0 && (int64_t)carry > p.pool_cap) atomicOr(p.overflow, 1);
 }
 
 // weights and destination-local corner positions of one end point, exactly as the reference (utils.py:1098-1114)
@@ -1216,9 +1220,21 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
     const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
     const float wmax = (float)(w - 1), hmax = (float)(h - 1);
     const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
-    const int launch_over = *p.overflow, qlen = p.counts[dtile], qoff = p.offsets[dtile];   // one round trip for the three
+    const int launch_over = *p.overflow, qlen = p.cursor[dtile];
     if (launch_over != 0) return;                                     // this launch takes the global-atomics path instead
-    const float* __restrict__ gq = p.pool + qoff;                     // column a of the queue: gq[a * pool_cap + i], 16-byte aligned
+    const float* __restrict__ gq = p.prim + (dtile * NREC) * kSpPrim;  // column a of the primary region: gq[a * kSpPrim + i], 16-byte aligned
+    // queue positions kSpPrim .. of a long queue live in blocks of kSpPrim records (one more round trip, long queues only)
+    __shared__ int qblk[kSpSlots];
+    if (qlen > kSpPrim) {
+        if (tid < kSpSlots) qblk[tid] = p.sec[dtile * kSpSlots + tid];
+        __syncthreads();
+    }
+    // record i of the queue, column a
+    auto qrec = [&](int a, int i) -> float {
+        if (i < kSpPrim) return gq[a * kSpPrim + i];
+        const int o = i - kSpPrim;
+        return p.secp[((int64_t)qblk[o / kSpPrim] * NREC + a) * kSpPrim + (o % kSpPrim)];
+    };
     const float* __restrict__ db = s.data + n * s.data_bs;
     const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
@@ -1315,7 +1331,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
             if (tid * 4 < qlen) {
 #pragma unroll
                 for (int a = 0; a < NREC; ++a)
-                    *reinterpret_cast<f4*>(rec + a * kSpQ + tid * 4) = *reinterpret_cast<const f4*>(gq + a * p.pool_cap + tid * 4);
+                    *reinterpret_cast<f4*>(rec + a * kSpQ + tid * 4) = *reinterpret_cast<const f4*>(gq + a * kSpPrim + tid * 4);
             }
         } else {
             // ---- A (band): compact the records with a corner row inside the band
@@ -1327,7 +1343,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
                 bool hit = i < qlen;
                 if (hit) {
 #pragma unroll
-                    for (int a = 0; a < NREC; ++a) col[a] = gq[a * p.pool_cap + i];
+                    for (int a = 0; a < NREC; ++a) col[a] = qrec(a, i);
                     const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(col[1]), -2.0f, (float)h) - dy0;
                     hit = (y0 >= r0 - 1) && (y0 < r1);
                 }
@@ -1482,10 +1498,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
     for (int i = tid; i < qlen; i += kSpNT2) {
         float dd[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) dd[c] = gq[(3 + c) * p.pool_cap + i];
-        const bool invalid = MCH ? ((__float_as_uint(gq[2 * p.pool_cap + i]) & 1u) == 0u) : false;
+        for (int c = 0; c < NC; ++c) dd[c] = qrec(3 + c, i);
+        const bool invalid = MCH ? ((__float_as_uint(qrec(2, i)) & 1u) == 0u) : false;
         float wx[2], wy[2]; int ix[2], iy[2];
-        sp_corners(gq[i], gq[p.pool_cap + i], wmax, hmax, dx0, dy0, wx, wy, ix, iy);
+        sp_corners(qrec(0, i), qrec(1, i), wmax, hmax, dx0, dy0, wx, wy, ix, iy);
 #pragma unroll
         for (int ky = 0; ky < 2; ++ky) {
 #pragma unroll
@@ -1838,14 +1854,15 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 #define OFL_SP_POOL_LOG2 30   // workspace budget of one pass, in 4-byte words (4 GiB: ~57 frames of 1080p; measured -8 % against 1 GiB at B=16)
 #endif
 constexpr int kSpRecFloats = 6;   // floats per record: x, y, key (+ mask-channel bit), up to 3 data channels
-// records the pool of one pass holds: 1.5 per pixel (smooth flows need ~1.1), and the images per pass (<= ~4 GiB)
-static int64_t splat_pool_records(int64_t images, int32_t h, int32_t w) {
+// workspace words of one pass of `images` frames: header | queue lengths | secondary block ids | primary regions |
+// secondary blocks
+static int64_t splat_sec_blocks(int64_t tiles) { return (tiles + kSpSecDiv - 1) / kSpSecDiv + 64; }   // (measured: 0.07 / 0.2 / 0.3 per tile drawn at sigma 8 / 12 / 16)
+static int64_t splat_pass_words(int64_t images, int32_t h, int32_t w) {
     const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
-    return ((images * h * w * 3 / 2 + 3 * tiles + 255) / 256) * 256;
+    return 8 + (((1 + kSpSlots) * tiles + 3) & ~(int64_t)3) + kSpRecFloats * (int64_t)kSpPrim * (tiles + splat_sec_blocks(tiles));
 }
 static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
-    const int64_t tiles_img = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
-    int64_t c = ((int64_t)1 << OFL_SP_POOL_LOG2) / (3 * tiles_img + kSpRecFloats * splat_pool_records(1, h, w));
+    int64_t c = ((int64_t)1 << OFL_SP_POOL_LOG2) / splat_pass_words(1, h, w);
     if (c < 1) c = 1;
     if (g_splat_pass_images > 0 && g_splat_pass_images < c) c = g_splat_pass_images;
     if (c >= n) return n;
@@ -1856,9 +1873,7 @@ static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w) { return splat_chunk_images(n, h, w); }
 
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w) {
-    const int64_t tiles_img = (int64_t)((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
-    const int64_t chunk = splat_chunk_images(n, h, w);
-    return 8 + 3 * chunk * tiles_img + kSpRecFloats * splat_pool_records(chunk, h, w);
+    return splat_pass_words(splat_chunk_images(n, h, w), h, w);
 }
 
 __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
@@ -1895,11 +1910,12 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     magic_u32(tp.tiles_img, tp.mi_m, tp.mi_s);
     const int64_t chunk = splat_chunk_images(n, h, w), ctiles = chunk * tp.tiles_img;
     tp.overflow = workspace;
-    tp.counts = workspace + 4;
-    tp.offsets = tp.counts + ctiles;
-    tp.cursor = tp.offsets + ctiles;
-    tp.pool = reinterpret_cast<float*>(workspace + ((4 + 3 * ctiles + 3) & ~(int64_t)3));   // 16-byte aligned columns
-    tp.pool_cap = splat_pool_records(chunk, h, w);
+    tp.sec_count = workspace + 4;
+    tp.cursor = workspace + 8;
+    tp.sec = tp.cursor + ctiles;
+    tp.nsec = (int32_t)splat_sec_blocks(ctiles);
+    tp.prim = reinterpret_cast<float*>(workspace + 8 + (((1 + kSpSlots) * ctiles + 3) & ~(int64_t)3));   // 16-byte aligned columns
+    tp.secp = tp.prim + (int64_t)kSpRecFloats * kSpPrim * ctiles;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(tp.overflow, 0, 4 * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
@@ -1935,12 +1951,12 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
         if (q.dst_flags) q.dst_flags = full.dst_flags + n0;
         tp.total = (int64_t)tp.tiles_img * nn;
         tp.per_xcd = (tp.total + kXcds - 1) / kXcds;
-        e = hipMemsetAsync(tp.counts, 0, (size_t)ctiles * 3 * sizeof(int32_t), st);      // counts | offsets | cursor
+        e = hipMemsetAsync(tp.sec_count, 0, (size_t)(4 + ctiles) * sizeof(int32_t), st);      // blocks drawn | queue lengths
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(tp.sec, 0xff, (size_t)ctiles * kSpSlots * sizeof(int32_t), st);   // no blocks yet (-1)
         if (e != hipSuccess) return (int)e;
         const unsigned grid = (unsigned)(tp.per_xcd * kXcds);
-        hipLaunchKernelGGL(splat_route_kernel<false>, dim3(grid), dim3(kSpNT), 0, st, tp);
-        hipLaunchKernelGGL(splat_scan_kernel, dim3(1), dim3(1024), 0, st, tp);
-        hipLaunchKernelGGL(splat_route_kernel<true>, dim3(grid), dim3(kSpNT), 0, st, tp);
+        hipLaunchKernelGGL(splat_route_kernel, dim3(grid), dim3(kSpNT), 0, st, tp);
         rc = (int)hipGetLastError();
         if (rc) return rc;
         switch (cg) {

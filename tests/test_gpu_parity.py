@@ -351,6 +351,30 @@ def test_compressing_flows_stay_exact(patch, dev):
     assert np.array_equal(out[3].cpu().numpy(), rwarped)
 
 
+def test_queue_capacity_exceeded_takes_the_two_pass_path(dev):
+    """A flow that shrinks the whole frame five-fold sends ~25 records per destination pixel to the tiles in the middle:
+    more than a tile's queue (primary region + 8 blocks) holds.  The launch is flagged on the device and the two-pass
+    path redoes it inside the same call: masks bit-exact, values within the stated tolerance."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    _native.collect_splat_stats = True
+    n, c, h, w = 1, 2, 256, 384
+    xs = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w)
+    ys = torch.arange(h, dtype=torch.float32).view(1, 1, h, 1)
+    flow = torch.cat([(-0.8 * (xs - 190.3)).expand(n, 1, h, w), (-0.8 * (ys - 120.7)).expand(n, 1, h, w)], 1).contiguous().to(dev)
+    g = torch.Generator().manual_seed(8)
+    data = (torch.rand(n, c, h, w, generator=g) * 10).to(dev)
+    wm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    out = _native.splat_fwd(flow, data, weight_mask=wm, chan_mask_a=wm, want_valid=True, want_density=True, want_warped=True)
+    assert _native._last_splat_stats.cpu().tolist()[0] == 1
+    dd = np.concatenate([data.cpu().numpy(), wm.cpu().numpy()[:, None].astype(np.float32)], 1)
+    ref, rwarped, rden = oracle.apply_s_flow(flow.cpu().numpy(), dd, wm.cpu().numpy(), True, return_density=True)
+    assert np.array_equal(out[3].cpu().numpy(), rwarped)
+    assert np.array_equal(out[1].cpu().numpy(), oracle.theta(ref[:, c]))
+    np.testing.assert_allclose(out[0].cpu().numpy(), ref[:, :c], rtol=3e-5, atol=3e-4)
+    np.testing.assert_allclose(out[2].cpu().numpy(), rden, rtol=3e-5, atol=1e-4)
+
+
 def test_a_fold_beyond_the_list_limit_falls_back_per_tile(dev):
     """Every source pixel of a 64-row band ends in ONE row of cells (> 64 per cell): those tiles take the float-atomics
     fallback (counted), masks stay bit-exact, values within the stated tolerance; the choice is the same in every run."""
