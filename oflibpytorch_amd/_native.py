@@ -15,6 +15,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
+ABI_VERSION = 13              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -44,6 +45,10 @@ def load_library(path: str = None):
         raise NativeUnavailable("oflibpytorch_amd: cannot load %s: %s" % (path, exc))
     p, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
     lib.ofl_version.argtypes = []
+    lib.ofl_version.restype = ctypes.c_int
+    if lib.ofl_version() != ABI_VERSION:     # a stale build would take the arguments below in the wrong places
+        raise NativeUnavailable("oflibpytorch_amd: %s has ABI version %d, this package needs %d -- rebuild it "
+                                "(python -m oflibpytorch_amd._build)" % (path, lib.ofl_version(), ABI_VERSION))
     lib.ofl_set_option.argtypes = [i32, i32]
     lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p, p,
                                      i32, i32, i32, i32, i32, p]
