@@ -166,6 +166,8 @@ int ofl_splat_finalize_f32(const float* accum,
  *                  tiles, ~72 B/px; the batch is processed in equal passes so that it stays under ~4 GiB);
  *                  contents irrelevant on entry; afterwards workspace[0] = 1 if the launch fell back to the two-pass
  *                  path, workspace[1] = number of tiles that left the exact path, workspace[4] = blocks drawn
+ *   data_b         optional [*,C,H,W] fp32 (C <= 2, else OFL_E_ARG): the data splatted is data - data_b (ONE fp32 subtraction per value, the
+ *                  reference's `flow - self` in combine_with modes 1-2, flow_class.py:1763,1768), then x data_sign
  *   dst_flags      optional int32[N] (C == 2 only, else OFL_E_ARG; zeroed in-stream): the flag word (see
  *                  ofl_flow_flags_f32) of the OUTPUT read as a flow under its `valid` mask -- a by-product that spares
  *                  the caller the validation pass (utils.py:98, flow_class.py:1226-1244) over an intermediate flow
@@ -181,6 +183,7 @@ int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w);   /* image
 int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
                         const float* xs, const float* ys, int64_t xy_bs,
                         const float* data, int64_t data_bs, float data_sign,
+                        const float* data_b, int64_t data_b_bs,
                         const uint8_t* weight_mask, int64_t weight_mask_bs,
                         const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
                         const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,

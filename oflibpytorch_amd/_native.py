@@ -15,7 +15,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 13              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 14              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -59,7 +59,7 @@ def load_library(path: str = None):
     lib.ofl_flow_flags_f32.argtypes = [p, i64, p, i64, f32, p, i32, i32, i32, p]
     lib.ofl_splat_tiled_workspace_ints.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_pass_images.argtypes = [i32, i32, i32]
-    lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
+    lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                         p, p, i64, p, i32, i32, i32, i32, i32, p]
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
@@ -188,19 +188,20 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
               chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False,
-              round_mode=ROUND_NONE, want_mask_chan=False, want_dst_flags=False):
+              round_mode=ROUND_NONE, want_mask_chan=False, want_dst_flags=False, data_b=None):
     """P-family kernels (ofl_splat_tiled_f32, or ofl_splat_fwd_f32 + ofl_splat_finalize_f32).
 
     Either flow [Nf,2,H,W] (endpoints computed in-kernel) or explicit positions xs, ys [N,H,W].
     Returns (dst [N,C,H,W], valid | None, density | None, warped | None) on the HIP device; with
     `want_mask_chan` the valid slot holds the warped mask channel itself (fp32) instead of its threshold.
+    `data_b` [*,C,H,W], C <= 2: splat data - data_b (one fp32 subtraction in the kernel instead of a materialised difference).
     `want_dst_flags` (2-channel data): a fifth result, the device flag words int32[N] of dst read as a flow under `valid`.
     """
     lib, dev = load_library(), device()
     c, h, w = data.shape[1:]
     if want_dst_flags and c != 2:
         raise ValueError("oflibpytorch_amd: output flags are defined for 2-channel data only")
-    n = max(data.shape[0], 1 if flow is None else flow.shape[0], 1 if xs is None else xs.shape[0],
+    n = max(data.shape[0], 1 if data_b is None else data_b.shape[0], 1 if flow is None else flow.shape[0], 1 if xs is None else xs.shape[0],
             1 if weight_mask is None else weight_mask.shape[0], 1 if chan_mask_a is None else chan_mask_a.shape[0],
             1 if chan_mask_b is None else chan_mask_b.shape[0])
     f, fbs = (None, 0) if flow is None else _planes(flow, dev, torch.float32, n, "flow")
@@ -210,6 +211,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
         x, y = x.expand(n, h, w).contiguous(), y.expand(n, h, w).contiguous()
         xbs = ybs = h * w
     d, dbs = _planes(data, dev, torch.float32, n, "data")
+    d2, d2bs = (None, 0) if data_b is None else _planes(data_b, dev, torch.float32, n, "data")
     wm, wmbs = (None, 0) if weight_mask is None else _planes(weight_mask, dev, torch.bool, n, "mask")
     ca, cabs = (None, 0) if chan_mask_a is None else _planes(chan_mask_a, dev, torch.bool, n, "mask")
     cb, cbbs = (None, 0) if chan_mask_b is None else _planes(chan_mask_b, dev, torch.bool, n, "mask")
@@ -228,7 +230,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
         ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
         accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
         rc = lib.ofl_splat_tiled_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
-                                     float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
+                                     float(data_sign), _ptr(d2), d2bs, _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
                                      _ptr(dst), _ptr(density), _ptr(warped), _ptr(valid), _ptr(mchan), _ptr(dflags),
                                      _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, int(round_mode), st)
         if rc not in (0, -4):
@@ -237,6 +239,9 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
             global _last_splat_stats
             _last_splat_stats = ws[:8].clone()   # [launch fell back to global atomics, tiles that left the exact path, -, -]
     if rc == -4:   # not eligible (alignment / channels): the general two-pass path
+        if d2 is not None:
+            d = (data.to(dev, torch.float32) - data_b.to(dev, torch.float32)).expand(n, -1, -1, -1).contiguous()
+            dbs = c * h * w
         accum = torch.zeros((n, 1 + c + mch, h, w), dtype=torch.float32, device=dev)
         _check(lib.ofl_splat_fwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
                                      float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,

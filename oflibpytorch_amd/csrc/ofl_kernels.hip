@@ -718,6 +718,7 @@ struct SplatParams {
     const float* flow; int64_t flow_bs; float flow_sign;
     const float* xs; const float* ys; int64_t xy_bs;
     const float* data; int64_t data_bs; float data_sign;
+    const float* data_b; int64_t data_b_bs;      // optional: the data is data - data_b (one fp32 subtraction, as `flow - self` in the reference's modes 1-2)
     const uint8_t* weight_mask; int64_t weight_mask_bs;
     const uint8_t* chan_mask_a; int64_t chan_mask_a_bs;
     const uint8_t* chan_mask_b; int64_t chan_mask_b_bs;
@@ -751,6 +752,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
 
     const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
     const float* __restrict__ db = p.data + n * p.data_bs;
+    const float* __restrict__ dbb = p.data_b ? p.data_b + n * p.data_b_bs : nullptr;
     const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
     const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
 #pragma unroll
                 for (int ch = 0; ch < (CT ? CT : 1); ++ch)
                     for (int cc = ch; cc < C; cc += (CT ? C : 1))
-                        atomicAdd(&acc[(int64_t)(1 + cc) * hw + pos], wgt * (p.data_sign * db[(int64_t)cc * hw + pix]));
+                        atomicAdd(&acc[(int64_t)(1 + cc) * hw + pos], wgt * (p.data_sign * (dbb ? db[(int64_t)cc * hw + pix] - dbb[(int64_t)cc * hw + pix] : db[(int64_t)cc * hw + pix])));
                 // mask channel: the reference accumulates wgt * mval next to the density.  All contributors of a
                 // pixel being valid is the common case and must give ratio == 1 exactly, whatever order the
                 // atomics land in -- so accumulate the INVALID weight instead and form den - inv in pass 2.
@@ -831,6 +833,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 
     const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
     const float* __restrict__ db = p.data + n * p.data_bs;
+    const float* __restrict__ dbb = p.data_b ? p.data_b + n * p.data_b_bs : nullptr;
     const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
     const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
@@ -857,7 +860,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 #pragma unroll
         for (int ch = 0; ch < (CT ? CT : 1); ++ch)
             for (int cc = ch; cc < C; cc += (CT ? C : 1)) {
-                float val = fill ? p.data_sign * db[(int64_t)cc * hw + pix] : acc[(int64_t)(1 + cc) * hw + pix] / dcl;
+                float val = fill ? p.data_sign * (dbb ? db[(int64_t)cc * hw + pix] - dbb[(int64_t)cc * hw + pix] : db[(int64_t)cc * hw + pix]) : acc[(int64_t)(1 + cc) * hw + pix] / dcl;
                 val = apply_round(val, p.round_mode);
                 dst[(int64_t)cc * hw + pix] = val;
                 if (cc < 2) uv[cc] = val;
@@ -1109,7 +1112,10 @@ __global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p)
         const uint32_t pix = (uint32_t)(sy * w + sx4) - (edge ? (uint32_t)(4 - wrem) : 0u);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-            if (c < nc) dat[c] = ld4(s.data + n * s.data_bs + c * hw + pix);
+            if (c < nc) {
+                dat[c] = ld4(s.data + n * s.data_bs + c * hw + pix);
+                if (s.data_b) dat[c] = dat[c] - ld4(s.data_b + n * s.data_b_bs + c * hw + pix);
+            }
         uint32_t ma = 0x01010101u, mb = 0x01010101u;
         if (s.with_mask_chan) {
             if (s.chan_mask_a) ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + pix);
@@ -1236,6 +1242,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
         return p.secp[((int64_t)qblk[o / kSpPrim] * NREC + a) * kSpPrim + (o % kSpPrim)];
     };
     const float* __restrict__ db = s.data + n * s.data_bs;
+    const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
     const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
     // this thread's 2 destination pixels
@@ -1275,7 +1282,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
             warped2 |= (uint32_t)warped << (8 * k);
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                out[c][k] = apply_round(fill ? s.data_sign * db[c * hw + pix + k] : tot[k][1 + c] / dcl, s.round_mode);
+                out[c][k] = apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? db[c * hw + pix + k] - dbb[c * hw + pix + k] : db[c * hw + pix + k]) : tot[k][1 + c] / dcl, s.round_mode);
             if (MCH) {
                 float mv;
                 if (fill) {
@@ -1691,7 +1698,7 @@ int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 13; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues
+__attribute__((visibility("default"))) int ofl_version(void) { return 14; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -1785,6 +1792,7 @@ static int fill_splat(SplatParams& p, const float* flow, int64_t flow_bs, const 
     if (occlude && !flow) return OFL_E_ARG;
     if (!(data_sign == 1.0f || data_sign == -1.0f)) return OFL_E_ARG;
     p.flow = flow; p.flow_bs = flow_bs; p.data = data; p.data_bs = data_bs; p.data_sign = data_sign;
+    p.data_b = nullptr; p.data_b_bs = 0;
     p.weight_mask = weight_mask; p.weight_mask_bs = weight_mask_bs;
     p.chan_mask_a = chan_mask_a; p.chan_mask_a_bs = chan_mask_a_bs;
     p.chan_mask_b = chan_mask_b; p.chan_mask_b_bs = chan_mask_b_bs;
@@ -1878,7 +1886,8 @@ __attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(in
 
 __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     const float* flow, int64_t flow_bs, float flow_sign, const float* xs, const float* ys, int64_t xy_bs,
-    const float* data, int64_t data_bs, float data_sign, const uint8_t* weight_mask, int64_t weight_mask_bs,
+    const float* data, int64_t data_bs, float data_sign, const float* data_b, int64_t data_b_bs,
+    const uint8_t* weight_mask, int64_t weight_mask_bs,
     const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
     int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
     float* mask_chan, int32_t* dst_flags, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n,
@@ -1888,6 +1897,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     if ((valid || mask_chan) && !with_mask_chan) return OFL_E_ARG;
     if (dst_flags && c != 2) return OFL_E_ARG;
+    if (data_b && c > 2) return OFL_E_ARG;                           // (flows: the tile kernel only carries it for <= 2 channels)
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
     TiledParams tp = {};
     unsigned grid_unused;
@@ -1902,6 +1912,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     tp.s.flow_sign = flow_sign; tp.s.xs = xs; tp.s.ys = ys; tp.s.xy_bs = xy_bs;
     tp.s.dst = dst; tp.s.density = density; tp.s.warped = warped; tp.s.valid = valid; tp.s.mask_chan = mask_chan;
     tp.s.dst_flags = dst_flags;
+    tp.s.data_b = data_b; tp.s.data_b_bs = data_b_bs;
     tp.s.round_mode = round_mode;
     tp.tiles_x = (w + kSpTW - 1) / kSpTW; tp.tiles_y = (h + kSpTH - 1) / kSpTH;
     tp.tiles_img = (uint32_t)(tp.tiles_x * tp.tiles_y);
@@ -1930,6 +1941,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     SplatParams full = all;
     full.c = (c - c0) < 3 ? (c - c0) : 3;
     full.data = all.data + c0 * hw; full.dst = all.dst + c0 * hw;
+    if (all.data_b) full.data_b = all.data_b + c0 * hw;
     if (c0 > 0) { full.with_mask_chan = 0; full.density = nullptr; full.warped = nullptr; full.valid = nullptr; full.mask_chan = nullptr; }
     const int32_t cg = full.c;
     for (int64_t n0 = 0; n0 < n; n0 += chunk) {          // same stream: the queues of a pass are re-used by the next one
@@ -1940,6 +1952,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
         if (q.flow) q.flow = full.flow + n0 * full.flow_bs;
         if (q.xs) { q.xs = full.xs + n0 * full.xy_bs; q.ys = full.ys + n0 * full.xy_bs; }
         q.data = full.data + n0 * full.data_bs;
+        if (q.data_b) q.data_b = full.data_b + n0 * full.data_b_bs;
         if (q.weight_mask) q.weight_mask = full.weight_mask + n0 * full.weight_mask_bs;
         if (q.chan_mask_a) q.chan_mask_a = full.chan_mask_a + n0 * full.chan_mask_a_bs;
         if (q.chan_mask_b) q.chan_mask_b = full.chan_mask_b + n0 * full.chan_mask_b_bs;

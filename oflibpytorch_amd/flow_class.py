@@ -483,12 +483,13 @@ class Flow(object):
         return (warped, valid) if return_valid_area else warped
 
     def _warp(self, t: torch.Tensor, tmask, need_valid: bool, consider_mask: bool, round_mode: int = 0,
-              flow_sign: float = 1.0, data_sign: float = 1.0):
+              flow_sign: float = 1.0, data_sign: float = 1.0, t_minus: torch.Tensor = None):
         """Core of `apply`: t [Nt,C,H,W] any dtype, tmask [Nt,H,W] bool or None (all True).
         Returns (warped fp32 [N,C,H,W], valid bool [N,H,W] | None) on self.device.
         `flow_sign` / `data_sign` = -1 (forward flows only) restate `(-self)` as the warper / `-t` as the target inside the
         kernel (exact negations; finiteness and zero tests do not depend on the sign), so that switch_ref / invert need
-        no negated copy and no second flag reduction."""
+        no negated copy and no second flag reduction.  `t_minus` (forward flows, past the early exit only): the target
+        is t - t_minus, subtracted inside the kernel (mode 2 's': target `flow - self`, its mask m_flow & m_self)."""
         if self._ref == 's' and not get_pure_pytorch():
             _griddata_unavailable("Flow.apply(ref='s')")
         self._require_finite("Error applying flow to a target: ")
@@ -525,7 +526,7 @@ class Flow(object):
             res = _native.splat_fwd(self._vecs, t, weight_mask=self._mask if consider_mask else None,
                                     chan_mask_a=tmask, chan_mask_b=self._mask,
                                     want_valid=need_valid, occlude=True, round_mode=round_mode,
-                                    flow_sign=flow_sign, data_sign=data_sign, want_dst_flags=want_f)
+                                    flow_sign=flow_sign, data_sign=data_sign, want_dst_flags=want_f, data_b=t_minus)
             warped, valid = res[0], res[1]
             dflags = res[4] if want_f else None
         return warped.to(self._device), (None if valid is None else valid.to(self._device)), dflags
@@ -667,7 +668,11 @@ class Flow(object):
                 return flow._minus_applied(self.switch_ref()._combine3(flow_inv_t, result_is_warper=True), self)
             return self.invert().apply(flow - self)                                  # :1763
         if ref == 's':                                                               # mode 2, :1768
-            return self.apply(flow - self)
+            # self.apply(flow - self): the difference (and the AND of the two masks) is formed inside the splat
+            if self._all_zero(_native.FLAG_NZ_THR) or not get_pure_pytorch():        # (apply's early exit / griddata gate)
+                return self.apply(flow - self)
+            warped, valid, dflags = self._warp(flow._vecs, flow._mask, True, True, t_minus=self._vecs)
+            return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
         if not get_pure_pytorch():
             _griddata_unavailable("combine_with(mode=2, ref='t')")
         return flow._minus_applied(flow, self.invert().apply(self))                  # :1773  flow - flow.apply(...)

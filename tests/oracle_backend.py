@@ -78,8 +78,13 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
               chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False, round_mode=0,
-              want_mask_chan=False, want_dst_flags=False):
-    d = _np(data, np.float32) * np.float32(data_sign)
+              want_mask_chan=False, want_dst_flags=False, data_b=None):
+    d = _np(data, np.float32)
+    if data_b is not None:
+        db = _np(data_b, np.float32)
+        nn = max(d.shape[0], db.shape[0])
+        d = _bcast(d, nn) - _bcast(db, nn)
+    d = d * np.float32(data_sign)
     n = max(d.shape[0], 1 if flow is None else flow.shape[0], 1 if xs is None else xs.shape[0],
             1 if weight_mask is None else weight_mask.shape[0], 1 if chan_mask_a is None else chan_mask_a.shape[0],
             1 if chan_mask_b is None else chan_mask_b.shape[0])

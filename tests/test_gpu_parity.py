@@ -463,6 +463,43 @@ def test_splat_output_flags_equal_a_flag_pass_over_the_output(kind, dev):
         assert all((f & _native.FLAG_NZ) != 0 and (f & _native.FLAG_NZ_THR) == 0 for f in out[4].cpu().tolist())
 
 
+@pytest.mark.parametrize("kind", ["routed", "general_path", "two_pass_inside", "narrow"])
+def test_splat_of_a_difference_equals_the_materialised_difference(kind, dev):
+    """`data_b`: the splat of data - data_b formed inside the kernels (route kernel, un-occlude fill, two-pass fallback)
+    is bit-identical to splatting the materialised difference -- combine_with mode 2 ('s') relies on it."""
+    from oflibpytorch_amd import _native
+    n, h, w = (2, 70, 132) if kind != "narrow" else (2, 20, 3)
+    flow = _smooth(n, h, w, 1.5 if kind != "two_pass_inside" else 400.0, 9, dev)
+    flow[0, :, : h // 3] = 0                                  # un-occlude fill candidates
+    a, b = _smooth(n, h, w, 3.0, 10, dev), _smooth(n, h, w, 2.0, 11, dev)
+    g = torch.Generator().manual_seed(5)
+    wm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    kw = dict(weight_mask=wm, chan_mask_a=wm, want_valid=True, want_density=True)
+    try:
+        if kind == "general_path":
+            _native.set_splat_path(1)
+        fused = _native.splat_fwd(flow, a, data_b=b, **kw)
+        plain = _native.splat_fwd(flow, a - b, **kw)
+    finally:
+        _native.set_splat_path(0)
+    if kind in ("two_pass_inside", "general_path"):            # float atomics: order differs from run to run
+        np.testing.assert_allclose(fused[0].cpu().numpy(), plain[0].cpu().numpy(), rtol=3e-5, atol=3e-4)
+    else:
+        assert torch.equal(fused[0], plain[0])
+    assert torch.equal(fused[1], plain[1])
+
+
+def test_mode2_s_is_the_composed_expression(dev):
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 96, 160
+    g = torch.Generator().manual_seed(12)
+    m1 = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    m2 = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    A, B = ofl.Flow(_smooth(n, h, w, 1.5, 20, dev), 's', m1), ofl.Flow(_smooth(n, h, w, 2.0, 21, dev), 's', m2)
+    x, y = A.combine_with(B, 2), A.apply(B - A)
+    assert torch.equal(x.vecs, y.vecs) and torch.equal(x.mask, y.mask) and x.ref == y.ref == 's'
+
+
 @pytest.mark.parametrize("rough", [False, True])
 def test_routed_splat_in_several_passes(rough, dev):
     """n = 5 images, at most 2 per pass: the passes re-use the queues; with a rough flow the launch-level two-pass fallback
