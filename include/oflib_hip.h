@@ -80,6 +80,10 @@ int ofl_set_option(int32_t key, int32_t value);
  *
  * flow      [*,2,H,W] fp32, flow_sign = +1 or -1 (exact negation; Flow.invert('t') of an 's' flow)
  * src       [*,C,H,W] fp32
+ * src_b     [*,C,H,W] fp32 or NULL: the field gathered is src - src_b (ONE fp32 subtraction per value: the reference's
+ *           `flow - self` in combine_with mode 1, flow_class.py:1763).  Only for C == 2 with `valid` wanted, no addend and
+ *           no flag outputs on frames the staged kernel takes (W >= 4, H >= 2); otherwise OFL_E_UNSUPPORTED and the
+ *           caller passes the materialised difference
  * src_mask  [*,H,W] u8 or NULL (all True)      -- the mask warped as an extra channel
  * flow_mask [*,H,W] u8 or NULL (all True)      -- ANDed after the warp
  * addend    [*,C,H,W] fp32 or NULL; may alias `flow` (mode-3 composition, C = 2)
@@ -94,6 +98,7 @@ int ofl_set_option(int32_t key, int32_t value);
  */
 int ofl_warp_bwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
                      const float* src, int64_t src_bs,
+                     const float* src_b, int64_t src_b_bs,
                      const uint8_t* src_mask, int64_t src_mask_bs,
                      const uint8_t* flow_mask, int64_t flow_mask_bs,
                      const float* addend, int64_t addend_bs, float a_sign, float g_sign,

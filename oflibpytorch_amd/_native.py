@@ -15,7 +15,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 14              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 15              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -50,7 +50,7 @@ def load_library(path: str = None):
         raise NativeUnavailable("oflibpytorch_amd: %s has ABI version %d, this package needs %d -- rebuild it "
                                 "(python -m oflibpytorch_amd._build)" % (path, lib.ofl_version(), ABI_VERSION))
     lib.ofl_set_option.argtypes = [i32, i32]
-    lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p, p,
+    lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p, p,
                                      i32, i32, i32, i32, i32, p]
     lib.ofl_splat_fwd_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p,
                                       i32, i32, i32, i32, p]
@@ -156,8 +156,9 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
              a_sign=1.0, g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False,
-             want_dst_flags=False):
-    """G-family kernel (include/oflib_hip.h: ofl_warp_bwd_f32).
+             want_dst_flags=False, src_b=None):
+    """G-family kernel (include/oflib_hip.h: ofl_warp_bwd_f32).  `src_b`: gather src - src_b (subtracted in the kernel
+    where the C ABI supports it, else materialised here).
 
     flow [Nf,2,H,W], src [Ns,C,H,W], masks [*,H,W] bool or None, addend [*,C,H,W] or None.
     Returns (dst [N,C,H,W] fp32, valid [N,H,W] bool | None, flow_flags int32[N] | None, src_flags | None),
@@ -166,7 +167,7 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
     """
     lib, dev = load_library(), device()
     c, h, w = src.shape[1:]
-    n = max(flow.shape[0], src.shape[0], 1 if src_mask is None else src_mask.shape[0],
+    n = max(flow.shape[0], src.shape[0], 1 if src_b is None else src_b.shape[0], 1 if src_mask is None else src_mask.shape[0],
             1 if flow_mask is None else flow_mask.shape[0], 1 if addend is None else addend.shape[0])
     f, fbs = _planes(flow, dev, torch.float32, n, "flow")
     s, sbs = _planes(src, dev, torch.float32, n, "source")
@@ -178,9 +179,16 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
     ff = torch.zeros(n, dtype=torch.int32, device=dev) if want_flags else None
     sf = torch.zeros(n, dtype=torch.int32, device=dev) if (want_flags and want_src_flags) else None
     df = torch.empty(n, dtype=torch.int32, device=dev) if want_dst_flags else None
-    _check(lib.ofl_warp_bwd_f32(_ptr(f), fbs, float(flow_sign), _ptr(s), sbs, _ptr(sm), smbs, _ptr(fm), fmbs,
-                                _ptr(ad), adbs, float(a_sign), float(g_sign), _ptr(dst), _ptr(valid), _ptr(ff),
-                                _ptr(sf), _ptr(df), n, c, h, w, int(round_mode), _stream(dev)), "ofl_warp_bwd_f32")
+    s2, s2bs = (None, 0) if src_b is None else _planes(src_b, dev, torch.float32, n, "source")
+    args = lambda: (_ptr(f), fbs, float(flow_sign), _ptr(s), sbs, _ptr(s2), s2bs, _ptr(sm), smbs, _ptr(fm), fmbs,
+                    _ptr(ad), adbs, float(a_sign), float(g_sign), _ptr(dst), _ptr(valid), _ptr(ff),
+                    _ptr(sf), _ptr(df), n, c, h, w, int(round_mode), _stream(dev))
+    rc = lib.ofl_warp_bwd_f32(*args())
+    if rc == -4 and s2 is not None:          # the difference is not formed in this kernel variant: materialise it
+        s = (src.to(dev, torch.float32) - src_b.to(dev, torch.float32)).expand(n, -1, -1, -1).contiguous()
+        sbs, s2, s2bs = c * h * w, None, 0
+        rc = lib.ofl_warp_bwd_f32(*args())
+    _check(rc, "ofl_warp_bwd_f32")
     if want_dst_flags:
         return dst, valid, ff, sf, df
     return dst, valid, ff, sf

@@ -86,6 +86,7 @@ __device__ __forceinline__ int64_t logical_block(int64_t per_xcd) {
 struct WarpParams {
     const float* flow; int64_t flow_bs;
     const float* src; int64_t src_bs;
+    const float* src_b; int64_t src_b_bs;      // optional (staged kernel, 2 channels): the gathered field is src - src_b (one fp32 subtraction per value)
     const uint8_t* src_mask; int64_t src_mask_bs;
     const uint8_t* flow_mask; int64_t flow_mask_bs;
     const float* addend; int64_t addend_bs;
@@ -346,9 +347,9 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
 }
 
 // step 3a: issue the staging loads of a tile into registers (nothing waits here)
-template <int NC, bool VALID>
+template <int NC, bool VALID, bool SUB = false>
 __device__ __forceinline__ void lds_issue(const WarpParams& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm,
-                                          uint32_t hw, const LdsBox& B, LdsStage<NC>& S) {
+                                          uint32_t hw, const LdsBox& B, LdsStage<NC>& S, const float* __restrict__ sbb = nullptr) {
     const int tid = threadIdx.x;
     const uint32_t inv = inv20((uint32_t)B.cw);
     const int rounds = B.fits ? (B.nch + kLdsNT - 1) / kLdsNT : 0;
@@ -369,7 +370,10 @@ __device__ __forceinline__ void lds_issue(const WarpParams& p, const float* __re
             const bool edge = wrem != 0 && on && (int)(B.bx0 + (int)c4 * 4) > p.w - 4;
             const uint32_t ge = edge ? g - (uint32_t)(4 - wrem) : g;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) S.q[it][c] = ld4(sb + c * hw + ge);
+            for (int c = 0; c < NC; ++c) {
+                S.q[it][c] = ld4(sb + c * hw + ge);
+                if (SUB) S.q[it][c] = S.q[it][c] - ld4(sbb + c * hw + ge);     // (mode 1 't': the warped field is flow - self)
+            }
             S.mq[it] = (VALID && sm) ? ld32(sm + ge) : 0x01010101u;
             if (wrem != 0) {
                 if (edge) {
@@ -402,10 +406,11 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
 }
 
 // step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
-template <int NC, bool VALID, bool INTERIOR>
+template <int NC, bool VALID, bool INTERIOR, bool SUB = false>
 __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw,
                                                 const float* __restrict__ sb, const uint8_t* __restrict__ sm,
-                                                const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4]) {
+                                                const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
+                                                const float* __restrict__ sbb = nullptr) {
     const int w = p.w, h = p.h;
     const int cw16 = B.cw * 16, P16 = B.Pp * 16;
     const float wf = (float)w, hf = (float)h;
@@ -463,7 +468,7 @@ __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw
                 f4 t = {0.f, 0.f, 0.f, 0.f};
                 if (ok[j]) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) t[c] = sb[c * hw + og];
+                    for (int c = 0; c < NC; ++c) t[c] = SUB ? sb[c * hw + og] - sbb[c * hw + og] : sb[c * hw + og];
                     if (VALID) t[3] = sm ? (float)(sm[og] != 0) : 1.0f;
                 }
                 tv[j] = t;
@@ -478,12 +483,13 @@ __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw
     }
 }
 
-template <int NC, bool VALID>
+template <int NC, bool VALID, bool SUB = false>
 __device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
                                            const float* __restrict__ sb, const uint8_t* __restrict__ sm,
-                                           const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4]) {
-    if (B.interior) lds_gather_impl<NC, VALID, true>(p, hw, sb, sm, T, B, smem, outv);
-    else lds_gather_impl<NC, VALID, false>(p, hw, sb, sm, T, B, smem, outv);
+                                           const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
+                                           const float* __restrict__ sbb = nullptr) {
+    if (B.interior) lds_gather_impl<NC, VALID, true, SUB>(p, hw, sb, sm, T, B, smem, outv, sbb);
+    else lds_gather_impl<NC, VALID, false, SUB>(p, hw, sb, sm, T, B, smem, outv, sbb);
 }
 
 // the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
@@ -533,7 +539,7 @@ __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, i
     }
 }
 
-template <int NC, bool VALID, bool ADD, bool DF = false>
+template <int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParams p) {
     constexpr int NW = kLdsNT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -547,6 +553,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     const uint32_t hw = (uint32_t)(h * w);
     const float* __restrict__ fu = p.flow + n * p.flow_bs;
     const float* __restrict__ sb = p.src + n * p.src_bs;
+    const float* __restrict__ sbb = SUB ? p.src_b + n * p.src_b_bs : nullptr;
     const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
     const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
     const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     LdsStage<NC> S;
     const int sq = p.shear ? lds_slope(p, fu, hw, tx, ty2) : 0;
     lds_coords_box(p, tx, tyA, uA, vA, sq, TA, BA, red[0]);
-    lds_issue<NC, VALID>(p, sb, sm, hw, BA, S);                 // staging loads of A fly ...
+    lds_issue<NC, VALID, SUB>(p, sb, sm, hw, BA, S, sbb);       // staging loads of A fly ...
     lds_coords_box(p, tx, tyB, uB, vB, sq, TB, BB, red[1]);     // ... while B's coordinates are computed
     lds_write<NC, VALID>(lds, BA, S);
     lds_barrier();
@@ -587,8 +594,8 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     f4 outv[4], aA[NC], aB[NC];
     const bool reuse = EARLY && NC == 2 && p.add_is_flow;         // block-uniform
     if (EARLY) { if (reuse) { aA[0] = uA; aA[NC - 1] = vA; } else lds_load_addend<NC>(p, tx, tyA, n, hw, aA); }
-    if (haveB) lds_issue<NC, VALID>(p, sb, sm, hw, BB, S);      // staging loads of B fly while A is gathered and stored
-    lds_gather<NC, VALID>(p, hw, sb, sm, TA, BA, smem, outv);
+    if (haveB) lds_issue<NC, VALID, SUB>(p, sb, sm, hw, BB, S, sbb);   // staging loads of B fly while A is gathered and stored
+    lds_gather<NC, VALID, SUB>(p, hw, sb, sm, TA, BA, smem, outv, sbb);
     if (EARLY && haveB) { if (reuse) { aB[0] = uB; aB[NC - 1] = vB; } else lds_load_addend<NC>(p, tx, tyB, n, hw, aB); }
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyA, n, hw, aA);
     int dflags = 0;
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     lds_barrier();
     lds_write<NC, VALID>(lds, BB, S);
     lds_barrier();
-    lds_gather<NC, VALID>(p, hw, sb, sm, TB, BB, smem, outv);
+    lds_gather<NC, VALID, SUB>(p, hw, sb, sm, TB, BB, smem, outv, sbb);
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
     lds_store<NC, VALID, ADD, DF>(p, tx, tyB, n, hw, fmB, outv, aB, &dflags);
     if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
@@ -1632,6 +1639,10 @@ int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 
 template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     const bool valid = p.valid != nullptr, add = p.addend != nullptr;
+    if (NC == 2 && p.src_b) {                              // (host: 2 channels, valid mask, no addend, no output flags)
+        hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+        return (int)hipGetLastError();
+    }
     if (NC == 2 && p.dst_flags) {                          // (host: only with a valid mask)
         if (add) hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, true, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         else hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
@@ -1698,7 +1709,7 @@ int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 14; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b
+__attribute__((visibility("default"))) int ofl_version(void) { return 15; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -1709,7 +1720,7 @@ __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t v
 
 __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
-    const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
+    const float* src_b, int64_t src_b_bs, const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
     const float* addend, int64_t addend_bs, float a_sign, float g_sign, float* dst, uint8_t* valid,
     int32_t* flow_flags, int32_t* src_flags, int32_t* dst_flags, int32_t n, int32_t c, int32_t h, int32_t w,
     int32_t round_mode, void* stream) {
@@ -1722,6 +1733,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     WarpParams p;
     p.flow = flow; p.flow_bs = flow_bs; p.src = src; p.src_bs = src_bs;
+    p.src_b = nullptr; p.src_b_bs = 0;
     p.src_mask = src_mask; p.src_mask_bs = src_mask_bs; p.flow_mask = flow_mask; p.flow_mask_bs = flow_mask_bs;
     p.addend = addend; p.addend_bs = addend_bs; p.dst = dst; p.valid = valid;
     p.flow_flags = flow_flags; p.src_flags = src_flags; p.dst_flags = nullptr;
@@ -1743,6 +1755,10 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     // LDS-staged fast path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit box coordinates (any width:
     // 16-byte accesses at 4-byte alignment, mask bytes at any alignment)
     const bool lds_ok = g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760;
+    if (src_b) {   // only the staged 2-channel kernel with a valid mask subtracts on the fly: anything else is the caller's job
+        if (!(lds_ok && c == 2 && valid && !addend && !dst_flags && !flow_flags)) return OFL_E_UNSUPPORTED;
+        p.src_b = src_b; p.src_b_bs = src_b_bs;
+    }
     if (lds_ok) {
         const int64_t hw = (int64_t)h * w;
         if (src_flags) {   // the staged path never reads `src` at its own pixel: a separate reduction supplies its flags

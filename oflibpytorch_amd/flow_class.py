@@ -488,8 +488,9 @@ class Flow(object):
         Returns (warped fp32 [N,C,H,W], valid bool [N,H,W] | None) on self.device.
         `flow_sign` / `data_sign` = -1 (forward flows only) restate `(-self)` as the warper / `-t` as the target inside the
         kernel (exact negations; finiteness and zero tests do not depend on the sign), so that switch_ref / invert need
-        no negated copy and no second flag reduction.  `t_minus` (forward flows, past the early exit only): the target
-        is t - t_minus, subtracted inside the kernel (mode 2 's': target `flow - self`, its mask m_flow & m_self)."""
+        no negated copy and no second flag reduction.  `t_minus` (past the early exit only): the target is t - t_minus,
+        subtracted inside the kernel (modes 1 't' / 2 's': target `flow - self`; `tmask` / the two channel masks carry
+        m_flow & m_self)."""
         if self._ref == 's' and not get_pure_pytorch():
             _griddata_unavailable("Flow.apply(ref='s')")
         self._require_finite("Error applying flow to a target: ")
@@ -518,7 +519,7 @@ class Flow(object):
         if self._ref == 't':
             warped, valid, _, _ = _native.warp_bwd(self._vecs, t, src_mask=tmask,
                                                    flow_mask=self._mask if need_valid else None,
-                                                   want_valid=need_valid, round_mode=round_mode)
+                                                   want_valid=need_valid, round_mode=round_mode, src_b=t_minus)
         else:
             # a warped FLOW (2 channels, with its valid mask) brings its flag word along: the splat produces it as a
             # by-product, so that using the result as a warper needs no validation pass of its own
@@ -666,7 +667,12 @@ class Flow(object):
                 # flow - (flow_inv_t + flow_inv_t.apply(self.switch_ref())).apply(self): the inner sum is the fused mode-3
                 # launch, the outer difference the epilogue of the second gather
                 return flow._minus_applied(self.switch_ref()._combine3(flow_inv_t, result_is_warper=True), self)
-            return self.invert().apply(flow - self)                                  # :1763
+            # self.invert().apply(flow - self)   (:1763): the difference is formed while the source box is staged
+            inv = self.invert()
+            if inv._all_zero(_native.FLAG_NZ_THR):
+                return inv.apply(flow - self)
+            warped, valid, _ = inv._warp(flow._vecs, flow._and_masks(self._mask), True, True, t_minus=self._vecs)
+            return Flow._wrap(warped, 't', valid, self._device)
         if ref == 's':                                                               # mode 2, :1768
             # self.apply(flow - self): the difference (and the AND of the two masks) is formed inside the splat
             if self._all_zero(_native.FLAG_NZ_THR) or not get_pure_pytorch():        # (apply's early exit / griddata gate)

@@ -45,9 +45,13 @@ def flow_flags(vecs, mask=None):
 
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
-             a_sign=1.0, g_sign=1.0, round_mode=0, want_flags=False, want_src_flags=False, want_dst_flags=False):
+             a_sign=1.0, g_sign=1.0, round_mode=0, want_flags=False, want_src_flags=False, want_dst_flags=False, src_b=None):
     f = _np(flow, np.float32) * np.float32(flow_sign)
     s = _np(src, np.float32)
+    if src_b is not None:
+        sb = _np(src_b, np.float32)
+        nn = max(s.shape[0], sb.shape[0])
+        s = _bcast(s, nn) - _bcast(sb, nn)
     n = max(f.shape[0], s.shape[0], 1 if src_mask is None else src_mask.shape[0],
             1 if flow_mask is None else flow_mask.shape[0], 1 if addend is None else addend.shape[0])
     s = _bcast(s, n)

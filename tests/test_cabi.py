@@ -32,22 +32,22 @@ def test_argument_validation_needs_no_gpu():
     null = ctypes.c_void_p(0)
     one = ctypes.c_void_p(16)      # never dereferenced: rejected on shape / argument checks first
     # NULL required pointers
-    assert lib.ofl_warp_bwd_f32(null, 0, 1.0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, null, null, null, null, null,
+    assert lib.ofl_warp_bwd_f32(null, 0, 1.0, null, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, null, null, null, null, null,
                                 1, 1, 4, 4, 0, null) == -1
     # bad dims / h*w >= 2^24 (utils.py:1118 fp32 index limit)
-    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
                                 0, 1, 4, 4, 0, null) == -2
-    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
                                 1, 1, 4096, 4096, 0, null) == -2
     # flow_sign must be +-1, round mode 0..2
-    assert lib.ofl_warp_bwd_f32(one, 0, 0.5, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
+    assert lib.ofl_warp_bwd_f32(one, 0, 0.5, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
                                 1, 1, 4, 4, 0, null) == -3
-    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
                                 1, 1, 4, 4, 7, null) == -3
     # dst_flags: two channels and a valid mask only
-    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, one, null, null, one,
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, one, null, null, one,
                                 1, 3, 4, 4, 0, null) == -3
-    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, one,
+    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, one,
                                 1, 2, 4, 4, 0, null) == -3
     assert lib.ofl_flow_flags_f32(null, 0, null, 0, 1e-3, null, 1, 4, 4, null) == -1
     assert lib.ofl_splat_fwd_f32(null, 0, 1.0, null, null, 0, null, 0, 1.0, null, 0, null, 0, null, 0, 0, 0, null,

@@ -489,6 +489,40 @@ def test_splat_of_a_difference_equals_the_materialised_difference(kind, dev):
     assert torch.equal(fused[1], plain[1])
 
 
+@pytest.mark.parametrize("shape", [(2, 70, 132), (1, 37, 50), (2, 9, 3), (1, 300, 400)])
+@pytest.mark.parametrize("kind", ["smooth", "huge", "generic"])
+def test_warp_of_a_difference_equals_the_materialised_difference(shape, kind, dev):
+    """`src_b`: gathering src - src_b (subtracted while the box is staged, or per tap when the box does not fit the LDS)
+    is bit-identical to gathering the materialised difference; shapes / paths the kernel variant does not cover are
+    materialised by the binding."""
+    from oflibpytorch_amd import _native
+    n, h, w = shape
+    flow = _smooth(n, h, w, 1.5 if kind != "huge" else 300.0, 9, dev)
+    a, b = _smooth(n, h, w, 3.0, 10, dev), _smooth(n, h, w, 2.0, 11, dev)
+    g = torch.Generator().manual_seed(5)
+    sm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    kw = dict(src_mask=sm, flow_mask=sm, want_valid=True)
+    try:
+        if kind == "generic":
+            _native.set_warp_path(1)
+        fused = _native.warp_bwd(flow, a, src_b=b, **kw)
+        plain = _native.warp_bwd(flow, a - b, **kw)
+    finally:
+        _native.set_warp_path(0)
+    assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
+
+
+def test_mode1_t_is_the_composed_expression(dev):
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 96, 160
+    g = torch.Generator().manual_seed(12)
+    m1 = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    m2 = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    A, B = ofl.Flow(_smooth(n, h, w, 1.5, 20, dev), 't', m1), ofl.Flow(_smooth(n, h, w, 2.0, 21, dev), 't', m2)
+    x, y = A.combine_with(B, 1), A.invert().apply(B - A)
+    assert torch.equal(x.vecs, y.vecs) and torch.equal(x.mask, y.mask) and x.ref == y.ref == 't'
+
+
 def test_mode2_s_is_the_composed_expression(dev):
     import oflibpytorch_amd as ofl
     n, h, w = 2, 96, 160
