@@ -663,10 +663,10 @@ class Flow(object):
             return self._combine3(flow)
         if mode == 1:
             if ref == 's':                                                           # :1759-1760
-                flow_inv_t = flow.invert('t')
-                # flow - (flow_inv_t + flow_inv_t.apply(self.switch_ref())).apply(self): the inner sum is the fused mode-3
-                # launch, the outer difference the epilogue of the second gather
-                return flow._minus_applied(self.switch_ref()._combine3(flow_inv_t, result_is_warper=True), self)
+                # flow - (flow_inv_t + flow_inv_t.apply(self.switch_ref())).apply(self) with flow_inv_t = flow.invert('t') =
+                # Flow(-flow.vecs, 't'): the inner sum is the fused mode-3 launch (the negation folded into its signs), the
+                # outer difference the epilogue of the second gather
+                return flow._minus_applied(self.switch_ref()._combine3(flow, result_is_warper=True, negated_warper=True), self)
             # self.invert().apply(flow - self)   (:1763): the difference is formed while the source box is staged
             inv = self.invert()
             if inv._all_zero(_native.FLAG_NZ_THR):
@@ -697,19 +697,26 @@ class Flow(object):
             valid = valid & self._mask
         return Flow._wrap(vecs, self._ref, valid, self._device)
 
-    def _combine3(self, flow: FlowAlias, speculative: bool = False, result_is_warper: bool = False) -> FlowAlias:
+    def _combine3(self, flow: FlowAlias, speculative: bool = False, result_is_warper: bool = False,
+                  negated_warper: bool = False) -> FlowAlias:
         """mode 3: 't'  f3 = f2 + G(f2, f1),  m3 = m2 & theta(G(f2, [m1]))           (flow_class.py:1808)
-                   's'  f3 = f1 + G(-f1, f2), m3 = m1 & theta(G(-f1, [m2]))          (flow_class.py:1804)"""
+                   's'  f3 = f1 + G(-f1, f2), m3 = m1 & theta(G(-f1, [m2]))          (flow_class.py:1804)
+        `negated_warper` ('t' only): `flow` stands for Flow(-flow.vecs, 't', flow.mask) -- `flow.invert('t')` of a
+        forward flow -- without the negated copy: positions and addend change sign in the kernel, flags do not."""
+        a_sign = 1.0
         if self._ref == 't':
             warper, sign, src = flow, 1.0, self
+            if negated_warper:
+                sign, a_sign = -1.0, -1.0
         else:
             warper, sign, src = self, -1.0, flow
         if not speculative and warper._all_zero(_native.FLAG_NZ_THR):
             # apply_flow's thresholded early exit inside .apply (utils.py:497): the gather is the identity
-            return warper + Flow._wrap(src._vecs, src._ref, src._and_masks(warper._mask), self._device)
+            w_ = warper._negated('t') if a_sign < 0 else warper
+            return w_ + Flow._wrap(src._vecs, src._ref, src._and_masks(warper._mask), self._device)
         # (`result_is_warper`: the result will warp something next, so its own flag word is worth the ~5 % it costs here)
         res = _native.warp_bwd(warper._vecs, src._vecs, flow_sign=sign, src_mask=src._mask,
-                               flow_mask=warper._mask, want_valid=True, addend=warper._vecs,
+                               flow_mask=warper._mask, want_valid=True, addend=warper._vecs, a_sign=a_sign,
                                want_flags=speculative, want_src_flags=speculative, want_dst_flags=result_is_warper)
         vecs, valid, wf, sf = res[:4]
         if speculative:
