@@ -108,6 +108,22 @@ int ofl_warp_bwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
                      int32_t round_mode, void* stream);
 
 /*
+ * The same warp for 8-bit images (Flow.apply / apply_flow on uint8 targets, flow_class.py:943-951, utils.py:613-618):
+ * src [*,C,H,W] uint8 is read as it is (no float copy); dst is fp32 [N,C,H,W] (dst_is_u8 = 0, any round_mode) or uint8
+ * (dst_is_u8 = 1, round_mode must be OFL_ROUND_U8: round half to even, clamp to [0, 255] -- the values the reference's
+ * `torch.round` / `clamp` / `.to(uint8)` produce).  17 instead of 35 bytes per pixel for C = 3 with masks, and no
+ * conversion passes around the kernel.  Staged kernel only (W >= 4, H >= 2), else OFL_E_UNSUPPORTED: convert and
+ * use ofl_warp_bwd_f32.
+ */
+int ofl_warp_bwd_u8(const float* flow, int64_t flow_bs, float flow_sign,
+                    const uint8_t* src, int64_t src_bs,
+                    const uint8_t* src_mask, int64_t src_mask_bs,
+                    const uint8_t* flow_mask, int64_t flow_mask_bs,
+                    void* dst, int32_t dst_is_u8, uint8_t* valid,
+                    int32_t n, int32_t c, int32_t h, int32_t w,
+                    int32_t round_mode, void* stream);
+
+/*
  * Forward ("s"-reference) splat, pass 1: scatter-add of weight * value into `accum`.
  *
  *   (x, y)  = xy ? (xy_x[n], xy_y[n]) : (gx, gy) + flow_sign * flow[n]

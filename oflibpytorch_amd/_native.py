@@ -15,12 +15,12 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 15              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 16              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
 _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
-            "ofl_splat_tiled_f32", "ofl_flow_flags_f32")
+            "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8")
 _lib = None
 
 
@@ -52,6 +52,7 @@ def load_library(path: str = None):
     lib.ofl_set_option.argtypes = [i32, i32]
     lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p, p,
                                      i32, i32, i32, i32, i32, p]
+    lib.ofl_warp_bwd_u8.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i32, p, i32, i32, i32, i32, i32, p]
     lib.ofl_splat_fwd_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p,
                                       i32, i32, i32, i32, p]
     lib.ofl_splat_finalize_f32.argtypes = [p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
@@ -156,9 +157,10 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
              a_sign=1.0, g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False,
-             want_dst_flags=False, src_b=None):
+             want_dst_flags=False, src_b=None, out_uint8=False):
     """G-family kernel (include/oflib_hip.h: ofl_warp_bwd_f32).  `src_b`: gather src - src_b (subtracted in the kernel
-    where the C ABI supports it, else materialised here).
+    where the C ABI supports it, else materialised here).  A uint8 `src` is read as bytes by ofl_warp_bwd_u8 (no float
+    copy); with `out_uint8` (round mode ROUND_U8 only: the caller is going to `.to(torch.uint8)` anyway) dst is uint8 too.
 
     flow [Nf,2,H,W], src [Ns,C,H,W], masks [*,H,W] bool or None, addend [*,C,H,W] or None.
     Returns (dst [N,C,H,W] fp32, valid [N,H,W] bool | None, flow_flags int32[N] | None, src_flags | None),
@@ -169,6 +171,20 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
     c, h, w = src.shape[1:]
     n = max(flow.shape[0], src.shape[0], 1 if src_b is None else src_b.shape[0], 1 if src_mask is None else src_mask.shape[0],
             1 if flow_mask is None else flow_mask.shape[0], 1 if addend is None else addend.shape[0])
+    if (src.dtype == torch.uint8 and addend is None and src_b is None and not want_flags and not want_dst_flags
+            and w >= 4 and h >= 2):
+        f, fbs = _planes(flow, dev, torch.float32, n, "flow")
+        s8, sbs = _planes(src, dev, torch.uint8, n, "source")
+        sm, smbs = (None, 0) if src_mask is None else _planes(src_mask, dev, torch.bool, n, "source mask")
+        fm, fmbs = (None, 0) if flow_mask is None else _planes(flow_mask, dev, torch.bool, n, "flow mask")
+        as_u8 = bool(out_uint8) and int(round_mode) == ROUND_U8
+        dst = torch.empty((n, c, h, w), dtype=torch.uint8 if as_u8 else torch.float32, device=dev)
+        valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
+        rc = lib.ofl_warp_bwd_u8(_ptr(f), fbs, float(flow_sign), _ptr(s8), sbs, _ptr(sm), smbs, _ptr(fm), fmbs,
+                                 _ptr(dst), int(as_u8), _ptr(valid), n, c, h, w, int(round_mode), _stream(dev))
+        if rc != -4:
+            _check(rc, "ofl_warp_bwd_u8")
+            return dst, valid, None, None
     f, fbs = _planes(flow, dev, torch.float32, n, "flow")
     s, sbs = _planes(src, dev, torch.float32, n, "source")
     sm, smbs = (None, 0) if src_mask is None else _planes(src_mask, dev, torch.bool, n, "source mask")

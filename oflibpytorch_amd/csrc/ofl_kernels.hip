@@ -143,6 +143,20 @@ __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<con
 __device__ __forceinline__ f4 ld4nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p)); }
 __device__ __forceinline__ f2 ld2(const float* p) { return *reinterpret_cast<const f2u*>(p); }
 __device__ __forceinline__ void st4(float* p, f4 v) { *reinterpret_cast<f4u*>(p) = v; }
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p);
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p);
+__device__ __forceinline__ void st32(uint8_t* p, uint32_t v);
+// 8-bit images (the staged warp kernel's uint8 variants): 4 / 2 / 1 pixels of one channel <-> floats
+__device__ __forceinline__ f4 ld4(const uint8_t* p) {
+    const uint32_t b = ld32(p);
+    return (f4){(float)(b & 0xffu), (float)((b >> 8) & 0xffu), (float)((b >> 16) & 0xffu), (float)(b >> 24)};
+}
+__device__ __forceinline__ f2 ld2(const uint8_t* p) { const uint32_t b = ld16(p); return (f2){(float)(b & 0xffu), (float)(b >> 8)}; }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint8_t* p) { return (float)*p; }
+__device__ __forceinline__ void st4(uint8_t* p, f4 v) {            // (values already rounded and clamped to [0, 255])
+    st32(p, (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24));
+}
 __device__ __forceinline__ void st2(float* p, f2 v) { *reinterpret_cast<f2u*>(p) = v; }
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return reinterpret_cast<const U16u*>(p)->v; }
@@ -347,8 +361,8 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
 }
 
 // step 3a: issue the staging loads of a tile into registers (nothing waits here)
-template <int NC, bool VALID, bool SUB = false>
-__device__ __forceinline__ void lds_issue(const WarpParams& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+template <int NC, bool VALID, bool SUB = false, typename TS = float>
+__device__ __forceinline__ void lds_issue(const WarpParams& p, const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                           uint32_t hw, const LdsBox& B, LdsStage<NC>& S, const float* __restrict__ sbb = nullptr) {
     const int tid = threadIdx.x;
     const uint32_t inv = inv20((uint32_t)B.cw);
@@ -406,9 +420,9 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
 }
 
 // step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
-template <int NC, bool VALID, bool INTERIOR, bool SUB = false>
+template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float>
 __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw,
-                                                const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+                                                const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                                 const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
                                                 const float* __restrict__ sbb = nullptr) {
     const int w = p.w, h = p.h;
@@ -468,7 +482,7 @@ __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw
                 f4 t = {0.f, 0.f, 0.f, 0.f};
                 if (ok[j]) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) t[c] = SUB ? sb[c * hw + og] - sbb[c * hw + og] : sb[c * hw + og];
+                    for (int c = 0; c < NC; ++c) t[c] = SUB ? ld1(sb + c * hw + og) - sbb[c * hw + og] : ld1(sb + c * hw + og);
                     if (VALID) t[3] = sm ? (float)(sm[og] != 0) : 1.0f;
                 }
                 tv[j] = t;
@@ -483,13 +497,13 @@ __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw
     }
 }
 
-template <int NC, bool VALID, bool SUB = false>
+template <int NC, bool VALID, bool SUB = false, typename TS = float>
 __device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
-                                           const float* __restrict__ sb, const uint8_t* __restrict__ sm,
+                                           const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                            const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
                                            const float* __restrict__ sbb = nullptr) {
-    if (B.interior) lds_gather_impl<NC, VALID, true, SUB>(p, hw, sb, sm, T, B, smem, outv, sbb);
-    else lds_gather_impl<NC, VALID, false, SUB>(p, hw, sb, sm, T, B, smem, outv, sbb);
+    if (B.interior) lds_gather_impl<NC, VALID, true, SUB, TS>(p, hw, sb, sm, T, B, smem, outv, sbb);
+    else lds_gather_impl<NC, VALID, false, SUB, TS>(p, hw, sb, sm, T, B, smem, outv, sbb);
 }
 
 // the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
@@ -502,7 +516,7 @@ __device__ __forceinline__ void lds_load_addend(const WarpParams& p, int tx, int
 }
 
 // step 4b: valid mask, epilogue (a_sign * addend + g_sign * G, rounding), 16-byte stores
-template <int NC, bool VALID, bool ADD, bool DF = false>
+template <int NC, bool VALID, bool ADD, bool DF = false, typename TD = float>
 __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, int n, uint32_t hw, uint32_t fmask4,
                                           const f4 (&outv)[4], const f4 (&addend)[NC], int* dflags = nullptr) {
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
@@ -519,7 +533,7 @@ __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, i
                 vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
             st32(p.valid + (int64_t)n * hw + pix, vo);
         }
-        float* __restrict__ db = p.dst + (int64_t)n * p.dst_bs;
+        TD* __restrict__ db = reinterpret_cast<TD*>(p.dst) + (int64_t)n * p.dst_bs;
         f4 o01[2];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -539,7 +553,7 @@ __device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, i
     }
 }
 
-template <int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false>
+template <int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParams p) {
     constexpr int NW = kLdsNT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -552,7 +566,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     const int w = p.w, h = p.h;
     const uint32_t hw = (uint32_t)(h * w);
     const float* __restrict__ fu = p.flow + n * p.flow_bs;
-    const float* __restrict__ sb = p.src + n * p.src_bs;
+    const TS* __restrict__ sb = reinterpret_cast<const TS*>(p.src) + n * p.src_bs;      // (uint8 variants: p.src / p.dst point at bytes)
     const float* __restrict__ sbb = SUB ? p.src_b + n * p.src_b_bs : nullptr;
     const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
     const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     LdsStage<NC> S;
     const int sq = p.shear ? lds_slope(p, fu, hw, tx, ty2) : 0;
     lds_coords_box(p, tx, tyA, uA, vA, sq, TA, BA, red[0]);
-    lds_issue<NC, VALID, SUB>(p, sb, sm, hw, BA, S, sbb);       // staging loads of A fly ...
+    lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, BA, S, sbb);   // staging loads of A fly ...
     lds_coords_box(p, tx, tyB, uB, vB, sq, TB, BB, red[1]);     // ... while B's coordinates are computed
     lds_write<NC, VALID>(lds, BA, S);
     lds_barrier();
@@ -594,12 +608,12 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     f4 outv[4], aA[NC], aB[NC];
     const bool reuse = EARLY && NC == 2 && p.add_is_flow;         // block-uniform
     if (EARLY) { if (reuse) { aA[0] = uA; aA[NC - 1] = vA; } else lds_load_addend<NC>(p, tx, tyA, n, hw, aA); }
-    if (haveB) lds_issue<NC, VALID, SUB>(p, sb, sm, hw, BB, S, sbb);   // staging loads of B fly while A is gathered and stored
-    lds_gather<NC, VALID, SUB>(p, hw, sb, sm, TA, BA, smem, outv, sbb);
+    if (haveB) lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, BB, S, sbb);   // staging loads of B fly while A is gathered and stored
+    lds_gather<NC, VALID, SUB, TS>(p, hw, sb, sm, TA, BA, smem, outv, sbb);
     if (EARLY && haveB) { if (reuse) { aB[0] = uB; aB[NC - 1] = vB; } else lds_load_addend<NC>(p, tx, tyB, n, hw, aB); }
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyA, n, hw, aA);
     int dflags = 0;
-    lds_store<NC, VALID, ADD, DF>(p, tx, tyA, n, hw, fmA, outv, aA, &dflags);
+    lds_store<NC, VALID, ADD, DF, TD>(p, tx, tyA, n, hw, fmA, outv, aA, &dflags);
     if (!haveB) {
         if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
         return;
@@ -607,9 +621,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     lds_barrier();
     lds_write<NC, VALID>(lds, BB, S);
     lds_barrier();
-    lds_gather<NC, VALID, SUB>(p, hw, sb, sm, TB, BB, smem, outv, sbb);
+    lds_gather<NC, VALID, SUB, TS>(p, hw, sb, sm, TB, BB, smem, outv, sbb);
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
-    lds_store<NC, VALID, ADD, DF>(p, tx, tyB, n, hw, fmB, outv, aB, &dflags);
+    lds_store<NC, VALID, ADD, DF, TD>(p, tx, tyB, n, hw, fmB, outv, aB, &dflags);
     if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
 }
 
@@ -1658,6 +1672,14 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     return OFL_E_ARG;
 }
 
+// 8-bit images: uint8 source planes, float or uint8 destination (no addend, no flag words)
+template <int NC, typename TD>
+int launch_warp_lds_u8(const WarpParams& p, unsigned grid, hipStream_t st) {
+    if (p.valid) hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, false, false, uint8_t, TD>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+    else hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, false, false, false, false, uint8_t, TD>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+    return (int)hipGetLastError();
+}
+
 inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
 void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, int64_t mask_bs, int32_t* flags, int32_t n,
@@ -1709,7 +1731,7 @@ int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 15; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b
+__attribute__((visibility("default"))) int ofl_version(void) { return 16; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -1796,6 +1818,59 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     if (rc == OFL_OK && dst_flags)                                            // generic kernel: a reduction over the output
         launch_flow_flags(dst, (int64_t)2 * h * w, valid, (int64_t)h * w, dst_flags, n, (int64_t)h * w, st);
     return rc;
+}
+
+__attribute__((visibility("default"))) int ofl_warp_bwd_u8(
+    const float* flow, int64_t flow_bs, float flow_sign, const uint8_t* src, int64_t src_bs,
+    const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
+    void* dst, int32_t dst_is_u8, uint8_t* valid, int32_t n, int32_t c, int32_t h, int32_t w, int32_t round_mode,
+    void* stream) {
+    if (!flow || !src || !dst) return OFL_E_NULL;
+    int rc = check_dims(n, c, h, w);
+    if (rc) return rc;
+    if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
+    if (dst_is_u8 && round_mode != OFL_ROUND_U8) return OFL_E_ARG;       // bytes only hold rounded, clamped values
+    if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
+    if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
+    if (!(g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760)) return OFL_E_UNSUPPORTED;   // staged kernel only
+    WarpParams p = {};
+    p.flow = flow; p.flow_bs = flow_bs; p.src_bs = src_bs;
+    p.src_mask = src_mask; p.src_mask_bs = src_mask_bs; p.flow_mask = flow_mask; p.flow_mask_bs = flow_mask_bs;
+    p.valid = valid;
+    p.n = n; p.c = c; p.h = h; p.w = w;
+    p.flow_sign = flow_sign; p.a_sign = 1.0f; p.g_sign = 1.0f; p.round_mode = round_mode;
+    p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
+    p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
+    p.rcp_wm1 = 1.0f / p.wm1; p.rcp_hm1 = 1.0f / p.hm1;
+    p.lds_bytes = kLdsBytes;
+    p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;
+    p.dst_bs = (int64_t)c * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t hw = (int64_t)h * w;
+    const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
+    for (int32_t c0 = 0; c0 < c; c0 += 3) {                               // channel groups of 3, as ofl_warp_bwd_f32
+        const int32_t nc = (c - c0) < 3 ? (c - c0) : 3;
+        WarpParams q = p;
+        q.c = nc;
+        q.src = reinterpret_cast<const float*>(src + c0 * hw);             // (the uint8 kernels re-read these as byte pointers)
+        q.dst = dst_is_u8 ? reinterpret_cast<float*>(static_cast<uint8_t*>(dst) + c0 * hw) : static_cast<float*>(dst) + c0 * hw;
+        if (c0 > 0) { q.valid = nullptr; q.src_mask = nullptr; }
+        if (dst_is_u8) {
+            switch (nc) {
+                case 1: rc = launch_warp_lds_u8<1, uint8_t>(q, g, st); break;
+                case 2: rc = launch_warp_lds_u8<2, uint8_t>(q, g, st); break;
+                default: rc = launch_warp_lds_u8<3, uint8_t>(q, g, st); break;
+            }
+        } else {
+            switch (nc) {
+                case 1: rc = launch_warp_lds_u8<1, float>(q, g, st); break;
+                case 2: rc = launch_warp_lds_u8<2, float>(q, g, st); break;
+                default: rc = launch_warp_lds_u8<3, float>(q, g, st); break;
+            }
+        }
+        if (rc) return rc;
+    }
+    return OFL_OK;
 }
 
 static int fill_splat(SplatParams& p, const float* flow, int64_t flow_bs, const float* data, int64_t data_bs,

@@ -519,7 +519,8 @@ class Flow(object):
         if self._ref == 't':
             warped, valid, _, _ = _native.warp_bwd(self._vecs, t, src_mask=tmask,
                                                    flow_mask=self._mask if need_valid else None,
-                                                   want_valid=need_valid, round_mode=round_mode, src_b=t_minus)
+                                                   want_valid=need_valid, round_mode=round_mode, src_b=t_minus,
+                                                   out_uint8=not get_pure_pytorch())   # (:943-949: only then is it cast back)
         else:
             # a warped FLOW (2 channels, with its valid mask) brings its flag word along: the splat produces it as a
             # by-product, so that using the result as a warper needs no validation pass of its own

@@ -357,7 +357,7 @@ def apply_flow(flow, target: torch.Tensor, ref: str, mask=None) -> torch.Tensor:
                          .format(flow.shape[0], t.shape[0]))
     rm = _round_mode(dtype)
     if ref == 't':
-        out = _native.warp_bwd(flow, t, round_mode=rm)[0]
+        out = _native.warp_bwd(flow, t, round_mode=rm, out_uint8=True)[0]
     else:
         if not get_pure_pytorch():
             _griddata_unavailable("apply_flow(ref='s')")

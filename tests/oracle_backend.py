@@ -45,7 +45,7 @@ def flow_flags(vecs, mask=None):
 
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
-             a_sign=1.0, g_sign=1.0, round_mode=0, want_flags=False, want_src_flags=False, want_dst_flags=False, src_b=None):
+             a_sign=1.0, g_sign=1.0, round_mode=0, want_flags=False, want_src_flags=False, want_dst_flags=False, src_b=None, out_uint8=False):
     f = _np(flow, np.float32) * np.float32(flow_sign)
     s = _np(src, np.float32)
     if src_b is not None:

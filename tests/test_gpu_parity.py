@@ -489,6 +489,47 @@ def test_splat_of_a_difference_equals_the_materialised_difference(kind, dev):
     assert torch.equal(fused[1], plain[1])
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 70, 132), (1, 1, 37, 50), (2, 4, 33, 47), (1, 3, 16, 4), (2, 3, 9, 3), (1, 3, 300, 400)])
+@pytest.mark.parametrize("kind", ["smooth", "huge", "generic"])
+def test_uint8_images_are_warped_from_their_bytes(shape, kind, dev):
+    """ofl_warp_bwd_u8 (uint8 source read as bytes, float or uint8 destination) against the float kernel on the converted
+    image: identical rounded values, identical valid mask -- including boxes that leave the LDS, narrow frames (binding
+    falls back to the conversion) and more than 3 channels."""
+    from oflibpytorch_amd import _native
+    n, c, h, w = shape
+    flow = _smooth(n, h, w, 1.5 if kind != "huge" else 300.0, 9, dev)
+    g = torch.Generator().manual_seed(7)
+    img = torch.randint(0, 256, (n, c, h, w), generator=g, dtype=torch.uint8).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    try:
+        if kind == "generic":
+            _native.set_warp_path(1)
+        for rm in (_native.ROUND_U8, _native.ROUND_NONE):
+            kw = dict(src_mask=sm, flow_mask=sm, want_valid=True, round_mode=rm)
+            ref = _native.warp_bwd(flow, img.float(), **kw)
+            got = _native.warp_bwd(flow, img, **kw)
+            assert got[0].dtype == torch.float32 and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+            got8 = _native.warp_bwd(flow, img, out_uint8=True, **kw)
+            if rm == _native.ROUND_U8 and kind != "generic" and w >= 4 and h >= 2:
+                assert got8[0].dtype == torch.uint8
+            assert torch.equal(got8[0].float(), ref[0]) and torch.equal(got8[1], ref[1])
+    finally:
+        _native.set_warp_path(0)
+
+
+def test_flow_apply_on_a_uint8_image(dev):
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 96, 160
+    g = torch.Generator().manual_seed(13)
+    img = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).to(dev)
+    f = ofl.Flow(_smooth(n, h, w, 2.0, 20, dev), 't')
+    out, valid = f.apply(img, return_valid_area=True)
+    ref, rvalid = f.apply(img.float(), return_valid_area=True)
+    assert torch.equal(out.float(), torch.clamp(torch.round(ref), 0, 255)) and torch.equal(valid, rvalid)
+    assert torch.equal(ofl.apply_flow(f.vecs, img, 't').float(), torch.clamp(torch.round(ref), 0, 255))
+    assert ofl.apply_flow(f.vecs, img, 't').dtype == torch.uint8
+
+
 @pytest.mark.parametrize("shape", [(2, 70, 132), (1, 37, 50), (2, 9, 3), (1, 300, 400)])
 @pytest.mark.parametrize("kind", ["smooth", "huge", "generic"])
 def test_warp_of_a_difference_equals_the_materialised_difference(shape, kind, dev):
