@@ -1098,27 +1098,37 @@ __global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p)
         const int d = n * (int)p.tiles_img + (miny + tid / ntx) * p.tiles_x + (minx + tid % ntx);
         const int cnt = lcount[tid];
         const int start = atomicAdd(&p.cursor[d], cnt);          // this block's records are start .. start + cnt - 1 of the queue
-        int b0 = -1, b1 = -1, s0 = 0;
-        if (start + cnt > kSpPrim) {                             // some of them go to blocks beyond the primary region
-            if (start + cnt > (1 + kSpSlots) * kSpPrim) {
-                atomicOr(p.overflow, 1);
-            } else {
-                s0 = (max(start, kSpPrim) - kSpPrim) / kSpPrim;
-                const int s1 = (start + cnt - 1 - kSpPrim) / kSpPrim;        // (cnt <= 512: at most two slots)
-                auto claim = [&](int slot) -> int {              // the block of this slot: draw one if nobody has yet
-                    int32_t* e = &p.sec[(int64_t)d * kSpSlots + slot];
-                    int cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cur < 0) {
-                        const int mine = atomicAdd(p.sec_count, 1);
-                        if (mine >= p.nsec) { atomicOr(p.overflow, 1); return -1; }
-                        const int prev = atomicCAS(e, -1, mine);             // (a lost race only leaks the block drawn)
-                        cur = prev < 0 ? mine : prev;
-                    }
-                    return cur;
-                };
-                b0 = claim(s0);
-                b1 = s1 != s0 ? claim(s1) : b0;
+        // Records beyond the primary region go to the block of their slot of kSpPrim queue positions.  Exactly ONE block is
+        // drawn per slot, whoever comes first: the first arrival swaps the slot's entry from -1 (none) to -2 (being
+        // drawn), draws and publishes; everybody else waits for the published id.  (Drawing first and swapping after
+        // would leak a block per lost race -- and make running out of blocks, hence the choice of path and the last bits
+        // of the result, depend on timing.)  All of a wave's draws are published before any of its lanes waits, and a wait
+        // is always for a wave that is already past its own draws: no cycle.
+        int b0 = -1, b1 = -1, s0 = 0, s1 = 0;
+        const bool need = start + cnt > kSpPrim && start + cnt <= (1 + kSpSlots) * kSpPrim;
+        if (start + cnt > (1 + kSpSlots) * kSpPrim) atomicOr(p.overflow, 1);
+        if (need) {
+            s0 = (max(start, kSpPrim) - kSpPrim) / kSpPrim;
+            s1 = (start + cnt - 1 - kSpPrim) / kSpPrim;                      // (cnt <= 512: at most two slots)
+            // (the entry's value is all that is communicated: relaxed accesses served by L2 are enough)
+            for (int slot = s0; slot <= s1; ++slot) {
+                int32_t* e = &p.sec[(int64_t)d * kSpSlots + slot];
+                int cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == -1 && atomicCAS(e, -1, -2) == -1) {
+                    const int mine = atomicAdd(p.sec_count, 1);
+                    if (mine >= p.nsec) atomicOr(p.overflow, 1);
+                    cur = mine < p.nsec ? mine : -3;                         // (-3: none left)
+                    __hip_atomic_store(e, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (slot == s0) b0 = cur; else b1 = cur;
             }
+            if (s1 == s0) b1 = b0;
+        }
+        __builtin_amdgcn_wave_barrier();                                     // (the waits stay behind the draws)
+        if (need) {
+            while (b0 == -1 || b0 == -2) b0 = __hip_atomic_load(&p.sec[(int64_t)d * kSpSlots + s0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s1 == s0) b1 = b0;
+            while (b1 == -1 || b1 == -2) b1 = __hip_atomic_load(&p.sec[(int64_t)d * kSpSlots + s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lbase[tid] = start; lsec[tid] = b0; lsec1[tid] = b1; lslot[tid] = s0; ltile[tid] = d;
     }
@@ -1955,7 +1965,7 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 constexpr int kSpRecFloats = 6;   // floats per record: x, y, key (+ mask-channel bit), up to 3 data channels
 // workspace words of one pass of `images` frames: header | queue lengths | secondary block ids | primary regions |
 // secondary blocks
-static int64_t splat_sec_blocks(int64_t tiles) { return (tiles + kSpSecDiv - 1) / kSpSecDiv + 64; }   // (measured: 0.07 / 0.2 / 0.3 per tile drawn at sigma 8 / 12 / 16)
+static int64_t splat_sec_blocks(int64_t tiles) { return (tiles + kSpSecDiv - 1) / kSpSecDiv + 64; }   // (measured: 0.02 / 0.06 / 0.09 per tile drawn at sigma 8 / 12 / 16)
 static int64_t splat_pass_words(int64_t images, int32_t h, int32_t w) {
     const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
     return 8 + (((1 + kSpSlots) * tiles + 3) & ~(int64_t)3) + kSpRecFloats * (int64_t)kSpPrim * (tiles + splat_sec_blocks(tiles));
