@@ -208,7 +208,7 @@ def main():
                         "step_GBs": round((BYTES_APPLY + BYTES_COMBINE) * px / (ms_step * 1e-3) / 1e9, 1)},
             "value_with_flow_construction": round(world * px / (el2 / k2) / 1e6, 1),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # (the CPU baseline is a single-node, N = 1 figure)
             # 64 OpenMP threads is where the oracle peaks on the 2 x 64-core host of the GPU box (tools/cpu_threads_probe.py)
             out["cpu_baseline"] = cpu_baseline(h, w, args.cpu_seconds, min(os.cpu_count() or 1, 64))
         print(json.dumps(out))
