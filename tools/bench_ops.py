@@ -66,6 +66,9 @@ def main():
                 rows.append(("apply 's' C=3 +valid", 35, timeit(lambda: A.apply(img, target_mask=tm, return_valid_area=True), a.iters)))
             continue
         rows.append(("apply '%s' C=3 +valid" % ref, 35, timeit(lambda: A.apply(img, target_mask=tm, return_valid_area=True), a.iters)))
+        if ref == 't':
+            img8 = img.to(torch.uint8)
+            rows.append(("apply 't' uint8 C=3 +valid", 26, timeit(lambda: A.apply(img8, target_mask=tm, return_valid_area=True), a.iters)))
         rows.append(("switch_ref %s" % ref, 18, timeit(lambda: A.switch_ref(), a.iters)))
         for mode in (3, 2, 1):
             rows.append(("combine_with mode %d '%s'" % (mode, ref), 27, timeit(lambda: A.combine_with(B, mode), a.iters)))
