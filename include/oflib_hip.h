@@ -234,6 +234,17 @@ int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
                        const uint8_t* mask, int64_t mask_bs, float thr,
                        int32_t* flags, int32_t n, int32_t h, int32_t w, void* stream);
 
+/*
+ * fp16-stored flows (BASELINE config 5): dst[N,2,H,W] fp32 = (float) src, flags[n] |= flag word of that image under
+ * `mask` -- the reference's entry conversion `vecs.float()` (utils.py:95,118) and its validation in ONE pass (12 B/px
+ * instead of 12 + 9).  The caller zeroes `flags`.  src [*,2,H,W] fp16 with H*W % 4 == 0 and 8-byte aligned planes, dst
+ * 16-byte aligned, mask planes 4-byte aligned; otherwise OFL_E_UNSUPPORTED (convert, then ofl_flow_flags_f32).
+ */
+int ofl_flow_from_f16(const void* src_f16, int64_t src_bs,
+                      const uint8_t* mask, int64_t mask_bs,
+                      float* dst, int32_t* flags,
+                      int32_t n, int32_t h, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,12 +15,12 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 16              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 17              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
 _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
-            "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8")
+            "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16")
 _lib = None
 
 
@@ -52,6 +52,7 @@ def load_library(path: str = None):
     lib.ofl_set_option.argtypes = [i32, i32]
     lib.ofl_warp_bwd_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, p, i64, f32, f32, p, p, p, p, p,
                                      i32, i32, i32, i32, i32, p]
+    lib.ofl_flow_from_f16.argtypes = [p, i64, p, i64, p, p, i32, i32, i32, p]
     lib.ofl_warp_bwd_u8.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i32, p, i32, i32, i32, i32, i32, p]
     lib.ofl_splat_fwd_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p,
                                       i32, i32, i32, i32, p]
@@ -153,6 +154,24 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
     _check(lib.ofl_flow_flags_f32(_ptr(v), vbs, _ptr(m), mbs, THRESHOLD, _ptr(flags), n, h, w, _stream(dev)),
            "ofl_flow_flags_f32")
     return flags
+
+
+def flow_from_half(vecs16: torch.Tensor, mask: torch.Tensor = None):
+    """fp16-stored flow [N,2,H,W] -> (fp32 copy, flag words int32[N]) in one pass (ofl_flow_from_f16); shapes / alignments
+    the kernel does not take are converted with torch and flagged by ofl_flow_flags_f32."""
+    lib, dev = load_library(), device()
+    n, _, h, w = vecs16.shape
+    v, vbs = _planes(vecs16, dev, torch.float16, n, "flow")
+    if vbs != 0 or n == 1:
+        m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+        dst = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+        flags = torch.zeros(n, dtype=torch.int32, device=dev)
+        rc = lib.ofl_flow_from_f16(_ptr(v), vbs, _ptr(m), mbs, _ptr(dst), _ptr(flags), n, h, w, _stream(dev))
+        if rc != -4:
+            _check(rc, "ofl_flow_from_f16")
+            return dst, flags
+    dst = vecs16.to(dev).float()
+    return dst, flow_flags(dst, mask)
 
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,

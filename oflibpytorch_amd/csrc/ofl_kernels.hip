@@ -1620,6 +1620,45 @@ __global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict
     if ((threadIdx.x & 63) == 0) flag_or(&flags[n], f);
 }
 
+// fp16-stored flows (BASELINE config 5): the reference's entry conversion `vecs.float()` (utils.py:95,118) and the flag
+// reduction in ONE pass -- 4 pixels per thread and step: 8-byte fp16 loads, 16-byte fp32 stores, one mask dword.
+// Needs hw % 4 == 0 and 8 / 16-byte aligned planes (else the binding converts with torch and calls ofl_flow_flags_f32).
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void flow_f16_kernel(const _Float16* __restrict__ src, int64_t src_bs,
+                                                       const uint8_t* __restrict__ mask, int64_t mask_bs,
+                                                       float* __restrict__ dst, int32_t* __restrict__ flags, int64_t hw) {
+    const int n = blockIdx.y;
+    const _Float16* su = src + n * src_bs;
+    float* du = dst + (int64_t)n * 2 * hw;
+    const uint8_t* mk = mask ? mask + n * mask_bs : nullptr;
+    int f = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, hw4 = hw >> 2;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < hw4; i0 += 4 * stride) {
+        h4 a[4], b[4]; uint32_t m4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                             // four independent groups in flight
+            const int64_t i = i0 + r * stride;
+            if (i < hw4) {
+                a[r] = reinterpret_cast<const h4*>(su)[i]; b[r] = reinterpret_cast<const h4*>(su + hw)[i];
+                m4[r] = mk ? reinterpret_cast<const uint32_t*>(mk)[i] : 0x01010101u;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = i0 + r * stride;
+            if (i < hw4) {
+                const f4 u = {(float)a[r][0], (float)a[r][1], (float)a[r][2], (float)a[r][3]};
+                const f4 v = {(float)b[r][0], (float)b[r][1], (float)b[r][2], (float)b[r][3]};
+                reinterpret_cast<f4*>(du)[i] = u; reinterpret_cast<f4*>(du + hw)[i] = v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f |= flag_bits(u[k], v[k], ((m4[r] >> (8 * k)) & 0xffu) != 0u);
+            }
+        }
+    }
+    f = wave_or_flags(f);
+    if ((threadIdx.x & 63) == 0) flag_or(&flags[n], f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
@@ -1741,7 +1780,7 @@ int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 16; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8
+__attribute__((visibility("default"))) int ofl_version(void) { return 17; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -2110,6 +2149,25 @@ __attribute__((visibility("default"))) int ofl_flow_flags_f32(const float* flow,
     if (rc) return rc;
     if (thr != kZeroThr) return OFL_E_ARG;  // the reference's DEFAULT_THRESHOLD is the only value on the path
     launch_flow_flags(flow, flow_bs, mask, mask_bs, flags, n, (int64_t)h * w, (hipStream_t)stream);
+    return (int)hipGetLastError();
+}
+
+__attribute__((visibility("default"))) int ofl_flow_from_f16(const void* src_f16, int64_t src_bs,
+                                                             const uint8_t* mask, int64_t mask_bs, float* dst,
+                                                             int32_t* flags, int32_t n, int32_t h, int32_t w,
+                                                             void* stream) {
+    if (!src_f16 || !dst || !flags) return OFL_E_NULL;
+    int rc = check_dims(n, 2, h, w);
+    if (rc) return rc;
+    const int64_t hw = (int64_t)h * w;
+    if ((hw % 4) != 0 || !aligned_to(src_f16, 8) || (src_bs % 4) != 0 || !aligned_to(dst, 16) ||
+        (mask && (!aligned_to(mask, 4) || (mask_bs % 4) != 0)))
+        return OFL_E_UNSUPPORTED;
+    int64_t bx = (hw / 4 + 1023) / 1024, cap = 512 / n;
+    cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(flow_f16_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const _Float16*>(src_f16), src_bs, mask, mask_bs, dst, flags, hw);
     return (int)hipGetLastError();
 }
 

@@ -35,7 +35,8 @@ class Flow(object):
         self._flag_cache = None
         self._pending_flags = None
         self._mask = None
-        self._vecs = get_valid_vecs(flow_vectors, error_string="Error setting flow vectors: ", _check_finite=False)
+        self._vecs = get_valid_vecs(flow_vectors, error_string="Error setting flow vectors: ", _check_finite=False,
+                                    _keep_half=True)
         self._device = self._vecs.device
         try:
             self.ref = ref
@@ -44,10 +45,19 @@ class Flow(object):
                 self._mask = m.to(self._vecs.device)
         except (TypeError, ValueError):
             self._mask = None
+            self._from_half()
             self._require_finite("Error setting flow vectors: ")   # the vecs error comes first in the reference
             raise
+        self._from_half()
         self._require_finite("Error setting flow vectors: ")
         self.device = device
+
+    def _from_half(self):
+        """fp16-stored vectors on a HIP device (BASELINE config 5): the reference's `.float()` (utils.py:95,118) and the
+        validation reduction run as one kernel, now that the mask is known."""
+        if self._vecs.dtype == torch.float16:
+            self._vecs, flags = _native.flow_from_half(self._vecs, self._mask)
+            self._set_pending_flags(flags)
 
     @classmethod
     def _wrap(cls, vecs: torch.Tensor, ref: str, mask, device=None, flags: torch.Tensor = None,

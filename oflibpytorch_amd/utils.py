@@ -54,7 +54,7 @@ def _flags_to_host(flags: torch.Tensor) -> list:
 
 
 def get_valid_vecs(vecs: Any, desired_shape: Union[tuple, list] = None, error_string: str = None,
-                   _check_finite: bool = True) -> torch.Tensor:
+                   _check_finite: bool = True, _keep_half: bool = False) -> torch.Tensor:
     """utils.py:72-118 -> N-2-H-W float tensor.  ``_check_finite=False`` is for internal callers that get the
     finiteness flag as a by-product of the kernel they are about to launch."""
     error_string = '' if error_string is None else error_string
@@ -72,6 +72,8 @@ def get_valid_vecs(vecs: Any, desired_shape: Union[tuple, list] = None, error_st
             vecs = move_axis(vecs, -1, 1)
         else:
             raise ValueError(error_string + "Input needs to be shape (N-)H-W-2 or (N-)2-H-W")
+    if _keep_half and not _check_finite and vecs.dtype == torch.float16 and vecs.device.type == 'cuda':
+        return vecs          # Flow.__init__ converts and validates in one fused pass once the mask is known
     vecs = vecs.float()
     if _check_finite:
         if vecs.device.type == 'cpu' and not torch.cuda.is_available():

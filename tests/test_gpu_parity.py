@@ -351,6 +351,29 @@ def test_compressing_flows_stay_exact(patch, dev):
     assert np.array_equal(out[3].cpu().numpy(), rwarped)
 
 
+@pytest.mark.parametrize("shape", [(3, 70, 132), (2, 37, 50), (1, 9, 3), (2, 64, 96)])
+def test_flows_stored_in_fp16_are_converted_and_validated_in_one_pass(shape, dev):
+    """ofl_flow_from_f16 (Flow(fp16 tensor) on a HIP device): the fp32 vectors are exactly `.float()`, the flag words those
+    of ofl_flow_flags_f32 over them; a NaN still raises the reference's ValueError; odd sizes take the torch conversion."""
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import _native
+    n, h, w = shape
+    v16 = _smooth(n, h, w, 2.0, 31, dev).half()
+    v16[0, :, : h // 2] = 0
+    g = torch.Generator().manual_seed(3)
+    m = (torch.rand(n, h, w, generator=g) > 0.3).to(dev)
+    got, flags = _native.flow_from_half(v16, m)
+    assert got.dtype == torch.float32 and torch.equal(got, v16.float())
+    assert flags.cpu().tolist() == _native.flow_flags(v16.float(), m).cpu().tolist()
+    f = ofl.Flow(v16, 't', m)
+    assert f.vecs.dtype == torch.float32 and torch.equal(f.vecs, v16.float())
+    assert f._flags() == [int(x) for x in _native.flow_flags(v16.float(), m).cpu().tolist()]
+    bad = v16.clone()
+    bad[n - 1, 1, h - 1, w - 1] = float('nan')
+    with pytest.raises(ValueError):
+        ofl.Flow(bad, 't', m)
+
+
 def test_queue_blocks_are_drawn_once_per_slot(dev):
     """Queue positions beyond a tile's primary region live in blocks drawn from a shared pool.  Exactly one block per slot
     must be drawn, whatever the timing of the route blocks: a leak per lost race would make running out of blocks -- and
