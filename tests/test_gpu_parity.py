@@ -498,10 +498,14 @@ def test_splat_output_flags_equal_a_flag_pass_over_the_output(kind, dev):
         if kind == "general_path":
             _native.set_splat_path(1)
         out = _native.splat_fwd(flow, data, weight_mask=wm, chan_mask_a=ca, want_valid=True, want_dst_flags=True)
+        _native.set_splat_pass_images(1)                     # ... and with one image per pass (flag words per pass)
+        out1 = _native.splat_fwd(flow, data, weight_mask=wm, chan_mask_a=ca, want_valid=True, want_dst_flags=True)
     finally:
         _native.set_splat_path(0)
+        _native.set_splat_pass_images(0)
     expect = _native.flow_flags(out[0], out[1])
     assert out[4].cpu().tolist() == expect.cpu().tolist()
+    assert out1[4].cpu().tolist() == _native.flow_flags(out1[0], out1[1]).cpu().tolist()
     if kind == "zero":
         assert all((f & _native.FLAG_NZ) == 0 for f in out[4].cpu().tolist())
     if kind == "tiny":
