@@ -245,6 +245,70 @@ int ofl_flow_from_f16(const void* src_f16, int64_t src_bs,
                       float* dst, int32_t* flags,
                       int32_t n, int32_t h, int32_t w, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Either side of the path: backward passes, point tracking, padding extents.
+ * ---------------------------------------------------------------------------------------------- */
+
+/*
+ * Backward pass of ofl_warp_bwd_f32 (the reference relies on autograd through F.grid_sample, utils.py:555, and through
+ * normalise_coords / `grid - flow`, utils.py:462-465, 549; differentiability is asserted by its tests, e.g.
+ * test_utils.py:500):
+ *   grad_src[n,c,tap] += g_scale * w_tap * grad_out[n,c]       float atomics; grad_src is ZEROED BY THE CALLER; its batch
+ *                                                               stride may be 0 when the forward source was broadcast
+ *   grad_flow[n,:]     = -flow_sign * d(sample)/d(position)     [N,2,H,W], written (not accumulated); a broadcast flow's
+ *                                                               gradient is the caller's sum over n
+ * flow / src as in the forward call (src = the field that was gathered, i.e. src - src_b where that was used); grad_out
+ * [N,C,H,W] contiguous; g_scale = the forward g_sign.  Either output may be NULL (not both).  Sums are not in ATen's CPU
+ * order: results agree with the reference's autograd within fp32 rounding (tests: rtol 1e-4 of the gradient scale).
+ */
+int ofl_warp_bwd_grad_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                          const float* src, int64_t src_bs,
+                          const float* grad_out, float g_scale,
+                          float* grad_src, int64_t grad_src_bs, float* grad_flow,
+                          int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
+/*
+ * Backward pass of the forward splat (autograd through utils.py:1098-1144 and :1185-1203 in the reference; claims at
+ * utils.py:1079-1080, 1167; asserted at test_utils.py:1113-1114).  A gather per source pixel, no atomics:
+ *   grad_data[n,c,i] = sum_k w_ik * grad_out[n,c,p_ik] / max(D[p_ik], 1e-3)        (+ grad_out[n,c,i] where i was un-occlude-filled)
+ *   grad_xy[n,0|1,i] = d/dx, d/dy of the same sums through the corner weights (and through D where D >= 1e-3)
+ * flow|xs,ys / data (the data actually splatted: data_sign * (data - data_b)) / weight_mask / occlude as in the forward
+ * call; out [N,C,H,W] and density [N,H,W] are the forward results (out before any rounding); grad_out [N,C,H,W];
+ * grad_density optional [N,H,W] (upstream gradient of the density output).  grad_data [N,C,H,W], grad_xy [N,2,H,W]
+ * (x then y; for a flow operand grad_flow = flow_sign * grad_xy) -- either may be NULL.  C <= 8 per call, else
+ * OFL_E_UNSUPPORTED (split the channels).
+ */
+int ofl_splat_grad_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                       const float* xs, const float* ys, int64_t xy_bs,
+                       const float* data, int64_t data_bs,
+                       const uint8_t* weight_mask, int64_t weight_mask_bs, int32_t occlude,
+                       const float* out, const float* density,
+                       const float* grad_out, const float* grad_density,
+                       float* grad_data, float* grad_xy,
+                       int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
+/*
+ * Sparse point sampler of track_pts (utils.py:1004-1014, 1033-1035): pts [*,M,2] fp32 as (y, x); out[n,m] = pts + the
+ * flow bilinearly sampled there (flip -> normalise_coords -> grid_sample(align_corners=True) -> flip: same fp32 operation
+ * order and FMA chain as the dense warp), rows with a NaN set to 0.  pts_bs = 0 broadcasts one point list.
+ * ..._grad: grad_flow [N,2,H,W] (float atomics; zeroed by the caller) and / or grad_pts [N,M,2].
+ */
+int ofl_sample_pts_f32(const float* flow, int64_t flow_bs, const float* pts, int64_t pts_bs, float* out,
+                       int32_t n, int32_t m, int32_t h, int32_t w, void* stream);
+int ofl_sample_pts_grad_f32(const float* flow, int64_t flow_bs, const float* pts, int64_t pts_bs,
+                            const float* grad_out, float* grad_flow, float* grad_pts,
+                            int32_t n, int32_t m, int32_t h, int32_t w, void* stream);
+
+/*
+ * Extents of the positions a flow reaches, under its mask -- the reduction of Flow.get_padding (flow_class.py:1196-1219):
+ *   pos = -(sign * thr(v) - grid) per component (thr: threshold_vectors, |v| < 1e-3 -> 0); sign = +1 for 't', -1 for 's'
+ *   extents[n] = { min y, max y, min x, max x, any valid pixel (0 / 1) }   fp32[N][5]
+ * workspace int32[5 N] (scratch).  min / max are exact in any order.
+ */
+int ofl_flow_extents_f32(const float* flow, int64_t flow_bs, const uint8_t* mask, int64_t mask_bs, float sign,
+                         int32_t* workspace, float* extents, int32_t n, int32_t h, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,12 +15,14 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 17              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 18              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
 _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
-            "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16")
+            "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
+            "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
+            "ofl_flow_extents_f32")
 _lib = None
 
 
@@ -34,11 +36,20 @@ def load_library(path: str = None):
     if _lib is not None and path is None:
         return _lib
     path = path or os.environ.get("OFL_HIP_LIB") or _build.LIB_PATH   # OFL_HIP_LIB: A/B of two builds (tools/ab_warp.py)
-    if not os.path.exists(path):
+    stale = False
+    if os.path.abspath(path) == os.path.abspath(_build.LIB_PATH):
+        try:                                    # the in-tree library is rebuilt when a source or the header is newer
+            stale = _build.needs_build()
+        except OSError:
+            stale = False
+    if not os.path.exists(path) or stale:
         try:
             _build.build()
         except Exception as exc:  # noqa: BLE001
-            raise NativeUnavailable("oflibpytorch_amd: %s is missing and could not be built: %s" % (path, exc))
+            if not os.path.exists(path):
+                raise NativeUnavailable("oflibpytorch_amd: %s is missing and could not be built: %s" % (path, exc))
+            import warnings                      # (no compiler here: run what is there, the ABI check below still applies)
+            warnings.warn("oflibpytorch_amd: %s is older than its sources and could not be rebuilt: %s" % (path, exc))
     try:
         lib = ctypes.CDLL(path)
     except OSError as exc:
@@ -63,6 +74,11 @@ def load_library(path: str = None):
     lib.ofl_splat_tiled_pass_images.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                         p, p, i64, p, i32, i32, i32, i32, i32, p]
+    lib.ofl_warp_bwd_grad_f32.argtypes = [p, i64, f32, p, i64, p, f32, p, i64, p, i32, i32, i32, i32, p]
+    lib.ofl_splat_grad_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, p, i64, i32, p, p, p, p, p, p, i32, i32, i32, i32, p]
+    lib.ofl_sample_pts_f32.argtypes = [p, i64, p, i64, p, i32, i32, i32, i32, p]
+    lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
+    lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
     lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
@@ -103,12 +119,25 @@ def exported_symbols():
     return _SYMBOLS
 
 
-def device() -> torch.device:
-    """The HIP device the kernels run on (torch's current device)."""
+def device(*operands) -> torch.device:
+    """The HIP device the kernels run on: the device of the first operand that already lives on one (the flow comes
+    first in every primitive), else torch's current device."""
     if not torch.cuda.is_available():
         raise NativeUnavailable("oflibpytorch_amd: no HIP device visible -- this package has no CPU fallback "
                                 "(its compute path is libofl_hip.so on MI355X)")
+    for t in operands:
+        if isinstance(t, torch.Tensor) and t.device.type == 'cuda':
+            return t.device
     return torch.device('cuda', torch.cuda.current_device())
+
+
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _on(dev):
+    """Launch context: kernels go to the current stream OF THE OPERANDS' DEVICE, whatever torch's current device is."""
+    return torch.cuda.device(dev)
 
 
 def _check(rc: int, what: str):
@@ -146,37 +175,63 @@ def _ptr(t):
 # ------------------------------------------------------------------------------------------------
 def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
     """Flag word per batch element (bits: FLAG_*), int32 tensor [N] on the HIP device (no host sync)."""
-    lib, dev = load_library(), device()
+    lib, dev = load_library(), device(vecs, mask)
     n, _, h, w = vecs.shape
-    v, vbs = _planes(vecs, dev, torch.float32, n, "flow")
-    m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
-    flags = torch.zeros(n, dtype=torch.int32, device=dev)
-    _check(lib.ofl_flow_flags_f32(_ptr(v), vbs, _ptr(m), mbs, THRESHOLD, _ptr(flags), n, h, w, _stream(dev)),
-           "ofl_flow_flags_f32")
+    with _on(dev):
+        v, vbs = _planes(vecs.detach(), dev, torch.float32, n, "flow")
+        m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+        flags = torch.zeros(n, dtype=torch.int32, device=dev)
+        _check(lib.ofl_flow_flags_f32(_ptr(v), vbs, _ptr(m), mbs, THRESHOLD, _ptr(flags), n, h, w, _stream(dev)),
+               "ofl_flow_flags_f32")
     return flags
 
 
 def flow_from_half(vecs16: torch.Tensor, mask: torch.Tensor = None):
     """fp16-stored flow [N,2,H,W] -> (fp32 copy, flag words int32[N]) in one pass (ofl_flow_from_f16); shapes / alignments
     the kernel does not take are converted with torch and flagged by ofl_flow_flags_f32."""
-    lib, dev = load_library(), device()
+    lib, dev = load_library(), device(vecs16, mask)
     n, _, h, w = vecs16.shape
-    v, vbs = _planes(vecs16, dev, torch.float16, n, "flow")
-    if vbs != 0 or n == 1:
-        m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
-        dst = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
-        flags = torch.zeros(n, dtype=torch.int32, device=dev)
-        rc = lib.ofl_flow_from_f16(_ptr(v), vbs, _ptr(m), mbs, _ptr(dst), _ptr(flags), n, h, w, _stream(dev))
-        if rc != -4:
-            _check(rc, "ofl_flow_from_f16")
-            return dst, flags
+    if _wants_grad(vecs16):                  # the reference's `.float()` is differentiable (utils.py:118): keep the graph
+        dst = vecs16.to(dev).float()
+        return dst, flow_flags(dst, mask)
+    with _on(dev):
+        v, vbs = _planes(vecs16, dev, torch.float16, n, "flow")
+        if vbs != 0 or n == 1:
+            m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+            dst = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+            flags = torch.zeros(n, dtype=torch.int32, device=dev)
+            rc = lib.ofl_flow_from_f16(_ptr(v), vbs, _ptr(m), mbs, _ptr(dst), _ptr(flags), n, h, w, _stream(dev))
+            if rc != -4:
+                _check(rc, "ofl_flow_from_f16")
+                return dst, flags
     dst = vecs16.to(dev).float()
     return dst, flow_flags(dst, mask)
 
 
-def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
-             a_sign=1.0, g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False,
-             want_dst_flags=False, src_b=None, out_uint8=False):
+def warp_bwd(flow, src, **kw):
+    """G-family primitive; see `_warp_bwd_raw` for the arguments.  When autograd is recording and the flow, the source,
+    `src_b` or the addend requires a gradient, the launch goes through `_autograd.WarpFn` (backward kernels:
+    ofl_warp_bwd_grad_f32) -- the reference's outputs are differentiable wrt flow and target (utils.py:555)."""
+    if _wants_grad(flow, src, kw.get("addend"), kw.get("src_b")):
+        from . import _autograd
+        return _autograd.warp(flow, src, **kw)
+    with _on(device(flow, src)):
+        return _warp_bwd_raw(flow, src, **kw)
+
+
+def splat_fwd(flow, data, **kw):
+    """P-family primitive; see `_splat_fwd_raw`.  Differentiable wrt flow (or xs, ys), data and data_b through
+    `_autograd.SplatFn` (ofl_splat_grad_f32) when autograd is recording (utils.py:1079-1080, 1167)."""
+    if _wants_grad(flow, data, kw.get("xs"), kw.get("ys"), kw.get("data_b")):
+        from . import _autograd
+        return _autograd.splat(flow, data, **kw)
+    with _on(device(flow, data, kw.get("xs"))):
+        return _splat_fwd_raw(flow, data, **kw)
+
+
+def _warp_bwd_raw(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
+                  a_sign=1.0, g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False,
+                  want_dst_flags=False, src_b=None, out_uint8=False):
     """G-family kernel (include/oflib_hip.h: ofl_warp_bwd_f32).  `src_b`: gather src - src_b (subtracted in the kernel
     where the C ABI supports it, else materialised here).  A uint8 `src` is read as bytes by ofl_warp_bwd_u8 (no float
     copy); with `out_uint8` (round mode ROUND_U8 only: the caller is going to `.to(torch.uint8)` anyway) dst is uint8 too.
@@ -186,7 +241,7 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
     all on the HIP device, N = max batch; with `want_dst_flags` (2 channels, valid wanted) a fifth result: the flag
     words int32[N] of dst read as a flow under `valid`.
     """
-    lib, dev = load_library(), device()
+    lib, dev = load_library(), device(flow, src)
     c, h, w = src.shape[1:]
     n = max(flow.shape[0], src.shape[0], 1 if src_b is None else src_b.shape[0], 1 if src_mask is None else src_mask.shape[0],
             1 if flow_mask is None else flow_mask.shape[0], 1 if addend is None else addend.shape[0])
@@ -229,9 +284,9 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
     return dst, valid, ff, sf
 
 
-def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
-              chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False,
-              round_mode=ROUND_NONE, want_mask_chan=False, want_dst_flags=False, data_b=None):
+def _splat_fwd_raw(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
+                   chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False,
+                   round_mode=ROUND_NONE, want_mask_chan=False, want_dst_flags=False, data_b=None):
     """P-family kernels (ofl_splat_tiled_f32, or ofl_splat_fwd_f32 + ofl_splat_finalize_f32).
 
     Either flow [Nf,2,H,W] (endpoints computed in-kernel) or explicit positions xs, ys [N,H,W].
@@ -240,7 +295,7 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     `data_b` [*,C,H,W], C <= 2: splat data - data_b (one fp32 subtraction in the kernel instead of a materialised difference).
     `want_dst_flags` (2-channel data): a fifth result, the device flag words int32[N] of dst read as a flow under `valid`.
     """
-    lib, dev = load_library(), device()
+    lib, dev = load_library(), device(flow, data, xs)
     c, h, w = data.shape[1:]
     if want_dst_flags and c != 2:
         raise ValueError("oflibpytorch_amd: output flags are defined for 2-channel data only")
@@ -298,3 +353,112 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     if want_dst_flags:
         return dst, (mchan if want_mask_chan else valid), density, warped, dflags
     return dst, (mchan if want_mask_chan else valid), density, warped
+
+
+# ------------------------------------------------------------------------------------------------
+# backward passes, point sampler, extents (csrc/ofl_aux_kernels.hip)
+# ------------------------------------------------------------------------------------------------
+def warp_bwd_grad(flow, src, grad_out, *, flow_sign=1.0, g_scale=1.0, want_src=True, want_flow=True):
+    """Backward of G (ofl_warp_bwd_grad_f32).  flow [Nf,2,H,W], src [Ns,C,H,W] (the field that was gathered), grad_out
+    [N,C,H,W] -> (grad_src [Ns,C,H,W] | None, grad_flow [N,2,H,W] | None); a broadcast source accumulates into its one image."""
+    lib, dev = load_library(), device(flow, src, grad_out)
+    n, c, h, w = grad_out.shape
+    with _on(dev):
+        f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
+        s, sbs = _planes(src.detach(), dev, torch.float32, n, "source")
+        g = grad_out.detach().to(dev, torch.float32).contiguous()
+        ns = 1 if sbs == 0 else n
+        gs = torch.zeros((ns, c, h, w), dtype=torch.float32, device=dev) if want_src else None
+        gf = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev) if want_flow else None
+        _check(lib.ofl_warp_bwd_grad_f32(_ptr(f), fbs, float(flow_sign), _ptr(s), sbs, _ptr(g), float(g_scale), _ptr(gs),
+                                         0 if ns == 1 else c * h * w, _ptr(gf), n, c, h, w, _stream(dev)),
+               "ofl_warp_bwd_grad_f32")
+    return gs, gf
+
+
+def splat_grad(flow, data, out, density, grad_out, *, xs=None, ys=None, flow_sign=1.0, weight_mask=None, occlude=True,
+               grad_density=None, want_data=True, want_xy=True):
+    """Backward of P (ofl_splat_grad_f32).  `data` is the data actually splatted.  -> (grad_data [N,C,H,W] | None,
+    grad_xy [N,2,H,W] | None) with grad_xy = (d/dx, d/dy) of the end points."""
+    lib, dev = load_library(), device(flow, data, xs, grad_out)
+    n, c, h, w = grad_out.shape
+    with _on(dev):
+        f, fbs = (None, 0) if flow is None else _planes(flow.detach(), dev, torch.float32, n, "flow")
+        x, xbs = (None, 0) if xs is None else _planes(xs.detach(), dev, torch.float32, n, "x")
+        y, ybs = (None, 0) if ys is None else _planes(ys.detach(), dev, torch.float32, n, "y")
+        if x is not None and xbs != ybs:
+            x, y = x.expand(n, h, w).contiguous(), y.expand(n, h, w).contiguous()
+            xbs = h * w
+        d, dbs = _planes(data.detach(), dev, torch.float32, n, "data")
+        wm, wmbs = (None, 0) if weight_mask is None else _planes(weight_mask, dev, torch.bool, n, "mask")
+        o = out.detach().to(dev, torch.float32).contiguous()
+        den = density.detach().to(dev, torch.float32).contiguous()
+        g = grad_out.detach().to(dev, torch.float32).contiguous()
+        gden = None if grad_density is None else grad_density.detach().to(dev, torch.float32).contiguous()
+        gd = torch.empty((n, c, h, w), dtype=torch.float32, device=dev) if want_data else None
+        gxy = None
+        occ = 1 if (occlude and f is not None) else 0
+        for c0 in range(0, c, 8):                       # (the kernel keeps 8 channels of a pixel in registers)
+            c1 = min(c0 + 8, c)
+            part = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev) if want_xy else None
+            dd = d[:, c0:c1]
+            if c1 - c0 != c:
+                dd = dd.contiguous()
+            ddbs = 0 if dbs == 0 else dd.stride(0)
+            oo, gg = (o, g) if c1 - c0 == c else (o[:, c0:c1].contiguous(), g[:, c0:c1].contiguous())
+            gdd = None if gd is None else (gd if c1 - c0 == c else torch.empty((n, c1 - c0, h, w), dtype=torch.float32, device=dev))
+            _check(lib.ofl_splat_grad_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(dd), ddbs, _ptr(wm), wmbs,
+                                          occ, _ptr(oo), _ptr(den), _ptr(gg), _ptr(gden if c0 == 0 else None), _ptr(gdd),
+                                          _ptr(part), n, c1 - c0, h, w, _stream(dev)), "ofl_splat_grad_f32")
+            if gd is not None and gdd is not gd:
+                gd[:, c0:c1] = gdd
+            if part is not None:
+                gxy = part if gxy is None else gxy + part
+    return gd, gxy
+
+
+def sample_pts(flow, pts):
+    """track_pts' sampler (ofl_sample_pts_f32): flow [N|1,2,H,W], pts [N|1,M,2] float (y, x) -> pts + sampled flow [N,M,2]."""
+    lib, dev = load_library(), device(flow, pts)
+    n = max(flow.shape[0], pts.shape[0])
+    m = pts.shape[1]
+    h, w = flow.shape[2:]
+    with _on(dev):
+        f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
+        q, qbs = _planes(pts.detach(), dev, torch.float32, n, "points")
+        out = torch.empty((n, m, 2), dtype=torch.float32, device=dev)
+        if m > 0:
+            _check(lib.ofl_sample_pts_f32(_ptr(f), fbs, _ptr(q), qbs, _ptr(out), n, m, h, w, _stream(dev)), "ofl_sample_pts_f32")
+    return out
+
+
+def sample_pts_grad(flow, pts, grad_out, *, want_flow=True, want_pts=True):
+    """Backward of `sample_pts` -> (grad_flow [N,2,H,W] | None, grad_pts [N,M,2] | None)."""
+    lib, dev = load_library(), device(flow, pts, grad_out)
+    n, m = grad_out.shape[:2]
+    h, w = flow.shape[2:]
+    with _on(dev):
+        f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
+        q, qbs = _planes(pts.detach(), dev, torch.float32, n, "points")
+        g = grad_out.detach().to(dev, torch.float32).contiguous()
+        gf = torch.zeros((n, 2, h, w), dtype=torch.float32, device=dev) if want_flow else None
+        gp = torch.empty((n, m, 2), dtype=torch.float32, device=dev) if want_pts else None
+        if m > 0:
+            _check(lib.ofl_sample_pts_grad_f32(_ptr(f), fbs, _ptr(q), qbs, _ptr(g), _ptr(gf), _ptr(gp), n, m, h, w,
+                                               _stream(dev)), "ofl_sample_pts_grad_f32")
+    return gf, gp
+
+
+def flow_extents(vecs, mask, sign: float) -> torch.Tensor:
+    """Flow.get_padding's reduction (ofl_flow_extents_f32) -> fp32 [N,5] on the HIP device: min y, max y, min x, max x of the
+    positions -(sign * thr(v) - grid) under the mask, and whether any pixel was valid."""
+    lib, dev = load_library(), device(vecs, mask)
+    n, _, h, w = vecs.shape
+    with _on(dev):
+        v, vbs = _planes(vecs.detach(), dev, torch.float32, n, "flow")
+        m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+        ws = torch.empty(5 * n, dtype=torch.int32, device=dev)
+        ext = torch.empty((n, 5), dtype=torch.float32, device=dev)
+        _check(lib.ofl_flow_extents_f32(_ptr(v), vbs, _ptr(m), mbs, float(sign), _ptr(ws), _ptr(ext), n, h, w, _stream(dev)),
+               "ofl_flow_extents_f32")
+    return ext

@@ -1662,9 +1662,14 @@ __global__ __launch_bounds__(256) void flow_f16_kernel(const _Float16* __restric
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-inline int check_dims(int32_t n, int32_t c, int32_t h, int32_t w) {
+// `splat`: the forward splat keeps the reference's own limit -- its position index is formed in fp32 (utils.py:1118), exact
+// only below 2^24 pixels.  The backward warp and the flag reductions have no such limit in the reference (grid_sample
+// indexes with integers): frames of 2^24 pixels and more take the generic kernels (64-bit pixel offsets); the staged
+// kernels' 24-bit multiplies stay below it.
+inline int check_dims(int32_t n, int32_t c, int32_t h, int32_t w, bool splat = true) {
     if (n < 1 || c < 1 || h < 1 || w < 1) return OFL_E_SHAPE;
-    if ((int64_t)h * w >= (1ll << 24)) return OFL_E_SHAPE;  // fp32 position index limit, utils.py:1118
+    if (splat && (int64_t)h * w >= (1ll << 24)) return OFL_E_SHAPE;
+    if ((int64_t)h * w >= (1ll << 31)) return OFL_E_SHAPE;
     return OFL_OK;
 }
 
@@ -1780,7 +1785,7 @@ int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 17; }   // 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 18; }   // 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -1796,7 +1801,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     int32_t* flow_flags, int32_t* src_flags, int32_t* dst_flags, int32_t n, int32_t c, int32_t h, int32_t w,
     int32_t round_mode, void* stream) {
     if (!flow || !src || !dst) return OFL_E_NULL;
-    int rc = check_dims(n, c, h, w);
+    int rc = check_dims(n, c, h, w, false);
     if (rc) return rc;
     if (src_flags && (c != 2 || !flow_flags)) return OFL_E_ARG;
     if (dst_flags && (c != 2 || !valid)) return OFL_E_ARG;
@@ -1825,7 +1830,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     }
     // LDS-staged fast path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit box coordinates (any width:
     // 16-byte accesses at 4-byte alignment, mask bytes at any alignment)
-    const bool lds_ok = g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760;
+    const bool lds_ok = g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760 && (int64_t)h * w < (1ll << 24);
     if (src_b) {   // only the staged 2-channel kernel with a valid mask subtracts on the fly: anything else is the caller's job
         if (!(lds_ok && c == 2 && valid && !addend && !dst_flags && !flow_flags)) return OFL_E_UNSUPPORTED;
         p.src_b = src_b; p.src_b_bs = src_b_bs;
@@ -1875,8 +1880,9 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_u8(
     void* dst, int32_t dst_is_u8, uint8_t* valid, int32_t n, int32_t c, int32_t h, int32_t w, int32_t round_mode,
     void* stream) {
     if (!flow || !src || !dst) return OFL_E_NULL;
-    int rc = check_dims(n, c, h, w);
+    int rc = check_dims(n, c, h, w, false);
     if (rc) return rc;
+    if ((int64_t)h * w >= (1ll << 24)) return OFL_E_UNSUPPORTED;          // staged kernel only (24-bit offsets)
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
     if (dst_is_u8 && round_mode != OFL_ROUND_U8) return OFL_E_ARG;       // bytes only hold rounded, clamped values
     if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
@@ -2145,8 +2151,9 @@ __attribute__((visibility("default"))) int ofl_flow_flags_f32(const float* flow,
                                                               int32_t* flags, int32_t n, int32_t h, int32_t w,
                                                               void* stream) {
     if (!flow || !flags) return OFL_E_NULL;
-    int rc = check_dims(n, 2, h, w);
+    int rc = check_dims(n, 2, h, w, false);
     if (rc) return rc;
+    if (n > 65535) return OFL_E_SHAPE;                       // (the batch index rides in blockIdx.y)
     if (thr != kZeroThr) return OFL_E_ARG;  // the reference's DEFAULT_THRESHOLD is the only value on the path
     launch_flow_flags(flow, flow_bs, mask, mask_bs, flags, n, (int64_t)h * w, (hipStream_t)stream);
     return (int)hipGetLastError();
@@ -2157,8 +2164,9 @@ __attribute__((visibility("default"))) int ofl_flow_from_f16(const void* src_f16
                                                              int32_t* flags, int32_t n, int32_t h, int32_t w,
                                                              void* stream) {
     if (!src_f16 || !dst || !flags) return OFL_E_NULL;
-    int rc = check_dims(n, 2, h, w);
+    int rc = check_dims(n, 2, h, w, false);
     if (rc) return rc;
+    if (n > 65535) return OFL_E_SHAPE;
     const int64_t hw = (int64_t)h * w;
     if ((hw % 4) != 0 || !aligned_to(src_f16, 8) || (src_bs % 4) != 0 || !aligned_to(dst, 16) ||
         (mask && (!aligned_to(mask, 4) || (mask_bs % 4) != 0)))

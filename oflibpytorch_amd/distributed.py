@@ -34,12 +34,23 @@ def is_enabled() -> bool:
 
 
 def reduce_flags(local_or: int, device) -> int:
-    """OR of a 5-bit flag word over all ranks (identity when sharding is off)."""
+    """OR of a 5-bit flag word over all ranks (identity when sharding is off).  Host word in, host word out: one
+    collective and one sync; the kernels' device-side words go through `with_global_or` instead."""
     if not is_enabled():
         return local_or
-    bits = torch.tensor([(local_or >> b) & 1 for b in range(5)], dtype=torch.int32, device=device)
-    dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=_group)
-    return sum(int(v) << b for b, v in enumerate(bits.cpu().tolist()))
+    return int(with_global_or(torch.tensor([local_or], dtype=torch.int32, device=device))[-1].item())
+
+
+def with_global_or(words: torch.Tensor) -> torch.Tensor:
+    """int32[N] per-element flag words ON THE DEVICE (a kernel's by-product) -> int32[N + 1]: the same words followed by
+    their OR over the whole batch and over every rank.  Device ops and one tiny all-reduce only -- no host round trip
+    here; the caller reads the N + 1 words with a single sync."""
+    w = words.to(torch.int32)
+    shifts = torch.arange(5, dtype=torch.int32, device=w.device)
+    bits = ((w.reshape(-1, 1) >> shifts) & 1).amax(0) if w.numel() else torch.zeros(5, dtype=torch.int32, device=w.device)
+    if is_enabled():
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=_group)
+    return torch.cat([w.reshape(-1), (bits << shifts).sum().to(torch.int32).reshape(1)])
 
 
 def shard_bounds(n: int, rank: int = None, world: int = None) -> tuple:
@@ -59,9 +70,23 @@ def broadcast_operand(t: torch.Tensor, src: int = 0) -> torch.Tensor:
 
 
 def all_gather_batch(t: torch.Tensor) -> torch.Tensor:
-    """Concatenate equally-sized shards along the batch axis on every rank (not part of the compute metric)."""
+    """Concatenate the ranks' shards along the batch axis on every rank (not part of the compute metric).  Shards may
+    be ragged (`shard_bounds` hands out a shorter, possibly empty, tail): the batch sizes are exchanged first and every
+    shard travels padded to the longest."""
     if not (dist.is_initialized() and dist.get_world_size(_group) > 1):
         return t
-    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(_group))]
-    dist.all_gather(parts, t.contiguous(), group=_group)
-    return torch.cat(parts, dim=0)
+    world = dist.get_world_size(_group)
+    sizes = torch.zeros(world, dtype=torch.int64, device=t.device)
+    sizes[dist.get_rank(_group)] = t.shape[0]
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=_group)
+    sizes = [int(v) for v in sizes.cpu().tolist()]
+    longest = max(sizes)
+    if longest == 0:
+        return t
+    padded = t.contiguous()
+    if t.shape[0] != longest:
+        padded = torch.zeros((longest,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        padded[:t.shape[0]] = t
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=_group)
+    return torch.cat([p[:k] for p, k in zip(parts, sizes)], dim=0)

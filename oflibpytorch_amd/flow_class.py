@@ -21,10 +21,15 @@ import torch.nn.functional as F
 from . import _native, distributed
 from .utils import (get_valid_vecs, get_valid_ref, get_valid_mask, get_valid_device, get_valid_padding,
                     get_valid_shape, get_pure_pytorch, move_axis, from_matrix, from_transforms, resize_flow,
-                    apply_flow, _flags_to_host, _griddata_unavailable)
+                    apply_flow, _flags_to_host, _griddata_unavailable, track_pts)
 
 FlowAlias = 'Flow'
 _VALID_THR = 0.99999   # flow_class.py:922
+
+
+def _ver(t: torch.Tensor) -> int:
+    """Version counter of a tensor, -1 for inference tensors (which have none and raise on `_version`)."""
+    return -1 if t.is_inference() else t._version
 
 
 class Flow(object):
@@ -82,7 +87,7 @@ class Flow(object):
         """`self` holds the vectors of `src` or their exact negation, under the same mask: every flag (finiteness, the
         symmetric zero / threshold tests) carries over, no reduction needed."""
         if src._flags_known() and (self._mask is src._mask):
-            key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+            key = self._key()
             self._flag_cache = (key, src._flag_cache[1])
 
     def _negated(self, ref: str) -> FlowAlias:
@@ -104,25 +109,37 @@ class Flow(object):
         obj.device = device
         return obj
 
+    def _key(self) -> tuple:
+        """Cache key of the flag word: tensor versions (in-place edits invalidate it).  Tensors created under
+        torch.inference_mode() carry no version counter (reading `_version` raises); they cannot be modified in place
+        outside inference mode, so their identity stands in."""
+        return (_ver(self._vecs), None if self._mask is None else (id(self._mask), _ver(self._mask)))
+
     def _flags_known(self) -> bool:
-        key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+        key = self._key()
         return self._flag_cache is not None and self._flag_cache[0] == key
 
     # -- flags: finiteness + zero tests, one fused reduction per tensor version ------------------
     def _flags(self) -> list:
-        key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+        key = self._key()
         if self._flag_cache is None or self._flag_cache[0] != key:
             if self._pending_flags is not None and self._pending_flags[0] == key:
                 dev_flags = self._pending_flags[1]
             else:
                 dev_flags = _native.flow_flags(self._vecs, self._mask)
             self._pending_flags = None
-            self._flag_cache = (key, _flags_to_host(dev_flags))
+            if distributed.is_enabled():
+                # batch sharding: the OR over every rank's shard is formed on the device (one small all-reduce) and read
+                # together with the local words -- one host sync per tensor version, as without sharding
+                host = _flags_to_host(distributed.with_global_or(dev_flags))
+                self._flag_cache = (key, host[:-1], (True, host[-1]))
+            else:
+                self._flag_cache = (key, _flags_to_host(dev_flags))
         return self._flag_cache[1]
 
     def _set_pending_flags(self, dev_flags):
         if dev_flags is not None:
-            key = (self._vecs._version, None if self._mask is None else (id(self._mask), self._mask._version))
+            key = self._key()
             self._pending_flags = (key, dev_flags)
 
     def _batch_flags(self) -> int:
@@ -179,8 +196,7 @@ class Flow(object):
         """Validity mask N-H-W bool (flow_class.py:159-172).  An all-True default is materialised on first use."""
         if self._mask is None:
             self._mask = torch.ones(self.shape, dtype=torch.bool, device=self._vecs.device)
-            self._flag_cache = None if self._flag_cache is None else \
-                ((self._vecs._version, (id(self._mask), self._mask._version)), self._flag_cache[1])
+            self._flag_cache = None if self._flag_cache is None else (self._key(), self._flag_cache[1])
         return self._mask
 
     @mask.setter
@@ -209,12 +225,12 @@ class Flow(object):
         if self._vecs.device != device:
             self._vecs = self._vecs.to(device)
             self._flag_cache = None if self._flag_cache is None else \
-                ((self._vecs._version, self._flag_cache[0][1]), self._flag_cache[1])
+                ((_ver(self._vecs), self._flag_cache[0][1]), self._flag_cache[1])
         if self._mask is not None and self._mask.device != device:
             flags = None if self._flag_cache is None else self._flag_cache[1]
             self._mask = self._mask.to(device)
             if flags is not None:
-                self._flag_cache = ((self._vecs._version, (id(self._mask), self._mask._version)), flags)
+                self._flag_cache = (self._key(), flags)
 
     @property
     def shape(self) -> tuple:
@@ -244,7 +260,9 @@ class Flow(object):
     # copies, indexing (flow_class.py:376-448)
     # ------------------------------------------------------------------------------------------
     def copy(self) -> FlowAlias:
-        return Flow(self._vecs, self._ref, self._mask, self._device)
+        """flow_class.py:376-383.  The copy aliases the same (already validated) tensors: its flag word is inherited
+        instead of recomputed (no launch, no host sync)."""
+        return Flow._wrap(self._vecs, self._ref, self._mask, self._device, like=self)
 
     def to_device(self, device) -> FlowAlias:
         device = get_valid_device(device)
@@ -544,6 +562,33 @@ class Flow(object):
         return warped.to(self._device), (None if valid is None else valid.to(self._device)), dflags
 
     # ------------------------------------------------------------------------------------------
+    # track (flow_class.py:961-1020)
+    # ------------------------------------------------------------------------------------------
+    def track(self, pts: torch.Tensor, int_out: bool = None, get_valid_status: bool = None):
+        """Warp points (y, x) of shape M-2 or N-M-2; optionally the status of each point = `valid_source()` at its
+        (rounded) position.  Differentiable wrt the flow vectors and the points."""
+        input_2d = pts.dim() == 2
+        get_valid_status = False if get_valid_status is None else get_valid_status
+        if not isinstance(get_valid_status, bool):
+            raise TypeError("Error tracking points: Get_tracked needs to be a boolean")
+        warped_pts = track_pts(flow=self._vecs, ref=self._ref, pts=pts, int_out=int_out)
+        if input_2d and self.shape[0] == 1:
+            warped_pts = warped_pts.squeeze(0)
+        if not get_valid_status:
+            return warped_pts
+        if pts.dtype.is_floating_point:
+            pts = torch.round(pts)
+        pts2 = pts.unsqueeze(0) if input_2d else pts
+        if pts2.shape[0] != self.shape[0]:
+            pts2 = pts2.expand(self.shape[0], -1, -1)
+        valid_source = self.valid_source().view(self.shape[0], -1)
+        pts2 = (pts2[..., 0] * self.shape[-1] + pts2[..., 1]).to(valid_source.device)
+        status_array = torch.gather(valid_source, 1, pts2.long())
+        if warped_pts.dim() == 2:
+            status_array = status_array.squeeze(0)
+        return warped_pts, status_array
+
+    # ------------------------------------------------------------------------------------------
     # switch_ref / invert (flow_class.py:1022-1086)
     # ------------------------------------------------------------------------------------------
     def switch_ref(self, mode: str = None) -> FlowAlias:
@@ -616,6 +661,25 @@ class Flow(object):
                                          weight_mask=self._mask if consider_mask else None, occlude=True,
                                          want_mask_chan=True)
         return (mch == 1).to(self._device)
+
+    # ------------------------------------------------------------------------------------------
+    # padding needed (flow_class.py:1174-1224)
+    # ------------------------------------------------------------------------------------------
+    def get_padding(self, item: int = None) -> list:
+        """[top, bottom, left, right] (per batch element, or of element `item`) by which a source image ('t') or the
+        flow itself ('s') must be padded so that no valid vector reaches outside.  One masked min / max reduction
+        kernel (`ofl_flow_extents_f32`) over the thresholded positions instead of clone + 4 elementwise passes + 4
+        boolean-indexed reductions per batch element."""
+        flow = self.select(item=item)
+        ext = _native.flow_extents(flow._vecs, flow._mask, 1.0 if flow._ref == 't' else -1.0).cpu().tolist()
+        h, w = flow.shape[1:]
+        padding = []
+        for lo_y, hi_y, lo_x, hi_x, any_valid in ext:
+            if not any_valid:        # torch.min of an empty selection raises in the reference as well
+                raise RuntimeError("Error getting padding: the flow mask is False everywhere")
+            pad = [max(-lo_y, 0), max(hi_y - (h - 1), 0), max(-lo_x, 0), max(hi_x - (w - 1), 0)]
+            padding.append([int(np.ceil(p)) for p in pad])
+        return padding[0] if item is not None else padding
 
     # ------------------------------------------------------------------------------------------
     # zero test (flow_class.py:1226-1244)
@@ -736,3 +800,58 @@ class Flow(object):
             if not src._flags_known():
                 src._set_pending_flags(sf)
         return Flow._wrap(vecs, self._ref, valid, self._device, flags=res[4] if result_is_warper else None)
+
+    # ------------------------------------------------------------------------------------------
+    # general composition (flow_class.py:1812-1939)
+    # ------------------------------------------------------------------------------------------
+    def combine(self, other: FlowAlias, mode: int, ref: str = None) -> FlowAlias:
+        """flow_1 (+) flow_2 = flow_3 for two flows of equal shape and ANY references, result in reference `ref`
+        (default: that of self); `mode` names the unknown.  Table-driven over apply / invert / switch_ref exactly as
+        the reference: every step below is a fused kernel launch of this package."""
+        if not isinstance(other, Flow):
+            raise TypeError("Error combining flows: Flow need to be of type 'Flow'")
+        if self.shape != other.shape:
+            raise ValueError("Error combining flows: Flow fields need to have the same shape, including batch size")
+        if self._device != other._device:
+            other = other.to_device(self._device)
+        if mode not in [1, 2, 3]:
+            raise ValueError("Error combining flows: Mode needs to be 1, 2 or 3")
+        ref = self._ref if ref is None else get_valid_ref(ref)
+
+        # time points 0, 1, 2: flow_1 goes 0 -> 1, flow_2 1 -> 2, flow_3 0 -> 2
+        direction = [[0, +1, +1], [-1, 0, +1], [-1, -1, 0]]
+        indices = [[1, 2], [0, 2], [0, 1]]
+        timetable = [[0, 1], [1, 2], [0, 2]]            # (source time, target time) of flow_1, flow_2, flow_3
+        r_time_list = [2, 0, 1]
+        mode -= 1
+        s_time, t_time = timetable[mode]                 # source / target time of the result
+        g_time = timetable[mode][0 if ref == 's' else 1]  # time the result is referenced in
+        r_time = r_time_list[mode]                       # the remaining time point
+        flow_ind = indices[mode]                         # which of flow_1..3 self and other are
+
+        if (mode == 0 and g_time == s_time) or (mode in [1, 2] and g_time == t_time):
+            close_input, far_input = other, self
+            flow_ind = [flow_ind[1], flow_ind[0]]
+        else:
+            close_input, far_input = self, other
+        close_time = timetable[flow_ind[0]][0 if close_input.ref == 's' else 1]
+        far_time = timetable[flow_ind[1]][0 if far_input.ref == 's' else 1]
+
+        if far_time in timetable[mode]:                  # far_input is referenced "around the corner"
+            far_input = far_input.switch_ref()
+        if close_time == g_time:                         # move far_input to g_time
+            if direction[r_time][g_time] == 1:
+                far_input = close_input.apply(far_input)
+            else:
+                far_input = close_input.invert(ref='t').apply(far_input)
+        if g_time == t_time:                             # linear combination at a common time
+            result = far_input * direction[s_time][r_time] + close_input * direction[r_time][t_time]
+        else:
+            result = close_input * direction[s_time][r_time] + far_input * direction[r_time][t_time]
+        if close_time != g_time:                         # the result sits at r_time: move it to g_time
+            if direction[r_time][g_time] == 1:
+                result = close_input.apply(result)
+            else:
+                result = close_input.invert(ref='s').apply(result)
+        result._ref = ref
+        return result

@@ -422,6 +422,65 @@ def is_zero_flow(flow, thresholded: bool = None) -> torch.Tensor:
     return torch.tensor([(f & bit) == 0 for f in host], dtype=torch.bool, device=flow.device)
 
 
+def track_pts(flow, ref: str, pts: torch.Tensor, int_out: bool = None) -> torch.Tensor:
+    """Warp points (y, x) of shape M-2 or N-M-2 with a flow field (utils.py:941-1042).  Differentiable wrt flow and
+    pts.  's': the flow is sampled bilinearly at the points (sparse sampler kernel `ofl_sample_pts_f32`: flip ->
+    normalise_coords -> grid_sample -> flip in the reference, :1004-1014; integer points read their pixel, :998-1003);
+    't' (PURE_PYTORCH): the flow is first splatted to its own start points -- `grid_from_unstructured_data` at
+    `get_flow_endpoints(-flow, 's')`, :993-996 -- one forward-splat launch with the end points formed in-kernel."""
+    flow = get_valid_vecs(flow, error_string="Error tracking points: ", _check_finite=False)
+    flags = _flags_to_host(_native.flow_flags(flow))
+    if any(f & _native.FLAG_NONFINITE for f in flags):                          # utils.py:98
+        raise ValueError("Error tracking points: Input contains NaN, Inf or -Inf values")
+    ref = get_valid_ref(ref)
+    if not isinstance(pts, torch.Tensor):
+        raise TypeError("Error tracking points: Pts needs to be a numpy array or a torch tensor")
+    return_2d = False
+    if pts.dim() == 2:
+        return_2d = True
+        pts = pts.unsqueeze(0).expand(flow.shape[0], -1, -1)
+    elif pts.dim() == 3:
+        if pts.shape[0] != flow.shape[0]:
+            if pts.shape[0] == 1:
+                pts = pts.expand(flow.shape[0], -1, -1)
+            else:
+                raise ValueError("Error tracking points: "
+                                 "If used, pts batch size needs to be equal to the flow batch size")
+    else:
+        raise ValueError("Error tracking points: Pts needs to have shape M-2 or N-M-2")
+    if pts.shape[-1] != 2:
+        raise ValueError("Error tracking points: Pts needs to have shape M-2 or N-M-2")
+    int_out = False if int_out is None else int_out
+    if not isinstance(int_out, bool):
+        raise TypeError("Error tracking points: Int_out needs to be a boolean")
+    pts = pts.to(flow.device)
+
+    if not any(f & _native.FLAG_NZ_THR for f in flags):                         # :988-989
+        warped_pts = pts
+    else:
+        if ref == 't':
+            if not get_pure_pytorch():
+                _griddata_unavailable("track_pts(ref='t')")
+            # x, y = get_flow_endpoints(-flow, 's'); flow, _ = grid_from_unstructured_data(x, y, flow)   (:993-995)
+            flow = _native.splat_fwd(flow, flow, flow_sign=-1.0, occlude=False)[0].to(flow.device)
+        if not pts.dtype.is_floating_point:                                     # :998-1003
+            flow_vecs = flow.permute(0, 2, 3, 1)
+            pts2 = pts[..., 0] * flow.shape[-1] + pts[..., 1]
+            pts2 = pts2.unsqueeze(-1).expand(-1, -1, 2)
+            flow_vecs = torch.gather(flow_vecs.reshape(flow_vecs.shape[0], -1, 2), 1, pts2.long()).flip(-1)
+            warped_pts = pts.float() + flow_vecs
+            nan_vals = torch.isnan(warped_pts)
+            warped_pts[nan_vals[:, :, 0] | nan_vals[:, :, 1]] = 0               # :1033-1035
+        else:
+            from . import _autograd
+            warped_pts = _autograd.sample_pts(flow, pts.float()).to(flow.device)   # (NaN rows are zeroed in the kernel)
+    if int_out:
+        warped_pts = torch.round(warped_pts).long()
+    if return_2d:
+        warped_pts = warped_pts.squeeze(0)
+    return warped_pts
+
+
 def get_flow_endpoints(flow: torch.Tensor, ref: str) -> tuple:
     """End ('s') / start ('t') point grids x, y of shape N-H-W (utils.py:1045-1058).  API helper; the splat kernel
     computes the same `s * flow + arange` in-register."""

@@ -56,6 +56,8 @@ def lib():
         L.orc_grid_from_unstructured_f32.argtypes = [fp, fp, fp, u8, fp, fp, i32, i32, i32, i32]
         L.orc_apply_s_flow_f32.argtypes = [fp, fp, u8, i32, fp, u8, fp, i32, i32, i32, i32]
         L.orc_flow_flags_f32.argtypes = [fp, u8, ctypes.c_float, ctypes.POINTER(i32), i32, i32, i32]
+        L.orc_sample_pts_f32.argtypes = [fp, i64, fp, i64, fp, i32, i32, i32, i32]
+        L.orc_sample_pts_f32.restype = None
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
         for name in ("orc_warp_bwd_f32", "orc_normalise_coords_f32", "orc_flow_endpoints_f32",
@@ -162,6 +164,62 @@ def P(flow, src, mask=None):
     if src.shape[0] != n:
         src = np.broadcast_to(src, (n,) + src.shape[1:])
     return apply_s_flow(flow, src, mask, True)[0]
+
+
+def sample_pts(flow, pts):
+    """track_pts' sampler for floating-point points (utils.py:1004-1015, 1033-1035): flow [N|1,2,H,W], pts [N|1,M,2]
+    as (y, x) -> pts + bilinearly sampled flow, NaN rows zeroed."""
+    flow, pts = _f32(flow), _f32(pts)
+    n = max(flow.shape[0], pts.shape[0])
+    m = pts.shape[1]
+    h, w = flow.shape[2:]
+    out = np.empty((n, m, 2), np.float32)
+    if m:
+        lib().orc_sample_pts_f32(_fp(flow), 0 if (flow.shape[0] == 1 and n > 1) else 2 * h * w, _fp(pts),
+                                 0 if (pts.shape[0] == 1 and n > 1) else 2 * m, _fp(out), n, m, h, w)
+    return out
+
+
+def track_pts(flow, ref, pts, int_out=False):
+    """utils.py:941-1042 (PURE_PYTORCH), floating-point or integer points [N|1,M,2] -> [N,M,2]."""
+    flow = _f32(flow)
+    pts = np.asarray(pts)
+    n = flow.shape[0]
+    if pts.shape[0] != n:
+        pts = np.broadcast_to(pts, (n,) + pts.shape[1:])
+    if bool(np.all(is_zero_flow(flow, True))):                    # :988-989
+        out = pts
+    else:
+        if ref == 't':                                            # :993-996
+            x, y = flow_endpoints(neg(flow), 's')
+            flow, _ = grid_from_unstructured_data(x, y, flow)
+        if pts.dtype.kind in 'iu':                                # :998-1003
+            h, w = flow.shape[2:]
+            lin = (pts[..., 0] * w + pts[..., 1]).astype(np.int64)
+            fv = np.take_along_axis(np.moveaxis(flow, 1, -1).reshape(n, h * w, 2), lin[..., None].repeat(2, -1), axis=1)
+            out = pts.astype(np.float32) + fv[..., ::-1]
+        else:
+            out = sample_pts(flow, pts.astype(np.float32))
+    if int_out:
+        out = np.rint(out).astype(np.int64)
+    return out
+
+
+def flow_extents(flow, mask, sign):
+    """The reduction of Flow.get_padding (flow_class.py:1196-1219): per batch element min y, max y, min x, max x of the
+    positions -(sign * thr(v) - grid) under the mask, and whether any pixel is valid."""
+    flow = _f32(flow).copy()
+    n, _, h, w = flow.shape
+    flow[(flow < THRESHOLD) & (flow > -THRESHOLD)] = 0            # threshold_vectors utils.py:642
+    v = flow * np.float32(sign)
+    gy, gx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing='ij')
+    px, py = -(v[:, 0] - gx), -(v[:, 1] - gy)
+    out = np.zeros((n, 5), np.float32)
+    for b in range(n):
+        mk = np.ones((h, w), bool) if mask is None else np.asarray(mask[b], bool)
+        if mk.any():
+            out[b] = [py[b][mk].min(), py[b][mk].max(), px[b][mk].min(), px[b][mk].max(), 1.0]
+    return out
 
 
 def flow_flags(flow, mask=None, thr=THRESHOLD):

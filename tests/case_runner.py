@@ -96,6 +96,23 @@ def run_case(case, golden, device):
             other = T(i["f2"], d) if a.get("tensor") else _flow(i, "f2", "m2", a["ref"], d)
             out = f1 + other if op == 'Flow.add' else f1 - other
         return {"vecs": out.vecs, "mask": out.mask}
+    if op == 'Flow.combine':
+        out = _flow(i, "f1", "m1", a["self_ref"], d).combine(_flow(i, "f2", "m2", a["other_ref"], d), a["mode"], a["ref"])
+        return {"vecs": out.vecs, "mask": out.mask, "_ref": out.ref}
+    if op in ('track_pts', 'Flow.track'):
+        fv = T(i["flow_raw"], d) if "flow_raw" in i else \
+            T(codec.decode_affine(i["flow__params"], i["flow__delta"], i["flow__esc"])[None], d)
+        if op == 'track_pts':
+            return {"out": ofl.track_pts(fv, a["ref"], T(i["pts"], d), a["int_out"])}
+        fl = Flow(fv, a["ref"], T(i["m"], d))
+        if a.get("batch"):
+            fl = ofl.batch_flows([fl] * a["batch"])
+        o, st = fl.track(T(i["pts"], d), get_valid_status=True)
+        return {"out": o, "status": st}
+    if op == 'Flow.get_padding':
+        return {"_padding": _flow(i, "f", "m", a["ref"], d).get_padding(a["item"])}
+    if op.startswith('grad_'):
+        return run_grad_case(case, golden, device)
     if op == 'kat_gfud':
         v = codec.decode_affine(i["flow__params"], i["flow__delta"], i["flow__esc"])
         vecs = T(np.stack([v, v]), d)                      # the reference test batches two copies
@@ -115,8 +132,56 @@ def run_case(case, golden, device):
     raise KeyError(op)
 
 
+def run_grad_case(case, golden, device):
+    """Gradient cases (group 'grads'): the same call with requires_grad inputs, loss = sum(out * w_out), backward."""
+    i, _ = golden.arrays(case)
+    a, op = case["args"], case["op"]
+    d = device
+    leaf = lambda k: T(i[k], d).clone().requires_grad_()
+    if op == 'grad_apply_flow':
+        fv, tv = leaf("flow"), leaf("target")
+        out = ofl.apply_flow(fv, tv, a["ref"], T(i.get("mask"), d))
+        assert out.grad_fn is not None                       # test_utils.py:500
+        (out * T(i["w_out"], d)).sum().backward()
+        return {"g_flow": fv.grad, "g_target": tv.grad}
+    if op == 'grad_gfud':
+        xv, yv, dv = leaf("x"), leaf("y"), leaf("data")
+        od, oden = ofl.grid_from_unstructured_data(xv, yv, dv, T(i.get("mask"), d))
+        assert od.grad_fn is not None and oden.grad_fn is not None   # test_utils.py:1113-1114
+        ((od * T(i["w_data"], d)).sum() + (oden * T(i["w_density"], d)).sum()).backward()
+        return {"g_x": xv.grad, "g_y": yv.grad, "g_data": dv.grad}
+    if op == 'grad_track_pts':
+        fv, pv = leaf("flow"), leaf("pts")
+        out = ofl.track_pts(fv, a["ref"], pv)
+        assert out.grad_fn is not None
+        (out * T(i["w_out"], d)).sum().backward()
+        return {"g_flow": fv.grad, "g_pts": pv.grad, "out": out.detach()}
+    fa, fb = leaf("f1"), leaf("f2")
+    m1, m2 = T(i["m1"], d), T(i["m2"], d)
+    if op == 'grad_Flow.apply':
+        out = Flow(fa, a["ref"], m1).apply(Flow(fb, a["target_ref"], m2))
+    elif op == 'grad_Flow.switch_ref':
+        out = Flow(fa, a["ref"], m1).switch_ref()
+    elif op == 'grad_Flow.invert':
+        out = Flow(fa, a["ref"], m1).invert()
+    elif op == 'grad_Flow.combine_with':
+        out = Flow(fa, a["ref"], m1).combine_with(Flow(fb, a["ref"], m2), a["mode"])
+    elif op == 'grad_Flow.combine':
+        out = Flow(fa, a["self_ref"], m1).combine(Flow(fb, a["other_ref"], m2), a["mode"], a["ref"])
+    else:
+        raise KeyError(op)
+    assert out.vecs.grad_fn is not None
+    (out.vecs * T(i["w_out"], d)).sum().backward()
+    z = lambda t, like: torch.zeros_like(like) if t.grad is None else t.grad
+    return {"g_f1": z(fa, fa), "g_f2": z(fb, fb), "vecs": out.vecs.detach(), "mask": out.mask}
+
+
 def _np(v):
     return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+GRAD_RTOL = 2e-4     # gradients: fp32 sums in a different order than ATen's CPU loops (and atomics on the device);
+                     # bar: |got - expected| <= GRAD_RTOL * max|expected| per tensor (stated in DESIGN.md)
 
 
 def check_case(case, golden, got, exact_values=True, rtol=0.0, atol=0.0, max_mask_flips=0):
@@ -145,9 +210,18 @@ def check_case(case, golden, got, exact_values=True, rtol=0.0, atol=0.0, max_mas
         s = float(vec.astype(np.float64).sum())
         assert abs(s - a["sum"]) <= 1e-6 * max(a["abs_sum"], 1.0), (s, a["sum"])
         return report
+    if op == 'Flow.get_padding':
+        assert got["_padding"] == a["padding"], (got["_padding"], a["padding"])
+        return report
     for k, e in exp.items():
         g = _np(got[k])
         assert g.shape == e.shape, "%s: shape %s != %s" % (k, g.shape, e.shape)
+        if k.startswith("g_"):                               # a gradient
+            assert g.dtype == e.dtype
+            scale = float(np.max(np.abs(e))) if e.size else 0.0
+            err = float(np.max(np.abs(g.astype(np.float64) - e.astype(np.float64)))) if e.size else 0.0
+            assert err <= GRAD_RTOL * max(scale, 1e-6), "%s: max |diff| %.3g vs gradient scale %.3g" % (k, err, scale)
+            continue
         assert g.dtype == e.dtype, "%s: dtype %s != %s" % (k, g.dtype, e.dtype)
         if e.dtype == np.bool_:
             flips = int(np.count_nonzero(g != e))
@@ -158,7 +232,7 @@ def check_case(case, golden, got, exact_values=True, rtol=0.0, atol=0.0, max_mas
         assert got["_ref"] == a["out_ref"]
     if "returns" in a and "_returns" in got:
         assert got["_returns"] == a["returns"], (got["_returns"], a["returns"])
-    if "same_object" in a:
+    if "same_object" in a and "_same" in got:
         assert got["_same"] == a["same_object"]
     return report
 

@@ -54,6 +54,6 @@ def oracle_native(monkeypatch):
     """Route the package's three native primitives to the CPU oracle (host-logic tests only)."""
     import oracle_backend
     from oflibpytorch_amd import _native
-    for name in ("flow_flags", "warp_bwd", "splat_fwd", "device"):
+    for name in ("flow_flags", "warp_bwd", "splat_fwd", "device", "sample_pts", "flow_extents"):
         monkeypatch.setattr(_native, name, getattr(oracle_backend, name))
     return oracle_backend

@@ -530,12 +530,194 @@ def gen_kats():
         {"self": "rot_t", "flow": "tr_t", "mode": 3, "mean_mag": mag})
 
 
+# ------------------------------------------------------------------------------------------------
+# group: next  (general Flow.combine, track_pts / Flow.track, get_padding)
+# ------------------------------------------------------------------------------------------------
+def gen_next():
+    g = 'next'
+    h, w = H, W
+    fa, fb = smooth_flow(2, h, w, 3.0, 301), smooth_flow(2, h, w, 2.5, 302)
+    ma, mb = hole_mask(2, h, w, 31), hole_mask(2, h, w, 33)
+    # Flow.combine: 3 modes x (self ref, other ref, result ref)   (flow_class.py:1812-1939; test_flow_class.py:2142-2231)
+    for mode in (1, 2, 3):
+        for sr in 'st':
+            for orf in 'st':
+                for rr in 'st':
+                    out = Flow(fa, sr, ma).combine(Flow(fb, orf, mb), mode, rr)
+                    rec(g, 'combine_m%d_%s%s%s' % (mode, sr, orf, rr), 'Flow.combine',
+                        {"mode": mode, "self_ref": sr, "other_ref": orf, "ref": rr, "out_ref": out.ref},
+                        {"f1": fa, "m1": ma, "f2": fb, "m2": mb}, {"vecs": out.vecs, "mask": out.mask})
+    out = Flow(fa, 's', ma).combine(Flow(fb, 't', mb), 3)        # ref defaults to self.ref
+    rec(g, 'combine_m3_st_default', 'Flow.combine', {"mode": 3, "self_ref": 's', "other_ref": 't', "ref": None,
+                                                     "out_ref": out.ref},
+        {"f1": fa, "m1": ma, "f2": fb, "m2": mb}, {"vecs": out.vecs, "mask": out.mask})
+
+    # track_pts (utils.py:941-1042; KAT inputs of test_utils.py:944-1040)
+    f_s = Flow.from_transforms([['rotation', 0, 0, 30]], (200, 210), 's').vecs
+    f_t = Flow.from_transforms([['rotation', 0, 0, 30]], (200, 210), 't').vecs
+    pts = torch.tensor([[20.5, 10.5], [8.3, 7.2], [120.4, 160.2]])
+    desired = np.array([[12.5035207776, 19.343266740], [3.58801085141, 10.385382907], [24.1694586156, 198.93726969]])
+    for ref, fl, rtol in (('s', f_s, 1e-6), ('t', f_t, 5e-3)):
+        out = ofu.track_pts(fl, ref, pts)
+        np.testing.assert_allclose(out.numpy(), desired, rtol=rtol)          # the reference's own assertion
+        rec(g, 'track_pts_%s_kat' % ref, 'track_pts', {"ref": ref, "int_out": None},
+            {**_affine_inputs("flow", fl), "pts": pts}, {"out": out})
+        out = ofu.track_pts(fl, ref, pts.unsqueeze(0))
+        rec(g, 'track_pts_%s_kat_3d' % ref, 'track_pts', {"ref": ref, "int_out": None},
+            {**_affine_inputs("flow", fl), "pts": pts.unsqueeze(0)}, {"out": out})
+        out = ofu.track_pts(fl, ref, pts, int_out=True)
+        rec(g, 'track_pts_%s_kat_int_out' % ref, 'track_pts', {"ref": ref, "int_out": True},
+            {**_affine_inputs("flow", fl), "pts": pts}, {"out": out})
+    out = ofu.track_pts(torch.zeros_like(f_s), 's', pts)
+    rec(g, 'track_pts_zero', 'track_pts', {"ref": 's', "int_out": None, "same_object": False},
+        {"flow_raw": torch.zeros(1, 2, 20, 21), "pts": pts[:, :] * 0.1}, {"out": ofu.track_pts(torch.zeros(1, 2, 20, 21), 's', pts * 0.1)})
+    # batched smooth flows, float and integer points, points out of range
+    fsm = smooth_flow(3, h, w, 4.0, 311)
+    gen = torch.Generator().manual_seed(312)
+    p3 = torch.rand(3, 9, 2, generator=gen) * torch.tensor([h + 4.0, w + 4.0]) - 2.0
+    pi = torch.stack([torch.randint(0, h, (3, 7), generator=gen), torch.randint(0, w, (3, 7), generator=gen)], dim=-1)
+    for ref in 'st':
+        rec(g, 'track_pts_%s_batched' % ref, 'track_pts', {"ref": ref, "int_out": None}, {"flow_raw": fsm, "pts": p3},
+            {"out": ofu.track_pts(fsm, ref, p3)})
+        rec(g, 'track_pts_%s_bcast_pts' % ref, 'track_pts', {"ref": ref, "int_out": None}, {"flow_raw": fsm, "pts": p3[0]},
+            {"out": ofu.track_pts(fsm, ref, p3[0])})
+        rec(g, 'track_pts_%s_intpts' % ref, 'track_pts', {"ref": ref, "int_out": None}, {"flow_raw": fsm, "pts": pi},
+            {"out": ofu.track_pts(fsm, ref, pi)})
+        rec(g, 'track_pts_%s_intpts_int_out' % ref, 'track_pts', {"ref": ref, "int_out": True}, {"flow_raw": fsm, "pts": pi},
+            {"out": ofu.track_pts(fsm, ref, pi, int_out=True)})
+    # Flow.track with the status of each point (flow_class.py:961-1020; test_flow_class.py:1315-1385 at 128 x 128)
+    for ref in 'st':
+        fl = Flow.from_transforms([['rotation', 0, 0, 30]], (128, 128), ref)
+        mk = torch.ones(1, 128, 128, dtype=torch.bool)
+        mk[:, :, 50:] = False
+        fl = Flow(fl.vecs, ref, mk)
+        tp = torch.tensor([[0, 12.0], [0, 125.0], [8.3, 7.2], [30.4, 40.2], [75.0, 50.0]])
+        o, st = fl.track(tp, get_valid_status=True)
+        rec(g, 'flow_track_%s_status' % ref, 'Flow.track', {"ref": ref, "int_out": None},
+            {**_affine_inputs("flow", fl.vecs), "m": mk, "pts": tp}, {"out": o, "status": st})
+        f3 = of.batch_flows([fl, fl, fl])
+        o, st = f3.track(tp.unsqueeze(0), get_valid_status=True)
+        rec(g, 'flow_track_%s_status_batched' % ref, 'Flow.track', {"ref": ref, "int_out": None, "batch": 3},
+            {**_affine_inputs("flow", fl.vecs), "m": mk, "pts": tp.unsqueeze(0)}, {"out": o, "status": st})
+
+    # get_padding (flow_class.py:1174-1224): the 7 x 7 KATs of test_flow_class.py:1619-1645 and smooth masked flows
+    transforms = [['rotation', 0, 0, 45]]
+    shape = (7, 7)
+    mk_s = np.ones(shape, 'bool'); mk_s[:, 4:] = False
+    mk_t = np.ones(shape, 'bool'); mk_t[4:] = False
+    kats = {'s': (Flow.from_transforms(transforms, shape, 's'), [5, 0, 0, 3]),
+            't': (Flow.from_transforms(transforms, shape, 't'), [0, 3, 5, 0]),
+            's_masked': (Flow.from_transforms(transforms, shape, 's', mk_s), [3, 0, 0, 1]),
+            't_masked': (Flow.from_transforms(transforms, shape, 't', mk_t), [0, 1, 3, 0])}
+    for name, (fl, want) in kats.items():
+        got = fl.get_padding()
+        assert got[0] == want, (name, got)
+        rec(g, 'get_padding_kat_' + name, 'Flow.get_padding', {"ref": fl.ref, "item": None, "padding": got},
+            flow_inputs(fl), {})
+    fl = Flow(smooth_flow(3, h, w, 6.0, 321), 's', hole_mask(3, h, w, 35))
+    for ref in 'st':
+        fl2 = Flow(fl.vecs, ref, fl.mask)
+        rec(g, 'get_padding_smooth_' + ref, 'Flow.get_padding', {"ref": ref, "item": None, "padding": fl2.get_padding()},
+            flow_inputs(fl2), {})
+        rec(g, 'get_padding_smooth_item1_' + ref, 'Flow.get_padding', {"ref": ref, "item": 1, "padding": fl2.get_padding(1)},
+            flow_inputs(fl2), {})
+    tiny = Flow(torch.rand(1, 2, 7, 7, generator=torch.Generator().manual_seed(5)) * 1e-4)
+    rec(g, 'get_padding_tiny', 'Flow.get_padding', {"ref": 't', "item": None, "padding": tiny.get_padding()},
+        flow_inputs(tiny), {})
+
+
+# ------------------------------------------------------------------------------------------------
+# group: grads  (the reference's own autograd, PyTorch CPU, as the expected gradients)
+#   loss = sum(out * w_out) with a stored random w_out; expected = d loss / d input for every floating input
+# ------------------------------------------------------------------------------------------------
+def _wts(t, seed):
+    return torch.randn(t.shape, generator=torch.Generator().manual_seed(seed))
+
+
+def gen_grads():
+    g = 'grads'
+    h, w = 20, 28
+    f = smooth_flow(2, h, w, 3.0, 401)
+    f[1, :, 4:9, 6:15] = 0                       # a zero-flow block: occlusion rule / un-occlude fill on the 's' side
+    f2 = smooth_flow(2, h, w, 2.5, 402)
+    f[1] += torch.tensor([0.2 * w, -0.25 * h]).view(2, 1, 1) * 0  # (kept in range: borders are exercised by f2 below)
+    f2[0] += torch.tensor([0.3 * w, 0.2 * h]).view(2, 1, 1)       # pushes samples / end points over the border
+    m, m2 = hole_mask(2, h, w, 41), hole_mask(2, h, w, 43)
+    img = image(2, 3, h, w, 45) / 255
+
+    def leaf(t):
+        return t.clone().requires_grad_()
+
+    # apply_flow 't' / 's' (utils.py:469-620)
+    for ref in 'st':
+        for name, fl in (('a', f), ('b', f2)):
+            fv, tv = leaf(fl), leaf(img)
+            out = ofu.apply_flow(fv, tv, ref, m if ref == 's' else None)
+            wo = _wts(out, 411)
+            (out * wo).sum().backward()
+            rec(g, 'apply_flow_%s_%s' % (ref, name), 'grad_apply_flow', {"ref": ref},
+                {"flow": fl, "target": img, "mask": m if ref == 's' else None, "w_out": wo},
+                {"g_flow": fv.grad, "g_target": tv.grad})
+        fv, tv = leaf(f[:1]), leaf(img)                        # broadcast flow: its gradient sums over the batch
+        out = ofu.apply_flow(fv, tv, ref)
+        wo = _wts(out, 412)
+        (out * wo).sum().backward()
+        rec(g, 'apply_flow_%s_bcast_flow' % ref, 'grad_apply_flow', {"ref": ref},
+            {"flow": f[:1], "target": img, "w_out": wo}, {"g_flow": fv.grad, "g_target": tv.grad})
+    # grid_from_unstructured_data (utils.py:1061-1154): x, y, data; data and density outputs both weighted
+    gen = torch.Generator().manual_seed(421)
+    x = torch.rand(2, h, w, generator=gen) * (w + 4) - 2
+    y = torch.rand(2, h, w, generator=gen) * (h + 4) - 2
+    xv, yv, dv = leaf(x), leaf(y), leaf(img)
+    od, oden = ofu.grid_from_unstructured_data(xv, yv, dv, m)
+    wd, wn = _wts(od, 422), _wts(oden, 423)
+    ((od * wd).sum() + (oden * wn).sum()).backward()
+    rec(g, 'gfud', 'grad_gfud', {}, {"x": x, "y": y, "data": img, "mask": m, "w_data": wd, "w_density": wn},
+        {"g_x": xv.grad, "g_y": yv.grad, "g_data": dv.grad})
+    # Flow-level chains: gradients wrt the vectors of both flows
+    def flow_case(cid, op, args, fn):
+        a, b = leaf(f), leaf(f2)
+        out = fn(a, b)
+        wo = _wts(out.vecs, 431)
+        (out.vecs * wo).sum().backward()
+        rec(g, cid, op, args, {"f1": f, "m1": m, "f2": f2, "m2": m2, "w_out": wo},
+            {"g_f1": a.grad if a.grad is not None else torch.zeros_like(f),
+             "g_f2": b.grad if b.grad is not None else torch.zeros_like(f2), "vecs": out.vecs.detach(), "mask": out.mask})
+    for ref in 'st':
+        oref = 't' if ref == 's' else 's'
+        flow_case('flow_apply_%s' % ref, 'grad_Flow.apply', {"ref": ref, "target_ref": oref},
+                  lambda a, b, ref=ref, oref=oref: Flow(a, ref, m).apply(Flow(b, oref, m2)))
+        flow_case('switch_ref_%s' % ref, 'grad_Flow.switch_ref', {"ref": ref},
+                  lambda a, b, ref=ref: Flow(a, ref, m).switch_ref())
+        flow_case('invert_%s' % ref, 'grad_Flow.invert', {"ref": ref},
+                  lambda a, b, ref=ref: Flow(a, ref, m).invert())
+        for mode in (1, 2, 3):
+            flow_case('combine_with_%s_m%d' % (ref, mode), 'grad_Flow.combine_with', {"ref": ref, "mode": mode},
+                      lambda a, b, ref=ref, mode=mode: Flow(a, ref, m).combine_with(Flow(b, ref, m2), mode))
+    flow_case('combine_m3_st_t', 'grad_Flow.combine', {"mode": 3, "self_ref": 's', "other_ref": 't', "ref": 't'},
+              lambda a, b: Flow(a, 's', m).combine(Flow(b, 't', m2), 3, 't'))
+    flow_case('combine_m1_ts_s', 'grad_Flow.combine', {"mode": 1, "self_ref": 't', "other_ref": 's', "ref": 's'},
+              lambda a, b: Flow(a, 't', m).combine(Flow(b, 's', m2), 1, 's'))
+    # track_pts: gradients wrt flow and points
+    gen = torch.Generator().manual_seed(441)
+    pts = torch.rand(2, 6, 2, generator=gen) * torch.tensor([h - 1.0, w - 1.0])
+    for ref in 'st':
+        fv, pv = leaf(f), leaf(pts)
+        out = ofu.track_pts(fv, ref, pv)
+        wo = _wts(out, 442)
+        (out * wo).sum().backward()
+        rec(g, 'track_pts_' + ref, 'grad_track_pts', {"ref": ref}, {"flow": f, "pts": pts, "w_out": wo},
+            {"g_flow": fv.grad, "g_pts": pv.grad, "out": out.detach()})
+
+
 def main():
     of.set_pure_pytorch()
     gen_prims()
     gen_flow_apply()
     gen_flow_ops()
     gen_kats()
+    gen_next()
+    gen_grads()
     for grp, store in GROUPS.items():
         path = os.path.join(HERE, grp + '.npz')
         np.savez_compressed(path, **store)

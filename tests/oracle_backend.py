@@ -35,8 +35,15 @@ def _round(a, mode):
     return a.astype(np.float32)
 
 
-def device():
+def device(*_operands):
     return torch.device('cpu')
+
+
+def _no_grad(*tensors):
+    """The oracle has no backward pass: a tensor that wants a gradient must not slip through silently (the HIP
+    primitives route such calls through oflibpytorch_amd._autograd)."""
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise NotImplementedError("oracle-backed primitives (CPU test tier) are forward-only")
 
 
 def flow_flags(vecs, mask=None):
@@ -46,6 +53,7 @@ def flow_flags(vecs, mask=None):
 
 def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
              a_sign=1.0, g_sign=1.0, round_mode=0, want_flags=False, want_src_flags=False, want_dst_flags=False, src_b=None, out_uint8=False):
+    _no_grad(flow, src, addend, src_b)
     f = _np(flow, np.float32) * np.float32(flow_sign)
     s = _np(src, np.float32)
     if src_b is not None:
@@ -83,6 +91,7 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
               chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False, round_mode=0,
               want_mask_chan=False, want_dst_flags=False, data_b=None):
+    _no_grad(flow, data, xs, ys, data_b)
     d = _np(data, np.float32)
     if data_b is not None:
         db = _np(data_b, np.float32)
@@ -115,3 +124,12 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     if want_dst_flags:
         res = res + (flow_flags(res[0], valid if want_valid and not want_mask_chan else None),)
     return res
+
+
+def sample_pts(flow, pts):
+    _no_grad(flow, pts)
+    return torch.tensor(oracle.sample_pts(_np(flow, np.float32), _np(pts, np.float32)))
+
+
+def flow_extents(vecs, mask, sign):
+    return torch.tensor(oracle.flow_extents(_np(vecs, np.float32), None if mask is None else _np(mask), sign))

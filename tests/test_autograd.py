@@ -1,0 +1,186 @@
+"""Differentiability of the path (reference: README.rst:7-10, test_utils.py:500, 1113-1114)
+and torch.inference_mode().
+
+CPU tier: the oracle-backed stand-ins are forward-only, so a tensor that wants a gradient must raise there instead of
+losing its gradient silently; Flow / apply / combine_with work under inference_mode (the flag cache must not read
+`_version` of an inference tensor).
+GPU tier: grad_fn presence on every differentiable output, gradient parity against torch's own autograd through the
+restated op sequence on the device (F.grid_sample / scatter_add_: a second, independent reference next to the fixtures
+of tests/golden/grads.npz, at the frame size of BASELINE config 1), non-differentiable masks, broadcast operands.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import case_runner
+
+
+def _smooth(n, h, w, sigma, seed):
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.randn(n, 2, max(h // 12, 2), max(w // 12, 2), generator=g) * sigma
+    return F.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU tier
+# ------------------------------------------------------------------------------------------------
+def test_oracle_backed_primitives_refuse_to_drop_gradients(oracle_native):
+    import oflibpytorch_amd as ofl
+    f = _smooth(1, 16, 20, 2.0, 1).requires_grad_()
+    img = torch.rand(1, 3, 16, 20)
+    with pytest.raises(NotImplementedError):
+        ofl.apply_flow(f, img, 't')
+    with pytest.raises(NotImplementedError):
+        ofl.Flow(f.detach(), 's').apply(img.clone().requires_grad_())
+    with torch.no_grad():                                      # no graph is being recorded: nothing to lose
+        assert ofl.apply_flow(f, img, 't').shape == img.shape
+
+
+def test_flow_api_under_inference_mode_cpu(oracle_native):
+    import oflibpytorch_amd as ofl
+    with torch.inference_mode():
+        f1, f2 = _smooth(2, 16, 20, 2.0, 1), _smooth(2, 16, 20, 1.5, 2)
+        m = torch.rand(2, 16, 20) > 0.1
+        a, b = ofl.Flow(f1, 't', m), ofl.Flow(f2, 't')
+        w, v = a.apply(torch.rand(2, 3, 16, 20), return_valid_area=True)
+        c = a.combine_with(b, 3)
+        assert c.vecs.shape == f1.shape and v.dtype == torch.bool and w.shape == (2, 3, 16, 20)
+        assert bool(a.is_zero().any()) is False and a.copy().mask is a.mask
+    with torch.inference_mode():
+        ref = ofl.Flow(f1.clone(), 't', m.clone()).combine_with(ofl.Flow(f2.clone(), 't'), 3)
+    assert torch.equal(ref.vecs, c.vecs)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU tier
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu tier needs a HIP device"
+    from oflibpytorch_amd import _native
+    _native.load_library()
+    return torch.device('cuda', 0)
+
+
+def _ref_apply_t(flow, target):
+    """utils.py:541-555 restated with torch ops on the device (autograd through grid_sample)."""
+    n, _, h, w = flow.shape
+    gy, gx = torch.meshgrid(torch.arange(h, device=flow.device), torch.arange(w, device=flow.device), indexing='ij')
+    grid = torch.stack((gx, gy), dim=-1).float().unsqueeze(0)
+    field = (grid - flow.permute(0, 2, 3, 1)) * 2
+    field = torch.stack((field[..., 0] / (w - 1), field[..., 1] / (h - 1)), dim=-1) - 1
+    return F.grid_sample(target.expand(n, -1, -1, -1), field, align_corners=True)
+
+
+def _ref_splat(x, y, data, mask):
+    """utils.py:1098-1144 restated with torch ops on the device (autograd through the weights and scatter_add_)."""
+    n, c, h, w = data.shape
+    x0, y0 = torch.floor(x), torch.floor(y)
+    xx, yy = torch.stack((x0, x0 + 1), -1), torch.stack((y0, y0 + 1), -1)
+    xs, ys = torch.clamp(xx, 0, w - 1), torch.clamp(yy, 0, h - 1)
+    wx = torch.stack((xx[..., 1] - x, x - xx[..., 0]), -1) * torch.eq(xx, xs).float()
+    wy = torch.stack((yy[..., 1] - y, y - yy[..., 0]), -1) * torch.eq(yy, ys).float()
+    wgt = torch.matmul(wy.unsqueeze(-1), wx.unsqueeze(-2)).permute(0, 3, 4, 1, 2).reshape(n * 4, h * w)
+    pos = ((w * ys).unsqueeze(-1) + xs.unsqueeze(-2)).permute(0, 3, 4, 1, 2).reshape(n * 4, h * w)
+    if mask is not None:
+        wgt = wgt * mask.repeat_interleave(4, dim=0).view(n * 4, h * w).float()
+    den = torch.zeros((n * 4, h * w), device=data.device).scatter_add(1, pos.long(), wgt)
+    den = den.view(n, 4, h, w).sum(1, keepdim=True)
+    acc = torch.zeros((n * 4 * c, h * w), device=data.device).scatter_add(
+        1, pos.repeat_interleave(c, dim=0).long(), wgt.repeat_interleave(c, dim=0) * data.repeat_interleave(4, dim=0).view(n * 4 * c, h * w))
+    return acc.view(n, 4, c, h, w).sum(1) / torch.clamp_min(den, 1e-3), den.squeeze(1)
+
+
+def _close(got, exp, what, rtol=case_runner.GRAD_RTOL):
+    scale = float(exp.abs().max())
+    err = float((got.double() - exp.double()).abs().max())
+    assert err <= rtol * max(scale, 1e-6), "%s: max |diff| %.3g against a gradient scale of %.3g" % (what, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bcast", [False, True])
+def test_backward_warp_gradients_against_torch_autograd(bcast, dev):
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 300, 400
+    f = _smooth(n, h, w, 6.0, 3).to(dev)
+    f[0] += torch.tensor([60.0, -40.0], device=dev).view(2, 1, 1)           # samples beyond the border (zero padding)
+    img = torch.rand(1 if bcast else n, 3, h, w, generator=torch.Generator().manual_seed(4)).to(dev)
+    wts = torch.randn(n, 3, h, w, generator=torch.Generator().manual_seed(5)).to(dev)
+    fa, ia = f.clone().requires_grad_(), img.clone().requires_grad_()
+    out = ofl.apply_flow(fa, ia, 't')
+    assert out.grad_fn is not None
+    (out * wts).sum().backward()
+    fb, ib = f.clone().requires_grad_(), img.clone().requires_grad_()
+    (_ref_apply_t(fb, ib) * wts).sum().backward()
+    _close(fa.grad, fb.grad, "grad wrt flow")
+    _close(ia.grad, ib.grad, "grad wrt target")
+    assert ia.grad.shape == img.shape
+
+
+@pytest.mark.gpu
+def test_forward_splat_gradients_against_torch_autograd(dev):
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 120, 160
+    g = torch.Generator().manual_seed(7)
+    f = _smooth(n, h, w, 4.0, 8).to(dev)
+    x = (f[:, 0] + torch.arange(w, device=dev)[None, None, :]).contiguous()
+    y = (f[:, 1] + torch.arange(h, device=dev)[None, :, None]).contiguous()
+    data = torch.rand(n, 3, h, w, generator=g).to(dev)
+    mask = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    wd, wn = torch.randn(n, 3, h, w, generator=g).to(dev), torch.randn(n, h, w, generator=g).to(dev)
+    xa, ya, da = x.clone().requires_grad_(), y.clone().requires_grad_(), data.clone().requires_grad_()
+    od, oden = ofl.grid_from_unstructured_data(xa, ya, da, mask)
+    assert od.grad_fn is not None and oden.grad_fn is not None               # test_utils.py:1113-1114
+    ((od * wd).sum() + (oden * wn).sum()).backward()
+    xb, yb, db = x.clone().requires_grad_(), y.clone().requires_grad_(), data.clone().requires_grad_()
+    rd, rden = _ref_splat(xb, yb, db, mask)
+    ((rd * wd).sum() + (rden * wn).sum()).backward()
+    _close(da.grad, db.grad, "grad wrt data")
+    _close(xa.grad, xb.grad, "grad wrt x", rtol=5e-4)
+    _close(ya.grad, yb.grad, "grad wrt y", rtol=5e-4)
+
+
+@pytest.mark.gpu
+def test_flow_methods_keep_the_graph_and_masks_do_not(dev):
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 40, 56
+    m = (torch.rand(n, h, w, generator=torch.Generator().manual_seed(2)) > 0.1).to(dev)
+    for ref in 'st':
+        fa = _smooth(n, h, w, 3.0, 11).to(dev).requires_grad_()
+        fb = _smooth(n, h, w, 2.0, 12).to(dev).requires_grad_()
+        a, b = ofl.Flow(fa, ref, m), ofl.Flow(fb, ref)
+        outs = [a.switch_ref(), a.invert(), a.invert('s' if ref == 't' else 't'), a.apply(b), a.combine(b, 3, 't')]
+        outs += [a.combine_with(b, mode) for mode in (1, 2, 3)]
+        for o in outs:
+            assert o.vecs.grad_fn is not None and not o.mask.requires_grad
+        img = torch.rand(n, 3, h, w, device=dev, requires_grad=True)
+        warped, valid = a.apply(img, return_valid_area=True)
+        assert warped.grad_fn is not None and valid.dtype == torch.bool and not valid.requires_grad
+        total = sum(o.vecs.sum() for o in outs) + warped.sum()
+        total.backward()
+        assert fa.grad is not None and fb.grad is not None and img.grad is not None
+        assert bool(torch.isfinite(fa.grad).all()) and bool(torch.isfinite(fb.grad).all())
+        # integer targets: rounded and cast back, no graph -- as in the reference (flow_class.py:943-951)
+        u8 = (torch.rand(n, 3, h, w, device=dev) * 255).to(torch.uint8)
+        assert a.apply(u8).grad_fn is None
+        pts = torch.rand(5, 2, device=dev) * torch.tensor([h - 1.0, w - 1.0], device=dev)
+        assert a.track(pts.requires_grad_()).grad_fn is not None
+
+
+@pytest.mark.gpu
+def test_flow_api_under_inference_mode_gpu(dev):
+    import oflibpytorch_amd as ofl
+    f1, f2 = _smooth(2, 64, 96, 3.0, 1).to(dev), _smooth(2, 64, 96, 2.0, 2).to(dev)
+    m = (torch.rand(2, 64, 96, generator=torch.Generator().manual_seed(3)) > 0.1).to(dev)
+    img = torch.rand(2, 3, 64, 96, device=dev)
+    plain = [ofl.Flow(f1, r, m).combine_with(ofl.Flow(f2, r), k).vecs for r in 'st' for k in (1, 2, 3)]
+    pw = ofl.Flow(f1, 's', m).apply(img)
+    with torch.inference_mode():
+        a = {r: ofl.Flow(f1.clone(), r, m.clone()) for r in 'st'}
+        got = [a[r].combine_with(ofl.Flow(f2.clone(), r), k).vecs for r in 'st' for k in (1, 2, 3)]
+        gw = a['s'].apply(img.clone())
+        assert a['t'].copy().switch_ref().ref == 's'
+    for p, q in zip(plain, got):
+        assert torch.equal(p, q)
+    assert torch.equal(pw, gw)

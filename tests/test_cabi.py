@@ -34,11 +34,19 @@ def test_argument_validation_needs_no_gpu():
     # NULL required pointers
     assert lib.ofl_warp_bwd_f32(null, 0, 1.0, null, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, null, null, null, null, null,
                                 1, 1, 4, 4, 0, null) == -1
-    # bad dims / h*w >= 2^24 (utils.py:1118 fp32 index limit)
+    # bad dims; h*w >= 2^24 is the forward splat's limit only (utils.py:1118: fp32 position index)
     assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
                                 0, 1, 4, 4, 0, null) == -2
-    assert lib.ofl_warp_bwd_f32(one, 0, 1.0, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
-                                1, 1, 4096, 4096, 0, null) == -2
+    assert lib.ofl_splat_fwd_f32(one, 0, 1.0, null, null, 0, one, 0, 1.0, null, 0, null, 0, null, 0, 0, 0, one,
+                                 1, 1, 4096, 4096, null) == -2
+    assert lib.ofl_warp_bwd_u8(one, 0, 1.0, one, 0, null, 0, null, 0, one, 0, null, 1, 1, 4096, 4096, 0, null) == -4
+    # the new entry points: NULL / shape / argument checks
+    assert lib.ofl_warp_bwd_grad_f32(null, 0, 1.0, null, 0, null, 1.0, null, 0, null, 1, 1, 4, 4, null) == -1
+    assert lib.ofl_warp_bwd_grad_f32(one, 0, 1.0, one, 0, one, 1.0, null, 0, null, 1, 1, 4, 4, null) == -3
+    assert lib.ofl_splat_grad_f32(one, 0, 1.0, null, null, 0, one, 0, null, 0, 1, one, one, one, null, one, null,
+                                  1, 9, 4, 4, null) == -4
+    assert lib.ofl_sample_pts_f32(one, 0, one, 0, one, 1, 0, 4, 4, null) == -2
+    assert lib.ofl_flow_extents_f32(one, 0, null, 0, 0.5, one, one, 1, 4, 4, null) == -3
     # flow_sign must be +-1, round mode 0..2
     assert lib.ofl_warp_bwd_f32(one, 0, 0.5, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
                                 1, 1, 4, 4, 0, null) == -3

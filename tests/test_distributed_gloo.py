@@ -76,6 +76,14 @@ def _worker(rank, world, port, q):
         assert float(ofd.broadcast_operand(shared, src=0).sum()) == 7.0 * 48
         gathered = ofd.all_gather_batch(out.vecs)
         assert np.array_equal(gathered.numpy(), ev)
+        # ragged shards (3 elements over 2 ranks: 2 + 1; 1 element: 1 + 0) gather in order
+        for total in (3, 1):
+            a0, a1 = ofd.shard_bounds(total, rank, world)
+            part = torch.arange(float(total))[a0:a1].reshape(-1, 1, 1) * torch.ones(1, 2, 3)
+            assert ofd.all_gather_batch(part)[:, 0, 0].tolist() == [float(v) for v in range(total)]
+        # device-side words: the local words come back unchanged, followed by the OR over both ranks
+        words = ofd.with_global_or(torch.tensor([1 << rank, 4], dtype=torch.int32))
+        assert words.tolist() == [1 << rank, 4, 0b111]
         ofd.disable_batch_sharding()
         assert not ofd.is_enabled()
         dist.barrier()

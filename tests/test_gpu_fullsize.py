@@ -147,3 +147,85 @@ def test_config5_4k_fp16_switch_ref_then_mode1(dev):
         assert np.array_equal(b.vecs.cpu().numpy(), cv)
     else:
         np.testing.assert_allclose(b.vecs.cpu().numpy(), cv, rtol=2e-5, atol=2e-5 * 60)
+
+
+def test_batch_of_64_switch_ref_and_mode1(frames, dev):
+    """B = 64 at 1080p through the forward-splat family: `switch_ref` (both references) and `combine_with` mode 1 (both
+    references) on 32 copies of two frames repeat the B = 2 results bit for bit -- several passes of the splat, every XCD."""
+    import oflibpytorch_amd as ofl
+    t, _ = frames
+    rep = lambda x: x.repeat((32,) + (1,) * (x.dim() - 1))
+    fs, f2, m1, m2 = (rep(t[k]) for k in ("fs", "f2", "m1", "m2"))
+    for ref in 'st':
+        big = ofl.Flow(fs, ref, m1).switch_ref()
+        small = ofl.Flow(t["fs"], ref, t["m1"]).switch_ref()
+        assert torch.equal(big.vecs, rep(small.vecs)) and torch.equal(big.mask, rep(small.mask)), ref
+        big = ofl.Flow(fs, ref, m1).combine_with(ofl.Flow(f2, ref, m2), 1)
+        small = ofl.Flow(t["fs"], ref, t["m1"]).combine_with(ofl.Flow(t["f2"], ref, t["m2"]), 1)
+        assert torch.equal(big.vecs, rep(small.vecs)) and torch.equal(big.mask, rep(small.mask)), ref
+
+
+def test_config5_at_its_per_gpu_batch(dev):
+    """BASELINE.json configs[4] at the batch one GPU of eight holds: B = 16, 2160 x 3840, flows stored in fp16;
+    `switch_ref` 's' -> 't', then `combine_with` mode 1 in 't' -- 8 copies of two frames must repeat the B = 2 results bit
+    for bit (the B = 2 results themselves are pinned against the oracle by the B = 1 test above)."""
+    import bench
+    import oflibpytorch_amd as ofl
+    h, w = 2160, 3840
+    f1 = bench.smooth_flow(2, h, w, 2.0, 7000, dev).half()
+    f2 = bench.smooth_flow(2, h, w, 8.0, 5000, dev).half()
+    m1 = torch.ones(2, h, w, dtype=torch.bool, device=dev)
+    m1[:, 300:500, 1000:2500] = False
+    m2 = torch.ones(2, h, w, dtype=torch.bool, device=dev)
+    m2[1, 1500:1550] = False
+    rep = lambda x: x.repeat((8,) + (1,) * (x.dim() - 1))
+    small_a = ofl.Flow(f1, 's', m1).switch_ref()
+    small_b = small_a.combine_with(ofl.Flow(f2, 't', m2), 1)
+    big_a = ofl.Flow(rep(f1), 's', rep(m1)).switch_ref()
+    assert big_a.vecs.shape[0] == 16 and big_a.ref == 't'
+    assert torch.equal(big_a.vecs, rep(small_a.vecs)) and torch.equal(big_a.mask, rep(small_a.mask))
+    big_b = big_a.combine_with(ofl.Flow(rep(f2), 't', rep(m2)), 1)
+    assert torch.equal(big_b.vecs, rep(small_b.vecs)) and torch.equal(big_b.mask, rep(small_b.mask))
+
+
+@pytest.mark.parametrize("size", [(300, 400), (1080, 1920)])
+def test_uint8_warp_against_the_oracle(size, dev):
+    """ofl_warp_bwd_u8 against the ORACLE (not against the float kernel): round-half-even + clamp of oracle.G on the
+    converted image (flow_class.py:943-951, utils.py:613-618), and the valid mask of the same call, at 300 x 400
+    (BASELINE config 1's frame) and 1080p."""
+    import bench
+    import oflibpytorch_amd as ofl
+    from oracle import oracle
+    h, w = size
+    g = torch.Generator().manual_seed(17)
+    img = torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8)
+    f = bench.smooth_flow(2, h, w, 8.0, 1234, torch.device('cpu'))
+    m = bench.hole_mask(2, h, w, torch.device('cpu'))
+    tm = bench.hole_mask(2, h, w, torch.device('cpu')).flip(1)
+    out, valid = ofl.Flow(f.to(dev), 't', m.to(dev)).apply(img.to(dev), target_mask=tm.to(dev), return_valid_area=True)
+    assert out.dtype == torch.uint8
+    exp, expv = oracle.flow_apply(f.numpy(), 't', m.numpy(), img.float().numpy(), tm.numpy())
+    exp8 = np.clip(np.rint(exp), 0, 255).astype(np.uint8)
+    assert np.array_equal(out.cpu().numpy(), exp8)
+    assert np.array_equal(valid.cpu().numpy(), expv)
+    plain = ofl.apply_flow(f.to(dev), img.to(dev), 't')                   # apply_flow's own uint8 rule
+    assert plain.dtype == torch.uint8 and np.array_equal(plain.cpu().numpy(), exp8)
+
+
+def test_frames_beyond_2_pow_24_pixels_take_the_backward_warp(dev):
+    """The 2^24-pixel limit is the forward splat's (fp32 position index, utils.py:1118); the reference's grid_sample path
+    has none.  A 4096 x 4352 frame is warped ('t') by the generic kernel: equal to the oracle on a strip."""
+    import oflibpytorch_amd as ofl
+    from oracle import oracle
+    h, w = 4096, 4352
+    g = torch.Generator().manual_seed(3)
+    lo = torch.randn(1, 2, 8, 9, generator=g) * 5
+    f = torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous()
+    img = torch.rand(1, 1, h, w, generator=g)
+    fl = ofl.Flow(f.to(dev), 't')
+    out, valid = fl.apply(img.to(dev), return_valid_area=True)
+    exp, expv = oracle.flow_apply(f.numpy(), 't', np.ones((1, h, w), bool), img.numpy())
+    assert np.array_equal(out.cpu().numpy(), exp) and np.array_equal(valid.cpu().numpy(), expv)
+    assert bool(fl.is_zero()[0]) is False
+    with pytest.raises((RuntimeError, ValueError)):
+        ofl.Flow(f.to(dev), 's').apply(img.to(dev))                       # the splat keeps the reference's limit
