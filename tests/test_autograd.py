@@ -5,7 +5,7 @@ CPU tier: the oracle-backed stand-ins are forward-only, so a tensor that wants a
 losing its gradient silently; Flow / apply / combine_with work under inference_mode (the flag cache must not read
 `_version` of an inference tensor).
 GPU tier: grad_fn presence on every differentiable output, gradient parity against torch's own autograd through the
-restated op sequence on the device (F.grid_sample / scatter_add_: a second, independent reference next to the fixtures
+restated op sequence on the CPU (F.grid_sample / scatter_add_: a second, independent reference next to the fixtures
 of tests/golden/grads.npz, at the frame size of BASELINE config 1), non-differentiable masks, broadcast operands.
 """
 import numpy as np
@@ -111,10 +111,12 @@ def test_backward_warp_gradients_against_torch_autograd(bcast, dev):
     out = ofl.apply_flow(fa, ia, 't')
     assert out.grad_fn is not None
     (out * wts).sum().backward()
-    fb, ib = f.clone().requires_grad_(), img.clone().requires_grad_()
-    (_ref_apply_t(fb, ib) * wts).sum().backward()
-    _close(fa.grad, fb.grad, "grad wrt flow")
-    _close(ia.grad, ib.grad, "grad wrt target")
+    # torch's CPU kernels: the reference's own device, whose fp32 operation order (and so every floor() decision -- the
+    # gradient wrt positions jumps across cell borders) the HIP kernels restate bit for bit
+    fb, ib = f.cpu().clone().requires_grad_(), img.cpu().clone().requires_grad_()
+    (_ref_apply_t(fb, ib) * wts.cpu()).sum().backward()
+    _close(fa.grad.cpu(), fb.grad, "grad wrt flow")
+    _close(ia.grad.cpu(), ib.grad, "grad wrt target")
     assert ia.grad.shape == img.shape
 
 
@@ -133,12 +135,12 @@ def test_forward_splat_gradients_against_torch_autograd(dev):
     od, oden = ofl.grid_from_unstructured_data(xa, ya, da, mask)
     assert od.grad_fn is not None and oden.grad_fn is not None               # test_utils.py:1113-1114
     ((od * wd).sum() + (oden * wn).sum()).backward()
-    xb, yb, db = x.clone().requires_grad_(), y.clone().requires_grad_(), data.clone().requires_grad_()
-    rd, rden = _ref_splat(xb, yb, db, mask)
-    ((rd * wd).sum() + (rden * wn).sum()).backward()
-    _close(da.grad, db.grad, "grad wrt data")
-    _close(xa.grad, xb.grad, "grad wrt x", rtol=5e-4)
-    _close(ya.grad, yb.grad, "grad wrt y", rtol=5e-4)
+    xb, yb, db = x.cpu().clone().requires_grad_(), y.cpu().clone().requires_grad_(), data.cpu().clone().requires_grad_()
+    rd, rden = _ref_splat(xb, yb, db, mask.cpu())
+    ((rd * wd.cpu()).sum() + (rden * wn.cpu()).sum()).backward()
+    _close(da.grad.cpu(), db.grad, "grad wrt data")
+    _close(xa.grad.cpu(), xb.grad, "grad wrt x", rtol=5e-4)
+    _close(ya.grad.cpu(), yb.grad, "grad wrt y", rtol=5e-4)
 
 
 @pytest.mark.gpu

@@ -180,3 +180,48 @@ def test_oracle_config1_known_answers(cid, golden):
     assert int(mask.sum()) == a["mask_count"]
     sub = codec.subsample(vec, 4)
     _exact(sub[0] if exp["sub4"].ndim == sub.ndim - 1 else sub, exp["sub4"], "vec")
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle/torch_ops.py: the reference's torch-CPU op sequence that bench.py times as the CPU baseline
+# ------------------------------------------------------------------------------------------------
+def _torch_apply_cases():
+    out = []
+    for cid in golden_ids('Flow.apply'):
+        from conftest import _GOLDEN
+        c = _GOLDEN.cases[cid]
+        if c["args"]["ref"] == 't' and c["args"]["kwargs"].get("padding") is None and "target_mask" in c["in"] \
+                and c["args"]["kwargs"].get("return_valid_area") and "tf" not in c["in"]:
+            out.append(cid)
+    return out
+
+
+@pytest.mark.parametrize("cid", _torch_apply_cases())
+def test_torch_op_sequence_apply_t(cid, golden):
+    import torch
+    from oracle import torch_ops
+    case = golden.cases[cid]
+    i, exp = golden.arrays(case)
+    t = torch.tensor(i["target"]).float()
+    if t.dim() != 4 or i["f"].ndim != 4 or i["target_mask"].ndim != 3:
+        pytest.skip("rank plumbing is not part of the timed sequence")
+    f, m, tm = torch.tensor(i["f"]), torch.tensor(i["m"]), torch.tensor(i["target_mask"])
+    if t.shape[0] != f.shape[0] or tm.shape[0] != f.shape[0] or i["target"].dtype.kind != 'f':
+        pytest.skip("broadcast / integer targets are not part of the timed sequence")
+    w, v = torch_ops.flow_apply_t(f, m, t, tm)
+    _exact(w.numpy(), exp["warped"], "warped")
+    _exact(v.numpy(), exp["valid"], "valid")
+
+
+@pytest.mark.parametrize("cid", [c for c in golden_ids('Flow.combine_with')])
+def test_torch_op_sequence_combine_mode3_t(cid, golden):
+    import torch
+    from oracle import torch_ops
+    case = golden.cases[cid]
+    a = case["args"]
+    if a["mode"] != 3 or a["ref"] != 't' or a.get("thresholded"):
+        pytest.skip("the timed sequence is mode 3, 't'")
+    i, exp = golden.arrays(case)
+    v, m = torch_ops.combine_mode3_t(torch.tensor(i["f1"]), torch.tensor(i["m1"]), torch.tensor(i["f2"]), torch.tensor(i["m2"]))
+    _exact(v.numpy(), exp["vecs"], "vecs")
+    _exact(m.numpy(), exp["mask"], "mask")
