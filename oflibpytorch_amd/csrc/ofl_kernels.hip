@@ -751,18 +751,21 @@ struct SplatParams {
     int32_t round_mode;
     int32_t tiles_x, tiles_y;
     int64_t total_tiles, per_xcd;
-    const int32_t* run_if_set;   // optional device flag: the atomics path runs only when *run_if_set != 0
+    const int32_t* run_if_set;   // optional device flags int32[n]: the atomics path runs for image i only when run_if_set[i] != 0
+    const int32_t* any_set;      // (with run_if_set) one word: some image of the pass is flagged
     int32_t* dst_flags;          // optional int32[N] (2-channel data only): flag word of the OUTPUT read as a flow under `valid`
 };
 
 template <int CT>
 __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
-    if (p.run_if_set && *p.run_if_set == 0) return;
-    const int64_t tile = logical_block(p.per_xcd);
-    if (tile >= p.total_tiles) return;
+    // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid that leaves at once when no
+    // image of the pass is flagged; otherwise one block per tile, XCD-aware
+    if (p.run_if_set && *p.any_set == 0) return;
+  for (int64_t tile = p.run_if_set ? (int64_t)blockIdx.x : logical_block(p.per_xcd); tile < p.total_tiles; tile += p.run_if_set ? (int64_t)gridDim.x : p.total_tiles) {
     const int tx = (int)(tile % p.tiles_x);
     const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
     const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
+    if (p.run_if_set && p.run_if_set[n] == 0) continue;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = tx * kTileW + lane;
     const int w = p.w, h = p.h;
@@ -832,6 +835,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
             }
         }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -839,12 +843,14 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
 // ------------------------------------------------------------------------------------------------
 template <int CT>
 __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p) {
-    if (p.run_if_set && *p.run_if_set == 0) return;
-    const int64_t tile = logical_block(p.per_xcd);
-    if (tile >= p.total_tiles) return;
+    // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid that leaves at once when no
+    // image of the pass is flagged; otherwise one block per tile, XCD-aware
+    if (p.run_if_set && *p.any_set == 0) return;
+  for (int64_t tile = p.run_if_set ? (int64_t)blockIdx.x : logical_block(p.per_xcd); tile < p.total_tiles; tile += p.run_if_set ? (int64_t)gridDim.x : p.total_tiles) {
     const int tx = (int)(tile % p.tiles_x);
     const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
     const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
+    if (p.run_if_set && p.run_if_set[n] == 0) continue;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = tx * kTileW + lane;
     const int w = p.w, h = p.h;
@@ -905,95 +911,107 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
         dflags = wave_or_flags(dflags);
         if (lane == 0) flag_or(&p.dst_flags[n], dflags);
     }
+  }
 }
 
 
 // ------------------------------------------------------------------------------------------------
-// forward splat, routed fast path (ofl_splat_tiled_f32): sort by destination tile, then exact per-tile accumulation
+// forward splat, GATHER formulation (ofl_splat_tiled_f32): the destination tile finds its own sources
 //
-//  route kernel: one block per 32 x 16 SOURCE tile.  End points of its pixels; every pixel goes, as a record of
-//     12 + 4 C bytes (end point x, y | raster key with the mask-channel bit below it | data x data_sign), to the queue
-//     of each DESTINATION tile one of its four corners falls into (1.1 queues per pixel on smooth flows).  Ranks come
-//     from LDS integer atomics per local destination tile, then ONE global atomic per (source tile, destination tile) on
-//     the queue's length.  Queues have fixed addresses -- no sizing pass, no scan: 1024 records per tile, then blocks
-//     of 1024 drawn from a shared pool on demand (one compare-and-swap per slot of 1024 queue positions).
-//  tile kernel : one block per 32 x 16 DESTINATION tile.
-//     A  its queue -> LDS, 16-byte loads;
-//     B  every record is pushed on the list of its CELL (the unit square floor(x), floor(y) of its end point): one LDS
-//        atomic exchange.  The four corner classes of destination pixel (X, Y) are the cells (X - kx, Y - ky), so one
-//        list per cell serves them all;
+//  bin kernel   : every 16 x 4 SOURCE subtile (16 lanes x 4 pixels: one DPP row) takes the bounding box of the destination
+//                 pixels its end points touch and appends its 4-byte id to the list of each DESTINATION tile the box
+//                 overlaps (2.0 lists per subtile on smooth flows; fixed capacity, one integer atomic per append).  Reads
+//                 the flow and the weight mask only (9 B/px), writes ~0.1 B/px.
+//  gather kernel: one block per 32 x 16 DESTINATION tile.
+//     A  walks its list, 16 subtiles per step: flow, mask and data of the listed source pixels straight from the operand
+//        tensors (16-byte row-coalesced loads, served by L2 for the ~2 tiles that share a subtile), end points in the
+//        reference's order (utils.py:1056-1057), the pixels whose unit cell lies in the tile's 33 x 17 cells become
+//        RECORDS IN LDS ONLY (x, y, raster key + mask-channel bit, data): ballot + popcount ranks, one LDS atomic per wave
+//        and step; every record is pushed on the list of its CELL (one LDS atomic exchange);
 //     S  every cell is put in raster order of its source pixels once: up to 4 records by a sorting network in registers
 //        (written as four 16-bit slots), 5 .. 64 by an insertion sort of the list itself;
 //     C  each thread sums its own 2 destination pixels in registers: its 3 x 2 cells, every record fetched once and
 //        added, in list order, to each corner-class sum it belongs to, then ((c0 + c1) + c2) + c3 -- exactly the order
 //        of the reference's four scatter_add_ passes and its corner sum (utils.py:1133-1143), products rounded before
-//        they are added: BIT-IDENTICAL to the reference, and run to run; normalise, threshold, un-occlude, store (and,
-//        for flows, the output's flag word as a by-product).
-//     A queue longer than the LDS records (1024) is processed in 2 or 4 bands of destination rows, each band compacting
-//     the records that touch it.
-//  No float atomics, no accumulator in HBM.
-//  Only a heavy fold of the flow (> 64 sources in one cell, or more records for one tile than four bands hold) makes
-//  THAT tile fall back to LDS float atomics over the same queue (tolerance instead of bit-exactness for that tile).
-//  The launch-level two-pass path only runs for input the queues cannot hold (> 9216 records for one tile, or more
-//  blocks drawn than the one per two tiles provisioned) or source tiles that spread over > 48 destination tiles.
+//        they are added: BIT-IDENTICAL to the reference, and run to run; normalise, threshold, un-occlude, 16-byte stores
+//        (lane pairs exchange their halves through DPP), and, for flows, the output's flag word as a by-product.
+//     More records than the LDS holds (1024: a compression of the flow) are taken in 2 or 4 bands of destination rows,
+//     each band walking the list again.
+//  No record ever reaches HBM (the routed version of round 1 wrote and re-read 27 B/px of them), no float atomics, no
+//  accumulator in HBM, no workspace beyond 516 bytes per destination tile.
+//  Only a heavy fold of the flow (> 64 sources in one cell, or more records than four bands hold) makes THAT tile fall
+//  back to LDS float atomics over the same list (tolerance instead of bit-exactness for that tile).  An IMAGE whose lists
+//  overflow (> 128 subtiles for one destination tile: a 16-fold compression) or whose subtiles spread over > 256
+//  destination tiles takes the two-pass global-atomics path inside the same call, decided on the device, per image.
 // ------------------------------------------------------------------------------------------------
-#ifndef OFL_SP_TH
-#define OFL_SP_TH 16
-#endif
-constexpr int kSpTW = 32, kSpTH = OFL_SP_TH;                 // source and destination tiles
-constexpr int kSpNT = kSpTW * kSpTH / 4;                     // route kernel: 4 source pixels per thread
-constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // tile kernel: 2 destination pixels per thread
+constexpr int kSpTW = 32, kSpTH = 16;                        // destination tiles
+constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // gather kernel: 2 destination pixels per thread
 #ifndef OFL_SP_Q
-#define OFL_SP_Q (64 * OFL_SP_TH)
+#define OFL_SP_Q 896    // (1024 leaves room for 3 blocks per CU only; 896: 39.7 KB per block, 4 blocks -- measured -4 % / -13 % on apply 's' / switch_ref)
 #endif
-constexpr int kSpQ = OFL_SP_Q;    // records the tile kernel holds in LDS at a time (1024 measured faster than 768 + one more block per CU)
-constexpr int kSpRouteMax = 48;   // destination tiles one source tile may feed
-// Queues have fixed addresses (no sizing pass): every destination tile owns kSpPrim records; the records beyond them go to
-// blocks of kSpPrim records drawn from a shared pool on demand, one per slot of kSpPrim queue positions (up to kSpSlots
-// per tile; one block per 2 tiles is provisioned).  More than (1 + kSpSlots) * kSpPrim records for a tile (18 per
-// pixel), or more draws than blocks, send the launch to the two-pass path.
-constexpr int kSpPrim = OFL_SP_Q, kSpSlots = 8, kSpSecDiv = 2;
-#ifndef OFL_SP_LONG
-#define OFL_SP_LONG 64
-#endif
-constexpr int kSpLong = OFL_SP_LONG;   // longest cell list (source pixels whose end points share one unit cell) that is summed in raster order
+constexpr int kSpQ = OFL_SP_Q;                               // records the gather kernel holds in LDS at a time
+constexpr int kSubW = 16, kSubH = 4;                         // source subtiles: 4 lanes x 4 pixels wide, 4 rows
+constexpr int kBinCap = 128;                                 // subtiles one destination tile can list
+constexpr int kBinSpread = 256;                              // destination tiles one subtile may touch
+constexpr int kSpLong = 64;   // longest cell list (source pixels whose end points share one unit cell) that is summed in raster order
 
-__device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-zero -> 0x01
-    uint32_t r = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r |= (uint32_t)(((x >> (8 * k)) & 0xffu) != 0u) << (8 * k);
-    return r;
+__device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-zero -> 0x01 (SWAR: the low 7 bits carry into bit 7)
+    return ((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;
 }
 
-struct TiledParams {
+struct GatherParams {
     SplatParams s;
-    int32_t* cursor;       // [n * tiles] records routed to the tile so far (its queue length once the route kernel is done)
-    int32_t* sec;          // [n * tiles][kSpSlots] block that holds queue positions kSpPrim * (1 + slot) .. of the tile, -1 = none
-    float* prim;           // [n * tiles][3 + C][kSpPrim]: end point x | end point y | raster key + mask-channel bit | data ...
-    float* secp;           // [nsec][3 + C][kSpPrim]: the blocks
-    int32_t nsec;
-    int32_t* sec_count;    // [1] secondary blocks drawn in this pass
-    int32_t* overflow;     // [4]: launch falls back | tiles that left the exact path | - | -
+    int32_t* cnt;          // [n * tiles] subtiles listed for the tile
+    uint32_t* list;        // [n * tiles][kBinCap] subtile ids (row-major over the image's subtile grid)
+    int32_t* stats;        // [0] some image took the two-pass path | [1] tiles that left the exact path | [2] images that did | [3] tiles of the current launch
+    int32_t* img_over;     // [n] this image takes the two-pass path
+    int32_t* fb_list;      // [n * tiles] gather blocks whose tile left the exact path (stats[1] of them): redone by splat_tile_fallback_kernel
     int32_t tiles_x, tiles_y;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;
     int64_t total, per_xcd;
+    int32_t subs_x; uint32_t sx_m, sx_s;                     // subtiles per image row (+ magic divisor)
+    int32_t regs_x, regs_y;                                  // bin kernel: 64 x 16 source regions (4 waves x 4 subtiles)
+    uint32_t regs_img, rx_m, rx_s, ri_m, ri_s;
+    int64_t rtotal, rper_xcd;
 };
 
-__device__ __forceinline__ bool sp_decode(const TiledParams& p, int& tx, int& ty, int& n) {
+// XCD-aware 32-bit decode of (column, row, image) from the block index
+__device__ __forceinline__ bool decode3(int64_t total, int64_t per_xcd, uint32_t per_img, uint32_t mi_m, uint32_t mi_s,
+                                        uint32_t mx_m, uint32_t mx_s, int32_t nx, int& tx, int& ty, int& n) {
     const uint32_t b = blockIdx.x;
-    const uint32_t tile = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
-    if (tile >= (uint32_t)p.total) return false;
-    const uint32_t nn = fastdiv(tile, p.mi_m, p.mi_s);
-    const uint32_t rem = tile - nn * p.tiles_img;
-    const uint32_t yy = fastdiv(rem, p.mx_m, p.mx_s);
-    n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (uint32_t)p.tiles_x);
+    const uint32_t tile = (b & 7u) * (uint32_t)per_xcd + (b >> 3);
+    if (tile >= (uint32_t)total) return false;
+    const uint32_t nn = fastdiv(tile, mi_m, mi_s);
+    const uint32_t rem = tile - nn * per_img;
+    const uint32_t yy = fastdiv(rem, mx_m, mx_s);
+    n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (uint32_t)nx);
     return true;
 }
 
 // end point + contribution test of the 4 source pixels of a thread
-struct SpSrc { float x[4], y[4]; bool on[4]; bool zero[4]; bool wm[4]; };
+struct SpSrc { float x[4], y[4]; uint32_t on; };   // on: bit k = pixel k contributes (inside the image, weight mask set, not an occluded zero-flow pixel)
 
-__device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4, int sy, bool inimg, uint32_t pix, uint32_t hw, SpSrc& q) {
+// end points and contribution test from the loaded flow (or positions) and weight-mask bytes of a 4-pixel group
+template <typename SP>
+__device__ __forceinline__ void sp_finish_src(const SP& s, int sx4, int sy, bool inimg, const f4& a, const f4& b, uint32_t wm4, SpSrc& q) {
+    q.on = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bool zero = false;
+        if (s.flow) {
+            q.x[k] = s.flow_sign * a[k] + (float)(sx4 + k);      // get_flow_endpoints utils.py:1056-1057
+            q.y[k] = s.flow_sign * b[k] + (float)sy;
+            if (s.occlude) zero = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr);
+        } else {
+            q.x[k] = a[k]; q.y[k] = b[k];
+        }
+        const bool wm = ((wm4 >> (8 * k)) & 0xffu) != 0u;
+        if (inimg && (sx4 + k < s.w) && wm && !zero) q.on |= 1u << k;
+    }
+}
+
+template <typename SP>
+__device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy, bool inimg, uint32_t pix, uint32_t hw, SpSrc& q) {
     f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     uint32_t wm4 = 0x01010101u;
     // the last group of a row of an image whose width is not a multiple of 4: fetch the last whole group and rotate
@@ -1013,177 +1031,111 @@ __device__ __forceinline__ void sp_load_src(const SplatParams& s, int n, int sx4
             if (edge) { a = rot4(a, 4 - wrem); b = rot4(b, 4 - wrem); wm4 >>= 8 * (4 - wrem); }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        q.zero[k] = false;
-        if (s.flow) {
-            q.x[k] = s.flow_sign * a[k] + (float)(sx4 + k);      // get_flow_endpoints utils.py:1056-1057
-            q.y[k] = s.flow_sign * b[k] + (float)sy;
-            if (s.occlude) q.zero[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr);
-        } else {
-            q.x[k] = a[k]; q.y[k] = b[k];
-        }
-        q.wm[k] = ((wm4 >> (8 * k)) & 0xffu) != 0u;
-        q.on[k] = inimg && (sx4 + k < s.w) && q.wm[k] && !q.zero[k];
-    }
+    sp_finish_src(s, sx4, sy, inimg, a, b, wm4, q);
 }
 
-__global__ __launch_bounds__(kSpNT) void splat_route_kernel(const TiledParams p) {
-    __shared__ int red[kSpNT / 64][4];
-    __shared__ int lcount[kSpRouteMax], lbase[kSpRouteMax], lsec[kSpRouteMax], lsec1[kSpRouteMax], lslot[kSpRouteMax], ltile[kSpRouteMax];
-    if (*p.overflow != 0) return;
-    int tx, ty, n;
-    if (!sp_decode(p, tx, ty, n)) return;
+// min / max of two packed 16-bit fields over the 16 lanes of a DPP row (every lane of the row gets the result)
+__device__ __forceinline__ int row_pk_min_dpp(int v) {
+    v = pk_min16(v, OFL_DPP(v, 0xB1)); v = pk_min16(v, OFL_DPP(v, 0x4E)); v = pk_min16(v, OFL_DPP(v, 0x141)); return pk_min16(v, OFL_DPP(v, 0x140));
+}
+__device__ __forceinline__ int row_pk_max_dpp(int v) {
+    v = pk_max16(v, OFL_DPP(v, 0xB1)); v = pk_max16(v, OFL_DPP(v, 0x4E)); v = pk_max16(v, OFL_DPP(v, 0x141)); return pk_max16(v, OFL_DPP(v, 0x140));
+}
+
+constexpr int kBinLocal = 64;   // destination tiles one 64 x 16 source region aggregates in LDS (more: straight to the global counters)
+
+__global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
+    __shared__ int red[4][2];
+    __shared__ int lcount[kBinLocal], lbase[kBinLocal];
+    int rx, ry, n;
+    if (!decode3(p.rtotal, p.rper_xcd, p.regs_img, p.ri_m, p.ri_s, p.rx_m, p.rx_s, p.regs_x, rx, ry, n)) return;
     const SplatParams& s = p.s;
-    const int tid = threadIdx.x, lx = tid & 7, ly = tid >> 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane >> 4, r = (lane >> 2) & 3, c4 = lane & 3;       // subtile of the wave, row and 4-pixel group in it
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
-    const int sx4 = tx * kSpTW + lx * 4, sy = ty * kSpTH + ly;
+    const int sx4 = rx * (4 * kSubW) + sub * kSubW + c4 * 4, sy = ry * (4 * kSubH) + wave * kSubH + r;
     const bool inimg = (sx4 < w) && (sy < h);
     SpSrc q;
     sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
-    if (tid < kSpRouteMax) lcount[tid] = 0;
-    // destination tile columns / rows of the (at most two) in-image corner columns / rows of every pixel; -1: none
-    int tca[4], tcb[4], tra[4], trb[4];
-    int minx = 0x7fffffff, maxx = -0x7fffffff, miny = 0x7fffffff, maxy = -0x7fffffff;
+    if (tid < kBinLocal) lcount[tid] = 0;
+    // destination pixels the four corners of this thread's end points touch (clamped corners carry weight 0,
+    // utils.py:1106-1111: they touch nothing)
+    int lo = 0x7fff7fff, hi = (int)0xffffffffu;                          // (x, y) = (32767, 32767) / (-1, -1)
     const float wf = (float)w, hf = (float)h;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        tca[k] = tcb[k] = tra[k] = trb[k] = -1;
-        if (q.on[k]) {
-            // a corner outside the image is clamped by the reference and carries weight 0 (utils.py:1106-1111)
+        if ((q.on >> k) & 1u) {
             const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf), y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf);
-            if ((uint32_t)x0 < (uint32_t)w) tca[k] = x0 / kSpTW;
-            if ((uint32_t)(x0 + 1) < (uint32_t)w) tcb[k] = (x0 + 1) / kSpTW;
-            if ((uint32_t)y0 < (uint32_t)h) tra[k] = y0 / kSpTH;
-            if ((uint32_t)(y0 + 1) < (uint32_t)h) trb[k] = (y0 + 1) / kSpTH;
-            if (tcb[k] == tca[k]) tcb[k] = -1;
-            if (trb[k] == tra[k]) trb[k] = -1;
-            if (tca[k] < 0) { tca[k] = tcb[k]; tcb[k] = -1; }
-            if (tra[k] < 0) { tra[k] = trb[k]; trb[k] = -1; }
-            if (tca[k] >= 0 && tra[k] >= 0) {
-                minx = min(minx, tca[k]); maxx = max(maxx, max(tca[k], tcb[k]));
-                miny = min(miny, tra[k]); maxy = max(maxy, max(tra[k], trb[k]));
+            const int xa = max(x0, 0), xb = min(x0 + 1, w - 1), ya = max(y0, 0), yb = min(y0 + 1, h - 1);
+            if (xa <= xb && ya <= yb) {
+                lo = pk_min16(lo, (int)((uint32_t)xa | ((uint32_t)ya << 16)));
+                hi = pk_max16(hi, (int)((uint32_t)xb | ((uint32_t)yb << 16)));
             }
         }
     }
-    minx = wave_min_dpp(minx); maxx = wave_max_dpp(maxx); miny = wave_min_dpp(miny); maxy = wave_max_dpp(maxy);
-    if ((tid & 63) == 0) { red[tid >> 6][0] = minx; red[tid >> 6][1] = maxx; red[tid >> 6][2] = miny; red[tid >> 6][3] = maxy; }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kSpNT / 64; ++i) {
-        minx = min(minx, red[i][0]); maxx = max(maxx, red[i][1]); miny = min(miny, red[i][2]); maxy = max(maxy, red[i][3]);
-    }
-    minx = __builtin_amdgcn_readfirstlane(minx); maxx = __builtin_amdgcn_readfirstlane(maxx);
-    miny = __builtin_amdgcn_readfirstlane(miny); maxy = __builtin_amdgcn_readfirstlane(maxy);
-    if (maxx < minx || maxy < miny) return;                      // nothing of this tile lands inside the image
-    const int ntx = maxx - minx + 1, nt = ntx * (maxy - miny + 1);
-    if (nt > kSpRouteMax) { if (tid == 0) atomicOr(p.overflow, 1); return; }
-    // local rank of every (pixel, destination tile) pair: LDS atomics; packed (local tile << 12 | rank), ~0 = none
-    uint32_t pr[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int tc = (j & 1) ? tcb[k] : tca[k], tr = (j & 2) ? trb[k] : tra[k];
-            pr[k][j] = 0xffffffffu;
-            if (tc >= 0 && tr >= 0) {
-                const int lt = (tr - miny) * ntx + (tc - minx);
-                pr[k][j] = ((uint32_t)lt << 12) | (uint32_t)atomicAdd(&lcount[lt], 1);
-            }
-        }
+    lo = row_pk_min_dpp(lo); hi = row_pk_max_dpp(hi);                    // over the subtile (16 lanes)
+    const int minx = (int)(short)(lo & 0xffff), miny = lo >> 16, maxx = (int)(short)(hi & 0xffff), maxy = hi >> 16;
+    const bool any = maxx >= minx && maxy >= miny;                       // something of this subtile lands inside the image
+    // destination tiles of the subtile (as packed 16-bit pairs, for the block-wide union)
+    const int tlo = any ? (int)((uint32_t)(minx / kSpTW) | ((uint32_t)(miny / kSpTH) << 16)) : 0x7fff7fff;
+    const int thi = any ? (int)((uint32_t)(maxx / kSpTW) | ((uint32_t)(maxy / kSpTH) << 16)) : (int)0xffffffffu;
+    {
+        const int a = pk_min16(pk_min16(__builtin_amdgcn_readlane(tlo, 0), __builtin_amdgcn_readlane(tlo, 16)),
+                               pk_min16(__builtin_amdgcn_readlane(tlo, 32), __builtin_amdgcn_readlane(tlo, 48)));
+        const int b = pk_max16(pk_max16(__builtin_amdgcn_readlane(thi, 0), __builtin_amdgcn_readlane(thi, 16)),
+                               pk_max16(__builtin_amdgcn_readlane(thi, 32), __builtin_amdgcn_readlane(thi, 48)));
+        if (lane == 0) { red[wave][0] = a; red[wave][1] = b; }
     }
     __syncthreads();
-    if (tid < nt && lcount[tid]) {
-        const int d = n * (int)p.tiles_img + (miny + tid / ntx) * p.tiles_x + (minx + tid % ntx);
-        const int cnt = lcount[tid];
-        const int start = atomicAdd(&p.cursor[d], cnt);          // this block's records are start .. start + cnt - 1 of the queue
-        // Records beyond the primary region go to the block of their slot of kSpPrim queue positions.  Exactly ONE block is
-        // drawn per slot, whoever comes first: the first arrival swaps the slot's entry from -1 (none) to -2 (being
-        // drawn), draws and publishes; everybody else waits for the published id.  (Drawing first and swapping after
-        // would leak a block per lost race -- and make running out of blocks, hence the choice of path and the last bits
-        // of the result, depend on timing.)  All of a wave's draws are published before any of its lanes waits, and a wait
-        // is always for a wave that is already past its own draws: no cycle.
-        int b0 = -1, b1 = -1, s0 = 0, s1 = 0;
-        const bool need = start + cnt > kSpPrim && start + cnt <= (1 + kSpSlots) * kSpPrim;
-        if (start + cnt > (1 + kSpSlots) * kSpPrim) atomicOr(p.overflow, 1);
-        if (need) {
-            s0 = (max(start, kSpPrim) - kSpPrim) / kSpPrim;
-            s1 = (start + cnt - 1 - kSpPrim) / kSpPrim;                      // (cnt <= 512: at most two slots)
-            // (the entry's value is all that is communicated: relaxed accesses served by L2 are enough)
-            for (int slot = s0; slot <= s1; ++slot) {
-                int32_t* e = &p.sec[(int64_t)d * kSpSlots + slot];
-                int cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur == -1 && atomicCAS(e, -1, -2) == -1) {
-                    const int mine = atomicAdd(p.sec_count, 1);
-                    if (mine >= p.nsec) atomicOr(p.overflow, 1);
-                    cur = mine < p.nsec ? mine : -3;                         // (-3: none left)
-                    __hip_atomic_store(e, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (slot == s0) b0 = cur; else b1 = cur;
-            }
-            if (s1 == s0) b1 = b0;
-        }
-        __builtin_amdgcn_wave_barrier();                                     // (the waits stay behind the draws)
-        if (need) {
-            while (b0 == -1 || b0 == -2) b0 = __hip_atomic_load(&p.sec[(int64_t)d * kSpSlots + s0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (s1 == s0) b1 = b0;
-            while (b1 == -1 || b1 == -2) b1 = __hip_atomic_load(&p.sec[(int64_t)d * kSpSlots + s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        lbase[tid] = start; lsec[tid] = b0; lsec1[tid] = b1; lslot[tid] = s0; ltile[tid] = d;
+    int blo = red[0][0], bhi = red[0][1];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) { blo = pk_min16(blo, red[i][0]); bhi = pk_max16(bhi, red[i][1]); }
+    const int btx0 = (int)(short)(blo & 0xffff), bty0 = blo >> 16, btx1 = (int)(short)(bhi & 0xffff), bty1 = bhi >> 16;
+    if (btx1 < btx0 || bty1 < bty0) return;                              // nothing of this region lands inside the image (block-uniform)
+    const int bntx = btx1 - btx0 + 1, bnt = bntx * (bty1 - bty0 + 1);
+    const bool local = bnt <= kBinLocal;                                 // block-uniform
+    const int tx0 = minx / kSpTW, tx1 = maxx / kSpTW, ty0 = miny / kSpTH, ty1 = maxy / kSpTH;
+    const int ntx = tx1 - tx0 + 1, cnt = any ? ntx * (ty1 - ty0 + 1) : 0;
+    const uint32_t subid = (uint32_t)((ry * 4 + wave) * p.subs_x + rx * 4 + sub);
+    if (cnt > kBinSpread) {                                              // a subtile torn over the whole frame: two-pass path
+        if ((lane & 15) == 0) atomicOr(&p.img_over[n], 1);
     }
-    __syncthreads();
-    // the records carry the pixel's data (x data_sign) and mask channel: the tile kernel reads everything coalesced
-    const int nc = s.c;
-    f4 dat[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    uint32_t mc4 = 0x01010101u;
-    if (inimg) {
-        const int wrem = w & 3;
-        const bool edge = wrem != 0 && sx4 > w - 4;                   // row-end group: last whole group, rotated
-        const uint32_t pix = (uint32_t)(sy * w + sx4) - (edge ? (uint32_t)(4 - wrem) : 0u);
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            if (c < nc) {
-                dat[c] = ld4(s.data + n * s.data_bs + c * hw + pix);
-                if (s.data_b) dat[c] = dat[c] - ld4(s.data_b + n * s.data_b_bs + c * hw + pix);
-            }
-        uint32_t ma = 0x01010101u, mb = 0x01010101u;
-        if (s.with_mask_chan) {
-            if (s.chan_mask_a) ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + pix);
-            if (s.chan_mask_b) mb = ld32(s.chan_mask_b + n * s.chan_mask_b_bs + pix);
-        }
-        if (wrem != 0) {
-            if (edge) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dat[c] = rot4(dat[c], 4 - wrem);
-                ma >>= 8 * (4 - wrem); mb >>= 8 * (4 - wrem);
-            }
-        }
-        mc4 = nz_bytes(ma) & nz_bytes(mb);
+    const int j0 = lane & 15;
+    // the common case: at most 16 destination tiles per subtile (one per lane), all inside the region's local grid -- ranks
+    // from LDS atomics, then ONE global atomic per (source region, destination tile) instead of one per (subtile, tile):
+    // device-scope atomics go all the way to memory and cost ~1 us each
+    int lt = -1, rank = 0;
+    const bool fast = local && cnt <= 16;
+    if (fast && j0 < cnt) {
+        const int jy = j0 / ntx;
+        lt = (ty0 + jy - bty0) * bntx + (tx0 + (j0 - jy * ntx) - btx0);
+        rank = atomicAdd(&lcount[lt], 1);
     }
-    const int ncol = 3 + nc;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (pr[k][j] != 0xffffffffu) {
-                const int lt = (int)(pr[k][j] >> 12), idx = lbase[lt] + (int)(pr[k][j] & 0xfffu);
-                float* rp; int cs;                               // column a of this record: rp[a * cs]
-                if (idx < kSpPrim) {
-                    rp = p.prim + ((int64_t)ltile[lt] * ncol) * kSpPrim + idx; cs = kSpPrim;
-                } else {
-                    const int o = idx - kSpPrim, sb = (o / kSpPrim == lslot[lt]) ? lsec[lt] : lsec1[lt];
-                    if (sb < 0) continue;                                 // (the launch is flagged: the two-pass path redoes it)
-                    rp = p.secp + ((int64_t)sb * ncol) * kSpPrim + (o % kSpPrim); cs = kSpPrim;
-                }
-                rp[0] = q.x[k]; rp[cs] = q.y[k];
-                // key: raster position of the source pixel (15 bits each, checked by ofl_splat_tiled_f32) with the mask-channel bit below it --
-                // two records never share a position, so ordering by the whole word is raster order
-                rp[2 * cs] = __uint_as_float(((((uint32_t)sy << 15) | (uint32_t)(sx4 + k)) << 1) | ((mc4 >> (8 * k)) & 1u));
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (c < nc) rp[(3 + c) * cs] = s.data_sign * dat[c][k];
-            }
+    if (local) {
+        __syncthreads();
+        if (tid < bnt && lcount[tid] > 0) {
+            const int ly_ = tid / bntx;
+            const int64_t d = (int64_t)n * p.tiles_img + (bty0 + ly_) * p.tiles_x + btx0 + (tid - ly_ * bntx);
+            const int start = atomicAdd(&p.cnt[d], lcount[tid]);
+            lbase[tid] = start;
+            if (start + lcount[tid] > kBinCap) atomicOr(&p.img_over[n], 1);
+        }
+        __syncthreads();
+        if (lt >= 0) {
+            const int ly_ = lt / bntx;
+            const int64_t d = (int64_t)n * p.tiles_img + (bty0 + ly_) * p.tiles_x + btx0 + (lt - ly_ * bntx);
+            const int pos = lbase[lt] + rank;
+            if (pos < kBinCap) p.list[d * kBinCap + pos] = subid;
+        }
+    }
+    if (!fast && cnt <= kBinSpread) {                                    // wide spreads: straight to the global counters
+        for (int j = j0; j < cnt; j += 16) {
+            const int jy = j / ntx;
+            const int64_t d = (int64_t)n * p.tiles_img + (ty0 + jy) * p.tiles_x + tx0 + (j - jy * ntx);
+            const int pos = atomicAdd(&p.cnt[d], 1);
+            if (pos < kBinCap) p.list[d * kBinCap + pos] = subid;
+            else atomicOr(&p.img_over[n], 1);
         }
     }
 }
@@ -1200,139 +1152,153 @@ __device__ __forceinline__ void sp_corners(float xv, float yv, float wmax, float
 }
 
 #ifndef OFL_SP_MINB
-#define OFL_SP_MINB 4   // blocks per CU the tile kernel's register budget is sized for (LDS allows 4; measured +9 % over 3)
+#define OFL_SP_MINB 4   // blocks per CU the gather kernel's register budget is sized for (what its 39.7 KB of LDS allow)
 #endif
+#ifndef OFL_SP_U
+#define OFL_SP_U 1      // list entries (subtiles) per thread and step of the gather kernel's walk
+#endif
+constexpr int kSpU = OFL_SP_U;
+// A RECORD is 32 bytes of LDS: the four corner weights w[ky][kx] = wy[ky] * wx[kx] of its end point -- wx = (x1 - x, x - x0),
+// wy alike, each product formed once, exactly as the reference's outer product (utils.py:1110-1114; a corner that a
+// destination pixel of the image reads is never clamped, so the `eq` factor is 1) -- then up to 3 data values and the key
+// (raster position of the source pixel, mask-channel bit below it).  Two ds_read_b128 bring a record.
+//
 // One record of the cell whose column is DC (-1, 0, +1) cells from the pair's middle cell and whose row serves corner
 // row KY, added to the sums of the destination pixels that read it: pixel 0 of the pair as its x-corner 1 (DC = -1) or
-// 0 (DC = 0), pixel 1 as its x-corner 1 (DC = 0) or 0 (DC = +1).  The corner is not clamped (the destination is inside
-// the image), so the reference's weight is (x1 - x | x - x0) * 1 (utils.py:1110-1114); product rounded, then added.
+// 0 (DC = 0), pixel 1 as its x-corner 1 (DC = 0) or 0 (DC = +1).  Product rounded, then added.
 template <int NC, int NCH, int DC, int KY>
-__device__ __forceinline__ void sp_use(const float* rec, uint32_t i, float (&a)[2][2][1 + NCH]) {
-    const float xv = rec[i], yv = rec[kSpQ + i];
-    const float x0 = floorf(xv), y0 = floorf(yv);
-    const float wyk = (KY ? yv - y0 : (y0 + 1.0f) - yv) * 1.0f;
+__device__ __forceinline__ void sp_use(const f4* rec4, uint32_t i, float (&a)[2][2][1 + NCH]) {
+    const f4 wv = rec4[2 * i], dv = rec4[2 * i + 1];
     float d[NCH];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) d[c] = rec[(3 + c) * kSpQ + i];
-    if (NCH > NC) d[NC] = (float)(__float_as_uint(rec[2 * kSpQ + i]) & 1u);   // the mask channel rides in the key
+    for (int c = 0; c < NC; ++c) d[c] = dv[c];
+    if (NCH > NC) d[NC] = (float)(__float_as_uint(dv[3]) & 1u);          // the mask channel rides in the key
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int kx = k - DC;                     // pixel k sits DC .. DC + 1 columns right of the cell: x-corner k - DC
         if (kx < 0 || kx > 1) continue;
-        const float wxk = (kx ? xv - x0 : (x0 + 1.0f) - xv) * 1.0f;
-        const float wgt = wyk * wxk;
+        const float wgt = wv[KY * 2 + kx];
         a[k][kx][0] += wgt;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) a[k][kx][1 + c] += wgt * d[c];
     }
 }
 
-template <int NC, bool MCH>
-__global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const TiledParams p) {
-    constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0), NREC = 3 + NC, kRounds = kSpQ / kSpNT2;
-    constexpr uint32_t kEnd = 0xffffu, kLongCell = 0xfffeu;
-    // A CELL is a unit square of the destination grid: the records whose end point has floor(x, y) = (cx, cy).  The four
-    // corner classes of a destination pixel (X, Y) are the cells (X - kx, Y - ky), so one list per cell serves them all:
-    // (kSpTW + 1) x (kSpTH + 1) cells per tile, the first column / row being the cells left of / above the tile.
-    constexpr int kCW = kSpTW + 1, kCH = kSpTH + 1, kCells = kCW * kCH, kCellsP = (kCells + 63) / 64 * 64;
-    constexpr int kCellRounds = (kCellsP + kSpNT2 - 1) / kSpNT2;
-    // LDS: records [x | y | key + mask-channel bit | data ...][kSpQ] | cell list heads | sorted cell slots | list links
-    // (the float-atomics fallback re-uses the record area as accumulator planes)
-    __shared__ __attribute__((aligned(16))) unsigned char raw[kSpQ * 4 * NREC + kCellsP * 4 + kCellsP * 8 + kSpQ * 2];
-    __shared__ int qcount;
-    static_assert(kSpQ * NREC >= (1 + NCH) * kPx, "fallback planes must fit the record area");
-    float* rec = reinterpret_cast<float*>(raw);                       // rec[a * kSpQ + i]
-    const float* rx = rec; const float* ry = rec + kSpQ;
-    const uint32_t* rkey = reinterpret_cast<const uint32_t*>(rec + 2 * kSpQ);
-    uint32_t* head = reinterpret_cast<uint32_t*>(rec + NREC * kSpQ);  // [kCellsP]: newest record of the cell, kEnd = empty
-    uint2* slots = reinterpret_cast<uint2*>(head + kCellsP);          // [kCellsP]: up to 4 records in raster order, 16 bits each
-    uint16_t* link = reinterpret_cast<uint16_t*>(slots + kCellsP);    // [kSpQ]: next record of the same cell
-    float* acc = rec;                                                 // fallback: [1 + NCH][kPx]
-    int tx, ty, n;
-    if (!sp_decode(p, tx, ty, n)) return;
-    const SplatParams& s = p.s;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = s.w, h = s.h;
+// exchange with the neighbouring lane (lanes 2j <-> 2j + 1): the pair's partner owns the other half of a 4-pixel group
+__device__ __forceinline__ float swap1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); }
+__device__ __forceinline__ uint32_t swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }
+
+// what a thread of a destination tile knows about its 2 output pixels (gather kernel and per-tile fallback kernel)
+struct SpTile {
+    int n, dx0, dy0, lx2, ly;
+    uint32_t pix;            // offset of the pair in a plane
+    bool solo, inimg, wide;  // solo: the tile is one pixel wide here; wide: a whole tile (lane pairs store 4 pixels at a time)
+    bool fill_ok[2];         // un-occlude fill candidates (utils.py:1198-1203)
+};
+
+template <typename SP>
+__device__ __forceinline__ void sp_tile_setup(const SP& s, int tx, int ty, int n, SpTile& t) {
+    const int tid = threadIdx.x, w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
-    const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
-    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
-    const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
-    const int launch_over = *p.overflow, qlen = p.cursor[dtile];
-    if (launch_over != 0) return;                                     // this launch takes the global-atomics path instead
-    const float* __restrict__ gq = p.prim + (dtile * NREC) * kSpPrim;  // column a of the primary region: gq[a * kSpPrim + i], 16-byte aligned
-    // queue positions kSpPrim .. of a long queue live in blocks of kSpPrim records (one more round trip, long queues only)
-    __shared__ int qblk[kSpSlots];
-    if (qlen > kSpPrim) {
-        if (tid < kSpSlots) qblk[tid] = p.sec[dtile * kSpSlots + tid];
-        __syncthreads();
-    }
-    // record i of the queue, column a
-    auto qrec = [&](int a, int i) -> float {
-        if (i < kSpPrim) return gq[a * kSpPrim + i];
-        const int o = i - kSpPrim;
-        return p.secp[((int64_t)qblk[o / kSpPrim] * NREC + a) * kSpPrim + (o % kSpPrim)];
-    };
-    const float* __restrict__ db = s.data + n * s.data_bs;
-    const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
-    const uint8_t* __restrict__ cma = s.chan_mask_a ? s.chan_mask_a + n * s.chan_mask_a_bs : nullptr;
-    const uint8_t* __restrict__ cmb = s.chan_mask_b ? s.chan_mask_b + n * s.chan_mask_b_bs : nullptr;
-    // this thread's 2 destination pixels
-    const int lx = tid & 15, ly = tid >> 4;
-    const int x2 = min(dx0 + lx * 2, w - 2), y = dy0 + ly;           // (odd widths: the last pair re-computes pixel w - 2)
-    const int lx2 = x2 - dx0;                                        // tile-local column of the pair (may be lx * 2 - 1)
-    const bool solo = lx2 < 0;                                       // a tile that is one pixel wide: only the pair's second pixel is its own
-    const bool inimg = (dx0 + lx * 2 < w) && (y < h);
-    const uint32_t pix = (uint32_t)(min(y, h - 1) * w + x2);
-    bool fill_ok[2] = {false, false};                    // un-occlude fill candidates (utils.py:1198-1203)
-    if (s.occlude && s.flow && inimg) {
-        const f2 a = ld2(s.flow + n * s.flow_bs + pix), b = ld2(s.flow + n * s.flow_bs + hw + pix);
+    t.n = n; t.dx0 = tx * kSpTW; t.dy0 = ty * kSpTH;
+    const int lx = tid & 15;
+    t.ly = tid >> 4;
+    const int x2 = min(t.dx0 + lx * 2, w - 2), y = t.dy0 + t.ly;     // (odd widths: the last pair re-computes pixel w - 2)
+    t.lx2 = x2 - t.dx0;                                              // tile-local column of the pair (may be lx * 2 - 1)
+    t.solo = t.lx2 < 0;
+    t.inimg = (t.dx0 + lx * 2 < w) && (y < h);
+    t.pix = (uint32_t)(min(y, h - 1) * w + x2);
+    t.wide = t.dx0 + kSpTW <= w;
+    t.fill_ok[0] = t.fill_ok[1] = false;
+    if (s.occlude && s.flow && t.inimg) {
+        const f2 a = ld2(s.flow + n * s.flow_bs + t.pix), b = ld2(s.flow + n * s.flow_bs + hw + t.pix);
         uint32_t wm2 = 0x0101u;
-        if (s.weight_mask) wm2 = ld16(s.weight_mask + n * s.weight_mask_bs + pix);
+        if (s.weight_mask) wm2 = ld16(s.weight_mask + n * s.weight_mask_bs + t.pix);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            fill_ok[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr) && (((wm2 >> (8 * k)) & 0xffu) != 0u);
+            t.fill_ok[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr) && (((wm2 >> (8 * k)) & 0xffu) != 0u);
     }
-    int dflags = 0;
-    auto flush_flags = [&]() {                            // (every thread of the block gets here)
-        if (NC == 2 && s.dst_flags) {
-            dflags = wave_or_flags(dflags);
-            if (lane == 0) flag_or(&s.dst_flags[n], dflags);
-        }
-    };
-    // normalise, masks, un-occlude fill, store (tot: density, channels, mask channel)
-    auto finalize = [&](const float (&tot)[2][1 + NCH]) {
-        f2 den2, out[NC], mch2;
-        uint32_t warped2 = 0, valid2 = 0;
+}
+
+// normalise, masks, un-occlude fill, store (tot: density, channels, mask channel).  EVERY thread of the block calls it
+// (`mine`: this thread's row is being finalized), so that lane pairs can exchange their halves.
+template <int NC, bool MCH, typename SP>
+__device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const float (&tot)[2][1 + NC + (MCH ? 1 : 0)], bool mine, int& dflags) {
+    const int n = t.n, tid = threadIdx.x;
+    const uint32_t hw = (uint32_t)(s.h * s.w);
+    // the pixel offset is made opaque HERE: otherwise every per-lane output address (64 bits each, a dozen of them) is
+    // computed once before the band loop, lives across the whole kernel and is spilled to scratch -- 16 scratch stores per
+    // thread and tile, 2 GB of scratch writes per launch (rocprofv3 WRITE_SIZE: profiles/r2_splat_gather_first_cut_pmc.txt)
+    uint32_t pix = t.pix;
+    asm volatile("" : "+v"(pix));
+    const float* __restrict__ db = s.data + n * s.data_bs;
+    const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
+    f2 den2, out[NC], mch2;
+    uint32_t warped2 = 0, valid2 = 0;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float den = tot[k][0];
-            const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
-            const bool warped = den > 0.0f;                            // utils.py:1197
-            const bool fill = fill_ok[k] && !warped;
-            den2[k] = den;
-            warped2 |= (uint32_t)warped << (8 * k);
+    for (int k = 0; k < 2; ++k) {
+        const float den = tot[k][0];
+        const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
+        const bool warped = den > 0.0f;                            // utils.py:1197
+        const bool fill = t.fill_ok[k] && !warped && mine;
+        den2[k] = den;
+        warped2 |= (uint32_t)warped << (8 * k);
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                out[c][k] = apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? db[c * hw + pix + k] - dbb[c * hw + pix + k] : db[c * hw + pix + k]) : tot[k][1 + c] / dcl, s.round_mode);
-            if (MCH) {
-                float mv;
-                if (fill) {
-                    const bool a = cma ? cma[pix + k] != 0 : true, b = cmb ? cmb[pix + k] != 0 : true;
-                    mv = (a && b) ? 1.0f : 0.0f;
-                } else {
-                    mv = tot[k][1 + NC] / dcl;
-                }
-                mch2[k] = mv;
-                valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
+        for (int c = 0; c < NC; ++c)
+            out[c][k] = apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? db[c * hw + pix + k] - dbb[c * hw + pix + k] : db[c * hw + pix + k]) : tot[k][1 + c] / dcl, s.round_mode);
+        if (MCH) {
+            float mv;
+            if (fill) {
+                const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix + k] != 0 : true;
+                const bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix + k] != 0 : true;
+                mv = (a && b) ? 1.0f : 0.0f;
+            } else {
+                mv = tot[k][1 + NC] / dcl;
             }
+            mch2[k] = mv;
+            valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
         }
-        if (NC == 2 && s.dst_flags) {                     // the output read as a flow under its valid mask (by-product)
+    }
+    if (mine && NC == 2 && s.dst_flags) {             // the output read as a flow under its valid mask (by-product)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-                if (k == 1 || !solo) dflags |= flag_bits(out[0][k], out[NC - 1][k], MCH ? ((valid2 >> (8 * k)) & 1u) != 0u : true);
+        for (int k = 0; k < 2; ++k)
+            if (k == 1 || !t.solo) dflags |= flag_bits(out[0][k], out[NC - 1][k], MCH ? ((valid2 >> (8 * k)) & 1u) != 0u : true);
+    }
+    float* __restrict__ dst = s.dst + (int64_t)n * s.dst_bs;
+    if (t.wide) {
+        // lanes 2j / 2j + 1 own pixels 4j .. 4j + 1 / 4j + 2 .. 4j + 3 of one row: the even lane stores the even planes of
+        // the 4-pixel group, the odd lane the odd ones -- 16 bytes per lane instead of 8 (partial-line stores are the
+        // expensive ones on this memory system)
+        const bool odd = (tid & 1) != 0;
+        const uint32_t pq = pix - (odd ? 2u : 0u);               // first pixel of the group
+        // plane A goes out through the even lane, plane B through the odd one; each gets the partner's half by DPP
+        auto emit = [&](const f2& pa, float* ptra, bool a_on, const f2& pb, float* ptrb, bool b_on) {
+            const f2 give = odd ? pa : pb, keep = odd ? pb : pa;
+            const f2 got = {swap1(give[0]), swap1(give[1])};
+            const f4 v = odd ? (f4){got[0], got[1], keep[0], keep[1]} : (f4){keep[0], keep[1], got[0], got[1]};
+            if (mine && (odd ? b_on : a_on)) st4((odd ? ptrb : ptra) + pq, v);
+        };
+        float* dpl = s.density ? s.density + (int64_t)n * hw : nullptr;
+        float* mpl = (MCH && s.mask_chan) ? s.mask_chan + (int64_t)n * hw : nullptr;
+        if (NC == 1) {
+            emit(out[0], dst, true, den2, dpl, dpl != nullptr);
+            if (MCH && s.mask_chan) emit(mch2, mpl, true, mch2, mpl, false);          // (block-uniform)
+        } else if (NC == 2) {
+            emit(out[0], dst, true, out[NC - 1], dst + hw, true);
+            if (dpl || mpl) emit(den2, dpl, dpl != nullptr, mch2, mpl, mpl != nullptr);
+        } else {
+            emit(out[0], dst, true, out[1 % NC], dst + hw, true);
+            emit(out[2 % NC], dst + 2 * hw, true, den2, dpl, dpl != nullptr);
+            if (MCH && s.mask_chan) emit(mch2, mpl, true, mch2, mpl, false);
         }
-        float* __restrict__ dst = s.dst + (int64_t)n * s.dst_bs;
-        if (!solo) {
+        const uint32_t pw = swap1(warped2), pv = swap1(valid2);      // (every lane takes part: no DPP under divergence)
+        const uint32_t w4 = warped2 | (pw << 16), v4 = valid2 | (pv << 16);
+        if (mine && !odd) {
+            if (s.warped) st32(s.warped + (int64_t)n * hw + pq, w4);
+            if (MCH && s.valid) st32(s.valid + (int64_t)n * hw + pq, v4);
+        }
+    } else if (mine) {
+        if (!t.solo) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) st2(dst + c * hw + pix, out[c]);
             if (s.density) st2(s.density + (int64_t)n * hw + pix, den2);
@@ -1347,237 +1313,472 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_tile_kernel(const T
             if (MCH && s.valid) s.valid[(int64_t)n * hw + pix + 1] = (uint8_t)(valid2 >> 8);
             if (MCH && s.mask_chan) s.mask_chan[(int64_t)n * hw + pix + 1] = mch2[1];
         }
-    };
-    // bands of destination rows: 1 when the whole queue fits the LDS records
-    int nb = 1;
-    if (qlen > kSpQ) {                                    // a band of r rows sees about (r + 1) / 16 of the records
-        nb = 2;
-        if (qlen * (kSpTH / 2 + 1) > (kSpQ - kSpQ / 8) * kSpTH) nb = 4;
-        if (qlen * (kSpTH / 4 + 1) > (kSpQ - kSpQ / 8) * kSpTH) nb = 0;   // a fold: straight to the float atomics
     }
-    const int rows = nb ? kSpTH / nb : kSpTH;
-    bool over = nb == 0;
-    for (int band = 0; band < nb; ++band) {
-        const int r0 = band * rows, r1 = r0 + rows;
+}
+
+// data (x data_sign applied later) and mask-channel bits of one 4-pixel group of a source subtile
+template <int NC, bool MCH, typename SP>
+__device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy, uint32_t hw, f4 (&dat)[NC], uint32_t& mc4) {
+    const int w = s.w;
+    const float* __restrict__ db = s.data + n * s.data_bs;
+    const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
+    const int wrem = w & 3;
+    const bool edge = wrem != 0 && sx4 > w - 4;                   // row-end group: last whole group, rotated
+    const uint32_t px = (uint32_t)(sy * w + sx4) - (edge ? (uint32_t)(4 - wrem) : 0u);
 #pragma unroll
-        for (int i = 0; i < kCellRounds; ++i)
-            if (tid + i * kSpNT2 < kCellsP) head[tid + i * kSpNT2] = kEnd;
-        int nrec = qlen;
-        if (nb == 1) {
-            // ---- A (whole queue): coalesced 16-byte copy into LDS (the queue is padded to whole groups of 4 records)
-            static_assert(kSpQ <= kSpNT2 * 4, "one 16-byte group per thread");
-            if (tid * 4 < qlen) {
+    for (int c = 0; c < NC; ++c) {
+        dat[c] = ld4(db + c * hw + px);
+        if (dbb) dat[c] = dat[c] - ld4(dbb + c * hw + px);
+    }
+    uint32_t ma = 0x01010101u, mb = 0x01010101u;
+    if (MCH) {
+        if (s.chan_mask_a) ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + px);
+        if (s.chan_mask_b) mb = ld32(s.chan_mask_b + n * s.chan_mask_b_bs + px);
+    }
+    if (wrem != 0) {
+        if (edge) {
 #pragma unroll
-                for (int a = 0; a < NREC; ++a)
-                    *reinterpret_cast<f4*>(rec + a * kSpQ + tid * 4) = *reinterpret_cast<const f4*>(gq + a * kSpPrim + tid * 4);
+            for (int c = 0; c < NC; ++c) dat[c] = rot4(dat[c], 4 - wrem);
+            ma >>= 8 * (4 - wrem); mb >>= 8 * (4 - wrem);
+        }
+    }
+    mc4 = nz_bytes(ma) & nz_bytes(mb);
+}
+
+// The gather kernel reads its ~400 bytes of parameters from the KERNARG SEGMENT through a pointer that is made opaque at
+// every phase boundary (OFL_OPAQUE_S): the compiler then fetches what a phase needs with scalar loads where it needs it.
+// Left to itself it loads all ~100 dwords at the top, cannot keep them in the 102 SGPRs, spills them to VGPR lanes and
+// re-reads them 16 lanes at a time: 1 000 of the 1 300 VALU instructions a wave executed per tile were v_readlane /
+// v_writelane (rocprofv3 SQ_INSTS_VALU with and without the sort / sum phases: profiles/r2_splat_gather_sq_*.txt).
+typedef const GatherParams __attribute__((address_space(4))) GatherParamsK;
+#define OFL_OPAQUE_S(ptr_) asm volatile("" : "+s"(ptr_))
+
+template <int NC, bool MCH>
+__global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const GatherParams p_by_value_unused) {
+    GatherParamsK* pp = (GatherParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*pp)
+    constexpr int NCH = NC + (MCH ? 1 : 0);
+    constexpr uint32_t kEnd = 0xffffu, kLongCell = 0xfffeu;
+    // A CELL is a unit square of the destination grid: the records whose end point has floor(x, y) = (cx, cy).  The four
+    // corner classes of a destination pixel (X, Y) are the cells (X - kx, Y - ky), so one list per cell serves them all:
+    // (kSpTW + 1) x (kSpTH + 1) cells per tile, the first column / row being the cells left of / above the tile.
+    constexpr int kCW = kSpTW + 1, kCH = kSpTH + 1, kCells = kCW * kCH, kCellsP = (kCells + 63) / 64 * 64;
+    constexpr int kCellRounds = (kCellsP + kSpNT2 - 1) / kSpNT2;
+    // LDS: records (32 bytes each) | records per cell | the first 4 records of every cell, 16 bits each | head of the chain
+    // of a cell's 5th, 6th ... record (later: of its sorted list) | chain links
+    __shared__ __attribute__((aligned(16))) unsigned char raw[kSpQ * 32 + kCellsP * 4 + kCellsP * 8 + kCellsP * 4 + kSpQ * 2];
+    __shared__ int qcount;
+    f4* rec4 = reinterpret_cast<f4*>(raw);                            // rec4[2 * i] weights, rec4[2 * i + 1] data | key
+    const uint32_t* rwords = reinterpret_cast<const uint32_t*>(raw);  // key of record i: rwords[8 * i + 7]
+    uint32_t* ccnt = reinterpret_cast<uint32_t*>(raw + kSpQ * 32);    // [kCellsP]: records of the cell
+    uint2* slots = reinterpret_cast<uint2*>(ccnt + kCellsP);          // [kCellsP]: records 0 .. 3 of the cell (kEnd: none), raster order after phase S
+    uint32_t* ohead = reinterpret_cast<uint32_t*>(slots + kCellsP);   // [kCellsP]: chain of the records beyond four / sorted list of a long cell
+    uint16_t* link = reinterpret_cast<uint16_t*>(ohead + kCellsP);    // [kSpQ]: next record of the chain
+#define s (pp->s)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    constexpr int kHalf = kSpNT2 / 16, kStep = 2 * kHalf;             // subtiles per half step (one per DPP row of lanes) / per step
+    int tx, ty, n;
+    if (!decode3(p.total, p.per_xcd, p.tiles_img, p.mi_m, p.mi_s, p.mx_m, p.mx_s, p.tiles_x, tx, ty, n)) return;
+    if (p.img_over[n] != 0) return;                                   // this image takes the global-atomics path instead
+    const uint32_t tile = (uint32_t)(n * (int)p.tiles_img + ty * p.tiles_x + tx);
+    const uint32_t* __restrict__ lst = p.list + (int64_t)tile * kBinCap;
+    // the first 32 entries of the list are fetched WITH its length (the list has a fixed address and kBinCap slots: entries
+    // past the length are stale ids that are never used): one round trip for the list, one for the end points, one for the data
+    const uint32_t pre[2] = {lst[tid >> 4], lst[kHalf + (tid >> 4)]};
+    const int nlist = min(p.cnt[tile], kBinCap);
+    OFL_OPAQUE_S(pp);
+    SpTile t;
+    sp_tile_setup(s, tx, ty, n, t);
+    const int dx0 = t.dx0, dy0 = t.dy0, ly = t.ly, lx2 = t.lx2;
+    int dflags = 0;
+    const int sl = tid & 15, srow = sl >> 2, sc4 = sl & 3;
+    // ---- A: walk the tile's list, 32 subtiles per step (4 source pixels per lane and half step), in three waves of loads:
+    // list -> flow + weight mask of both halves -> data of the 4-pixel groups that have a pixel in the tile.  The pixels
+    // whose cell lies in the tile (cell rows r0 .. r1) become LDS records and join their cell; qcount ends up as the number
+    // of records wanted (more than kSpQ: not all were kept).
+    // one half step: the hit test of a lane's 4 source pixels, ranks by ballot + popcount, records and cells in LDS
+    auto process = [&](const SpSrc& q, int sx4, int sy, const f4 (&dat)[NC], uint32_t mc4, int r0, int r1) {
+        int cell[4];
+        unsigned long long m[4];
+        int wtot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, (float)w) - dx0 + 1;
+            const int cy = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, (float)h) - dy0 + 1;
+            const bool hit = ((q.on >> k) & 1u) != 0u && (uint32_t)cx < (uint32_t)kCW && cy >= r0 && cy <= r1;
+            cell[k] = hit ? cy * kCW + cx : -1;
+            m[k] = __ballot(hit);
+            wtot += __popcll(m[k]);
+        }
+        if (wtot != 0) {                                   // wave-uniform
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&qcount, wtot);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pos = wbase + __popcll(m[k] & below);
+                wbase += __popcll(m[k]);
+#ifdef OFL_ABL_NOREC
+                if (cell[k] == -12345) {
+#else
+                if (cell[k] >= 0 && pos < kSpQ) {
+#endif
+                    const float xv = q.x[k], yv = q.y[k];
+                    const float x0 = floorf(xv), y0 = floorf(yv);
+                    const float wx0 = (x0 + 1.0f) - xv, wx1 = xv - x0, wy0 = (y0 + 1.0f) - yv, wy1 = yv - y0;   // utils.py:1110-1111
+                    rec4[2 * pos] = (f4){wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};                        // utils.py:1114
+                    // key: raster position of the source pixel (15 bits each, checked by ofl_splat_tiled_f32) with the
+                    // mask-channel bit below it -- two records never share a position, so ordering by the whole word is raster order
+                    f4 dv = {0.f, 0.f, 0.f, __uint_as_float(((((uint32_t)sy << 15) | (uint32_t)(sx4 + k)) << 1) | ((mc4 >> (8 * k)) & 1u))};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dv[c] = s.data_sign * dat[c][k];
+                    rec4[2 * pos + 1] = dv;
+                    // the cell's first four records go to its slots (arrival order), later ones on a chain
+                    const uint32_t slot = atomicAdd(&ccnt[cell[k]], 1u);
+                    if (slot < 4u) reinterpret_cast<uint16_t*>(slots)[4 * cell[k] + (int)slot] = (uint16_t)pos;
+                    else link[pos] = (uint16_t)atomicExch(&ohead[cell[k]], (uint32_t)pos);
+                }
             }
-        } else {
-            // ---- A (band): compact the records with a corner row inside the band
+        }
+    };
+    // ---- A: walk the tile's list from entry `first`, 32 subtiles per step (4 source pixels per lane and half step): list ->
+    // flow + weight mask of both halves -> data of the 4-pixel groups that have a pixel in the tile.  The pixels whose cell
+    // lies in the tile (cell rows r0 .. r1) become LDS records and join their cell; qcount ends up as the number of records
+    // wanted (more than kSpQ: not all were kept).
+    auto scan = [&](int r0, int r1, int first) {
+        OFL_OPAQUE_S(pp);
+#ifdef OFL_ABL_NOSCAN
+        for (int base = first; base < 0; base += kStep) {
+#else
+        for (int base = first; base < nlist; base += kStep) {
+#endif
+            SpSrc q[2];
+            int sx4[2], sy[2];
+#ifdef OFL_SP_EAGER_DATA
+            bool inb[2];
+#endif
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = base + u * kHalf + (tid >> 4);
+                const bool have = e < nlist;
+                const uint32_t sub = base == 0 ? pre[u] : (have ? lst[e] : 0u);
+                const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
+                sx4[u] = (int)subx * kSubW + sc4 * 4; sy[u] = (int)suby * kSubH + srow;
+                const bool in = have && (sx4[u] < w) && (sy[u] < h);
+                sp_load_src(s, n, sx4[u], sy[u], in, (uint32_t)(sy[u] * w + sx4[u]), hw, q[u]);
+#ifdef OFL_SP_EAGER_DATA
+                inb[u] = in;
+#endif
+            }
+            f4 dat[2][NC];
+            uint32_t mc4[2] = {0x01010101u, 0x01010101u};
+#ifdef OFL_SP_EAGER_DATA
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
+                if (inb[u]) sp_load_data<NC, MCH>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
+            }
+#endif
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bool anyhit = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cx = (int)__builtin_amdgcn_fmed3f(floorf(q[u].x[k]), -2.0f, (float)w) - dx0 + 1;
+                    const int cy = (int)__builtin_amdgcn_fmed3f(floorf(q[u].y[k]), -2.0f, (float)h) - dy0 + 1;
+                    anyhit |= ((q[u].on >> k) & 1u) != 0u && (uint32_t)cx < (uint32_t)kCW && cy >= r0 && cy <= r1;
+                }
+#ifndef OFL_SP_EAGER_DATA
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
+#endif
+#ifndef OFL_ABL_NODATA
+#ifdef OFL_SP_EAGER_DATA
+                (void)anyhit;
+#else
+                if (anyhit) sp_load_data<NC, MCH>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
+#endif
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) process(q[u], sx4[u], sy[u], dat[u], mc4[u], r0, r1);
+        }
+    };
+    using std::integral_constant;
+    // bands of destination rows: 1 when every record fits the LDS; decided from the number of records the whole tile wants
+    int nb = 1;
+    bool over = false;
+    for (int attempt = 0; attempt < 2 && !over; ++attempt) {
+        const int rows = kSpTH / nb;
+        bool redo = false;
+        for (int band = 0; band < nb; ++band) {
+            const int r0 = band * rows, r1 = r0 + rows;
+#pragma unroll
+            for (int i = 0; i < kCellRounds; ++i)
+                if (tid + i * kSpNT2 < kCellsP) {
+                    ccnt[tid + i * kSpNT2] = 0u; ohead[tid + i * kSpNT2] = kEnd;
+                    slots[tid + i * kSpNT2] = make_uint2(0xffffffffu, 0xffffffffu);
+                }
             if (tid == 0) qcount = 0;
             __syncthreads();
-            for (int base = 0; base < qlen; base += kSpNT2) {
-                float col[NREC];
-                const int i = base + tid;
-                bool hit = i < qlen;
-                if (hit) {
-#pragma unroll
-                    for (int a = 0; a < NREC; ++a) col[a] = qrec(a, i);
-                    const int y0 = (int)__builtin_amdgcn_fmed3f(floorf(col[1]), -2.0f, (float)h) - dy0;
-                    hit = (y0 >= r0 - 1) && (y0 < r1);
+            scan(r0, r1, 0);
+            __syncthreads();                                   // records, cells and the count are in place
+            const int nrec = qcount;
+            if (nrec > kSpQ) {                                 // block-uniform
+                if (nb == 1) {                                 // a band of r rows sees about (r + 1) / 16 of the records
+                    nb = 2;
+                    if (nrec * (kSpTH / 2 + 1) > (kSpQ - kSpQ / 8) * kSpTH) nb = 4;
+                    if (nrec * (kSpTH / 4 + 1) > (kSpQ - kSpQ / 8) * kSpTH) over = true;   // a fold: straight to the float atomics
+                    redo = !over;
+                } else {
+                    over = true;
                 }
-                const unsigned long long m = __ballot(hit);
-                if (m != 0ull) {                                 // wave-uniform
-                    int bpos = 0;
-                    if (lane == 0) bpos = atomicAdd(&qcount, __popcll(m));
-                    bpos = __builtin_amdgcn_readfirstlane(bpos);
-                    const int pos = bpos + __popcll(m & ((1ull << lane) - 1ull));
-                    if (hit && pos < kSpQ) {
-#pragma unroll
-                        for (int a = 0; a < NREC; ++a) rec[a * kSpQ + pos] = col[a];
-                    }
-                }
+                break;
             }
-            __syncthreads();
-            nrec = qcount;
-            if (nrec > kSpQ) { over = true; nrec = 0; }     // block-uniform
-        }
-        __syncthreads();                                     // records and list heads are in place
-        // ---- B: every record joins the list of its cell (cell rows r0 .. r1 serve the destination rows of the band)
+#ifdef OFL_ABL_NOSORT
+            { float t0[2][1 + NCH] = {}; sp_finalize<NC, MCH>(s, t, t0, t.inimg && ly >= r0 && ly < r1, dflags); if (nb > 1) __syncthreads(); continue; }
+#endif
+            // ---- S: every cell's records in raster order of their source pixels (ascending key) -- the order in which the
+            // reference's scatter_add_ adds them within a corner class.  One or two records need nothing (a + b = b + a, and
+            // the sums start from +0); three or four are sorted by a network in registers; a longer list (a compression or
+            // fold of the flow) becomes a chain sorted by insertion, walked by its readers.
+            bool toolong = false;
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
-            const int i = tid + r * kSpNT2;
-            if (i < nrec) {
-                const int cx = (int)__builtin_amdgcn_fmed3f(floorf(rx[i]), -2.0f, (float)w) - dx0 + 1;
-                const int cy = (int)__builtin_amdgcn_fmed3f(floorf(ry[i]), -2.0f, (float)h) - dy0 + 1;
-                if ((uint32_t)cx < (uint32_t)kCW && cy >= r0 && cy <= r1)
-                    link[i] = (uint16_t)atomicExch(&head[cy * kCW + cx], (uint32_t)i);
-            }
-        }
-        over = __syncthreads_or((int)over) != 0;
-        if (over) break;
-        // ---- S: every cell's records in raster order of their source pixels (ascending key) -- the order in which the
-        // reference's scatter_add_ adds them within a corner class.  Up to four are sorted in registers and written as
-        // one 8-byte slot group; a longer list (a compression or fold of the flow) is sorted as a list and walked by its
-        // readers.
-        bool toolong = false;
+            for (int r = 0; r < kCellRounds; ++r) {
+                const int c = tid + r * kSpNT2;
+                if (c < kCells) {
+                    const uint32_t cn = ccnt[c];
+                    if (cn > 4u) {
+                        // the four slots join the chain of the later records, then an insertion sort of the chain itself.  The
+                        // limit is on the LENGTH (the same in every run, unlike the order the atomics leave): beyond it the tile
+                        // takes the float-atomics fallback.
+                        if (cn > (uint32_t)kSpLong) {
+                            toolong = true;
+                        } else {
+                            const uint2 sl4 = slots[c];
+                            const uint32_t e4[4] = {sl4.x & 0xffffu, sl4.x >> 16, sl4.y & 0xffffu, sl4.y >> 16};
+                            uint32_t cur = ohead[c];
 #pragma unroll
-        for (int r = 0; r < kCellRounds; ++r) {
-            const int c = tid + r * kSpNT2;
-            if (c < kCells) {
-                uint32_t e[4];
-                e[0] = head[c];
-                e[1] = e[0] != kEnd ? (uint32_t)link[e[0]] : kEnd;
-                e[2] = e[1] != kEnd ? (uint32_t)link[e[1]] : kEnd;
-                e[3] = e[2] != kEnd ? (uint32_t)link[e[2]] : kEnd;
-                const uint32_t e4 = e[3] != kEnd ? (uint32_t)link[e[3]] : kEnd;
-                if (e4 != kEnd) {
-                    // a longer list: insertion sort of the linked list itself.  Records were pushed in roughly ascending
-                    // key order, so the list runs roughly descending and most nodes go straight to the front of the
-                    // sorted list.  The limit is on the LENGTH (the same in every run, unlike the order the atomics leave):
-                    // beyond it the tile takes the float-atomics fallback.
-                    int len = 5;
-                    for (uint32_t e = link[e4]; e != kEnd && len <= kSpLong; e = link[e]) ++len;
-                    if (len > kSpLong) {
-                        toolong = true;
-                    } else {
-                        uint32_t sorted = kEnd, cur = e[0];
-                        while (cur != kEnd) {
-                            const uint32_t nxt = link[cur], k = rkey[cur];
-                            if (sorted == kEnd || rkey[sorted] > k) {
-                                link[cur] = (uint16_t)sorted; sorted = cur;
-                            } else {
-                                uint32_t q = sorted, qn = link[q];
-                                while (qn != kEnd && rkey[qn] < k) { q = qn; qn = link[q]; }
-                                link[cur] = (uint16_t)qn; link[q] = (uint16_t)cur;
+                            for (int j4 = 0; j4 < 4; ++j4) { link[e4[j4]] = (uint16_t)cur; cur = e4[j4]; }
+                            uint32_t sorted = kEnd;
+                            while (cur != kEnd) {
+                                const uint32_t nxt = link[cur], k = rwords[8 * cur + 7];
+                                if (sorted == kEnd || rwords[8 * sorted + 7] > k) {
+                                    link[cur] = (uint16_t)sorted; sorted = cur;
+                                } else {
+                                    uint32_t q = sorted, qn = link[q];
+                                    while (qn != kEnd && rwords[8 * qn + 7] < k) { q = qn; qn = link[q]; }
+                                    link[cur] = (uint16_t)qn; link[q] = (uint16_t)cur;
+                                }
+                                cur = nxt;
                             }
-                            cur = nxt;
+                            ohead[c] = sorted;
+                            slots[c] = make_uint2(kLongCell | (kEnd << 16), 0xffffffffu);
                         }
-                        head[c] = sorted;
-                    }
-                    e[0] = kLongCell;
-                } else if (e[1] != kEnd) {
-                    uint32_t key[4];
+                    } else if (cn > 2u) {
+                        const uint2 sl4 = slots[c];
+                        uint32_t e[4] = {sl4.x & 0xffffu, sl4.x >> 16, sl4.y & 0xffffu, sl4.y >> 16};
+                        uint32_t key[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) key[j] = e[j] != kEnd ? rkey[e[j]] : 0xffffffffu;
+                        for (int j4 = 0; j4 < 4; ++j4) key[j4] = e[j4] != kEnd ? rwords[8 * e[j4] + 7] : 0xffffffffu;
 #define OFL_CSWAP(a_, b_) { const bool sw = key[a_] > key[b_]; const uint32_t tk = sw ? key[b_] : key[a_], te = sw ? e[b_] : e[a_]; \
                             key[b_] = sw ? key[a_] : key[b_]; e[b_] = sw ? e[a_] : e[b_]; key[a_] = tk; e[a_] = te; }
-                    OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
+                        OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
 #undef OFL_CSWAP
+                        slots[c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+                    }
                 }
-                slots[c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
             }
-        }
-        over = __syncthreads_or((int)toolong) != 0;
-        if (over) break;
-        // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.
-        // The pair reads 3 x 2 cells; every record of a cell is fetched once and added to each corner-class sum it
-        // belongs to (sp_use).
-        const bool mine = inimg && ly >= r0 && ly < r1;
-        float tot[2][1 + NCH];
-        if (mine) {
-            float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
-            auto clear = [&]() {
+            over = __syncthreads_or((int)toolong) != 0;
+            if (over) break;
+            // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.
+            // The pair reads 3 x 2 cells; every record of a cell is fetched once and added to each corner-class sum it
+            // belongs to (sp_use).
+            const bool mine = t.inimg && ly >= r0 && ly < r1;
+            float tot[2][1 + NCH];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
+#ifdef OFL_ABL_NOC
+            if (false) {
+#else
+            if (mine) {
+#endif
+                float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
+                auto clear = [&]() {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+                            for (int c = 0; c < 1 + NCH; ++c) a[k][kx][c] = 0.0f;
+                };
+                const int cm = max(lx2 + 1, 0);                            // cell column of pixel 1's x-corner 1 = of pixel 0's x-corner 0
+                auto cell = [&](auto dc_, auto ky_) {
+                    constexpr int DC = decltype(dc_)::value, KY = decltype(ky_)::value;
+                    const int c = (ly + 1 - KY) * kCW + max(cm + DC, 0);   // (solo: pixel 0's own cells do not exist; it is never stored)
+                    const uint2 sl2 = slots[c];
+                    const uint32_t e0 = sl2.x & 0xffffu, e1 = sl2.x >> 16, e2 = sl2.y & 0xffffu, e3 = sl2.y >> 16;
+                    if (e0 == kEnd) return;
+                    if (e0 != kLongCell) {
+                        sp_use<NC, NCH, DC, KY>(rec4, e0, a);
+                        if (e1 != kEnd) {
+                            sp_use<NC, NCH, DC, KY>(rec4, e1, a);
+                            if (e2 != kEnd) {
+                                sp_use<NC, NCH, DC, KY>(rec4, e2, a);
+                                if (e3 != kEnd) sp_use<NC, NCH, DC, KY>(rec4, e3, a);
+                            }
+                        }
+                    } else {                                               // phase S left the chain in raster order
+                        for (uint32_t e = ohead[c]; e != kEnd; e = link[e]) sp_use<NC, NCH, DC, KY>(rec4, e, a);
+                    }
+                };
+                clear();                                                   // corner row 0: classes 0, 1
+                cell(integral_constant<int, -1>{}, integral_constant<int, 0>{});
+                cell(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+                cell(integral_constant<int, 1>{}, integral_constant<int, 0>{});
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
 #pragma unroll
-                    for (int kx = 0; kx < 2; ++kx)
+                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = a[k][0][c] + a[k][1][c];
+                clear();                                                   // corner row 1: classes 2, 3
+                cell(integral_constant<int, -1>{}, integral_constant<int, 1>{});
+                cell(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+                cell(integral_constant<int, 1>{}, integral_constant<int, 1>{});
 #pragma unroll
-                        for (int c = 0; c < 1 + NCH; ++c) a[k][kx][c] = 0.0f;
-            };
-            const int cm = max(lx2 + 1, 0);                            // cell column of pixel 1's x-corner 1 = of pixel 0's x-corner 0
-            auto cell = [&](auto dc_, auto ky_) {
-                constexpr int DC = decltype(dc_)::value, KY = decltype(ky_)::value;
-                const int c = (ly + 1 - KY) * kCW + max(cm + DC, 0);   // (solo: pixel 0's own cells do not exist; it is never stored)
-                const uint2 sl = slots[c];
-                const uint32_t e0 = sl.x & 0xffffu, e1 = sl.x >> 16, e2 = sl.y & 0xffffu, e3 = sl.y >> 16;
-                if (e0 == kEnd) return;
-                if (e0 != kLongCell) {
-                    sp_use<NC, NCH, DC, KY>(rec, e0, a);
-                    if (e1 != kEnd) {
-                        sp_use<NC, NCH, DC, KY>(rec, e1, a);
-                        if (e2 != kEnd) {
-                            sp_use<NC, NCH, DC, KY>(rec, e2, a);
-                            if (e3 != kEnd) sp_use<NC, NCH, DC, KY>(rec, e3, a);
-                        }
-                    }
-                } else {                                               // phase S left the list in raster order
-                    for (uint32_t e = head[c]; e != kEnd; e = link[e]) sp_use<NC, NCH, DC, KY>(rec, e, a);
-                }
-            };
-            using std::integral_constant;
-            clear();                                                   // corner row 0: classes 0, 1
-            cell(integral_constant<int, -1>{}, integral_constant<int, 0>{});
-            cell(integral_constant<int, 0>{}, integral_constant<int, 0>{});
-            cell(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+                for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = a[k][0][c] + a[k][1][c];
-            clear();                                                   // corner row 1: classes 2, 3
-            cell(integral_constant<int, -1>{}, integral_constant<int, 1>{});
-            cell(integral_constant<int, 0>{}, integral_constant<int, 1>{});
-            cell(integral_constant<int, 1>{}, integral_constant<int, 1>{});
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
+                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
+            }
+            OFL_OPAQUE_S(pp);
+            sp_finalize<NC, MCH>(s, t, tot, mine, dflags);
+            if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
         }
-        if (mine) finalize(tot);
-        if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
+        if (!redo) break;
+        dflags = 0;                                           // (nothing was finalized before the first band overflowed)
+        __syncthreads();
     }
-    if (!over) { flush_flags(); return; }
-    // ---- fallback for this tile (a band of destination rows that more than kSpQ records touch): LDS float atomics,
-    // records streamed from the queue (plane 0 density, then the data channels; the mask channel accumulates the INVALID
-    // weight so that an all-valid pixel is exactly 1 in any order)
-    if (tid == 0) atomicAdd(&p.overflow[1], 1);                       // statistics: tiles that left the exact path
-    __syncthreads();
-    for (int i = tid; i < (1 + NCH) * kPx; i += kSpNT2) acc[i] = 0.0f;
-    __syncthreads();
-    for (int i = tid; i < qlen; i += kSpNT2) {
-        float dd[NC];
+    if (over) {
+        // a fold (more records than four bands hold, or > 64 sources in one cell): this tile is redone with LDS float
+        // atomics by splat_tile_fallback_kernel (same stream, right after this kernel); whatever its first bands stored is
+        // overwritten there, and its flag word comes from there
+        if (tid == 0) { p.fb_list[atomicAdd(&p.stats[3], 1)] = (int32_t)tile; atomicAdd(&p.stats[1], 1); }
+        return;
+    }
+    if (NC == 2 && s.dst_flags) {                             // (every thread of the block gets here)
+        dflags = wave_or_flags(dflags);
+        if (lane == 0) flag_or(&s.dst_flags[n], dflags);
+    }
+#undef s
+#undef p
+}
+
+// The tiles the gather kernel could not sum in order (heavy folds of the flow): LDS float atomics over the tile's list
+// (plane 0 density, then the data channels; the mask channel accumulates the INVALID weight, so that an all-valid pixel is
+// exactly 1 in any order).  Tolerance instead of bit-exactness for these tiles; masks stay exact.  A persistent grid walks
+// the list of such tiles the gather kernel left (usually empty: the kernel ends at once).
+template <int NC, bool MCH>
+__global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const GatherParams p) {
+    constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0);
+    __shared__ float acc[(1 + NCH) * kPx];
+    const SplatParams& s = p.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    const int count = p.stats[3];                                     // (of this launch; stats[1] counts the whole call)
+    for (int item = blockIdx.x; item < count; item += gridDim.x) {
+        const uint32_t tile = (uint32_t)p.fb_list[item];              // the tile the gather kernel gave up on
+        const uint32_t nn = fastdiv(tile, p.mi_m, p.mi_s);
+        const uint32_t rem = tile - nn * p.tiles_img;
+        const uint32_t yy = fastdiv(rem, p.mx_m, p.mx_s);
+        const int n = (int)nn, ty = (int)yy, tx = (int)(rem - yy * (uint32_t)p.tiles_x);
+        const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
+        const uint32_t* __restrict__ lst = p.list + dtile * kBinCap;
+        const int nlist = min(p.cnt[dtile], kBinCap);
+        SpTile t;
+        sp_tile_setup(s, tx, ty, n, t);
+        __syncthreads();
+        for (int i = tid; i < (1 + NCH) * kPx; i += kSpNT2) acc[i] = 0.0f;
+        __syncthreads();
+        const int sl = tid & 15, srow = sl >> 2, sc4 = sl & 3;
+        for (int base = 0; base < nlist; base += kSpNT2 / 16) {
+            const int e = base + (tid >> 4);
+            const bool have = e < nlist;
+            const uint32_t sub = have ? lst[e] : 0u;
+            const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
+            const int sx4 = (int)subx * kSubW + sc4 * 4, sy = (int)suby * kSubH + srow;
+            const bool in = have && (sx4 < w) && (sy < h);
+            SpSrc q;
+            sp_load_src(s, n, sx4, sy, in, (uint32_t)(sy * w + sx4), hw, q);
+            f4 dat[NC];
+            uint32_t mc4 = 0x01010101u;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) dd[c] = qrec(3 + c, i);
-        const bool invalid = MCH ? ((__float_as_uint(qrec(2, i)) & 1u) == 0u) : false;
-        float wx[2], wy[2]; int ix[2], iy[2];
-        sp_corners(qrec(0, i), qrec(1, i), wmax, hmax, dx0, dy0, wx, wy, ix, iy);
+            for (int c = 0; c < NC; ++c) dat[c] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (q.on != 0u) sp_load_data<NC, MCH>(s, n, sx4, sy, hw, dat, mc4);
 #pragma unroll
-        for (int ky = 0; ky < 2; ++ky) {
+            for (int k = 0; k < 4; ++k) {
+                if (!((q.on >> k) & 1u)) continue;
+                float wx[2], wy[2]; int ix[2], iy[2];
+                sp_corners(q.x[k], q.y[k], wmax, hmax, t.dx0, t.dy0, wx, wy, ix, iy);
+                const bool invalid = MCH ? (((mc4 >> (8 * k)) & 1u) == 0u) : false;
 #pragma unroll
-            for (int kx = 0; kx < 2; ++kx) {
-                const float wgt = wy[ky] * wx[kx];
-                const int xl = ix[kx], yl = iy[ky];
-                if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
-                const int d = yl * kSpTW + xl;
-                atomicAdd(&acc[d], wgt);
+                for (int ky = 0; ky < 2; ++ky) {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) atomicAdd(&acc[(1 + c) * kPx + d], wgt * dd[c]);
-                if (MCH && invalid) atomicAdd(&acc[(1 + NC) * kPx + d], wgt);
+                    for (int kx = 0; kx < 2; ++kx) {
+                        const float wgt = wy[ky] * wx[kx];
+                        const int xl = ix[kx], yl = iy[ky];
+                        if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
+                        const int d = yl * kSpTW + xl;
+                        atomicAdd(&acc[d], wgt);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) atomicAdd(&acc[(1 + c) * kPx + d], wgt * (s.data_sign * dat[c][k]));
+                        if (MCH && invalid) atomicAdd(&acc[(1 + NC) * kPx + d], wgt);
+                    }
+                }
             }
         }
-    }
-    __syncthreads();
-    dflags = 0;                                           // (bands finalized before the tile left the exact path are overwritten)
-    if (inimg) {
+        __syncthreads();
+        int dflags = 0;
         float tot[2][1 + NCH];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int d = ly * kSpTW + max(lx2 + k, 0);
+            const int d = t.ly * kSpTW + max(t.lx2 + k, 0);
 #pragma unroll
             for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
             if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];      // density - invalid weight
         }
-        finalize(tot);
+        sp_finalize<NC, MCH>(s, t, tot, t.inimg, dflags);
+        if (NC == 2 && s.dst_flags) {
+            dflags = wave_or_flags(dflags);
+            if (lane == 0) flag_or(&s.dst_flags[n], dflags);
+        }
     }
-    flush_flags();
 }
 
-// zero the fallback accumulator only when the atomics path will run
-__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t count, const int32_t* __restrict__ flag) {
-    if (*flag == 0) return;
-    const int64_t n4 = count >> 2;
+// zero the fallback accumulator of the images that take the atomics path
+__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t count_per_image, const int32_t* __restrict__ flags) {
+    const int n = blockIdx.y;
+    if (flags[n] == 0) return;
+    float* __restrict__ q = ptr + (int64_t)n * count_per_image;
+    const int64_t n4 = count_per_image >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
-        reinterpret_cast<f4*>(ptr)[i] = (f4){0.f, 0.f, 0.f, 0.f};
-    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) ptr[(n4 << 2) + threadIdx.x] = 0.0f;
+        reinterpret_cast<f4u*>(q)[i] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (blockIdx.x == 0 && threadIdx.x < (count_per_image & 3)) q[(n4 << 2) + threadIdx.x] = 0.0f;
+}
+
+// statistics of a launch: [0] some image took the two-pass path, [2] how many
+__global__ void splat_stats_kernel(const int32_t* __restrict__ img_over, int32_t n, int32_t* __restrict__ stats) {
+    int k = 0;
+    for (int i = threadIdx.x; i < n; i += 64) k += img_over[i] != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o);
+    if (threadIdx.x == 0 && k) { atomicOr(&stats[0], 1); atomicAdd(&stats[2], k); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1771,11 +1972,16 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 }
 
 
-template <int NC>
-int launch_splat_tile(const TiledParams& tp, unsigned grid, hipStream_t st) {
-    if (tp.s.with_mask_chan) hipLaunchKernelGGL((splat_tile_kernel<NC, true>), dim3(grid), dim3(kSpNT2), 0, st, tp);
-    else hipLaunchKernelGGL((splat_tile_kernel<NC, false>), dim3(grid), dim3(kSpNT2), 0, st, tp);
+template <int NC, bool MCH>
+int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((splat_gather_kernel<NC, MCH>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    hipLaunchKernelGGL((splat_tile_fallback_kernel<NC, MCH>), dim3(512), dim3(kSpNT2), 0, st, gp);
     return (int)hipGetLastError();
+}
+
+template <int NC>
+int launch_splat_gather(const GatherParams& gp, unsigned grid, hipStream_t st) {
+    return gp.s.with_mask_chan ? launch_splat_gather2<NC, true>(gp, grid, st) : launch_splat_gather2<NC, false>(gp, grid, st);
 }
 
 }  // namespace
@@ -2004,23 +2210,19 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 }
 
 
-#ifndef OFL_SP_POOL_LOG2
-#define OFL_SP_POOL_LOG2 30   // workspace budget of one pass, in 4-byte words (4 GiB: ~57 frames of 1080p; measured -8 % against 1 GiB at B=16)
-#endif
-constexpr int kSpRecFloats = 6;   // floats per record: x, y, key (+ mask-channel bit), up to 3 data channels
-// workspace words of one pass of `images` frames: header | queue lengths | secondary block ids | primary regions |
-// secondary blocks
-static int64_t splat_sec_blocks(int64_t tiles) { return (tiles + kSpSecDiv - 1) / kSpSecDiv + 64; }   // (measured: 0.02 / 0.06 / 0.09 per tile drawn at sigma 8 / 12 / 16)
+// workspace words of one pass of `images` frames: statistics (8) | per-image fallback flags | list lengths | lists
 static int64_t splat_pass_words(int64_t images, int32_t h, int32_t w) {
     const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
-    return 8 + (((1 + kSpSlots) * tiles + 3) & ~(int64_t)3) + kSpRecFloats * (int64_t)kSpPrim * (tiles + splat_sec_blocks(tiles));
+    return 8 + ((images + 3) & ~(int64_t)3) + 2 * ((tiles + 3) & ~(int64_t)3) + (int64_t)kBinCap * tiles;
 }
 static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
-    int64_t c = ((int64_t)1 << OFL_SP_POOL_LOG2) / splat_pass_words(1, h, w);
-    if (c < 1) c = 1;
+    // one pass unless the caller bounds it (a testing aid) or the fallback accumulator of a pass would pass ~2^31 floats
+    int64_t c = n;
+    const int64_t cap = ((int64_t)1 << 31) / (5 * (int64_t)h * w);
+    if (cap >= 1 && c > cap) c = cap;
     if (g_splat_pass_images > 0 && g_splat_pass_images < c) c = g_splat_pass_images;
     if (c >= n) return n;
-    const int64_t passes = (n + c - 1) / c;            // equal passes: every pass pays ~0.1 ms of launch gaps and tails
+    const int64_t passes = (n + c - 1) / c;            // equal passes
     return (n + passes - 1) / passes;
 }
 
@@ -2043,105 +2245,117 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     if ((valid || mask_chan) && !with_mask_chan) return OFL_E_ARG;
     if (dst_flags && c != 2) return OFL_E_ARG;
-    if (data_b && c > 2) return OFL_E_ARG;                           // (flows: the tile kernel only carries it for <= 2 channels)
+    if (data_b && c > 2) return OFL_E_ARG;                           // (flows: the un-occlude fill only carries it for <= 2 channels)
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
-    TiledParams tp = {};
+    GatherParams gp = {};
     unsigned grid_unused;
-    int rc = fill_splat(tp.s, flow, flow_bs, data, data_bs, data_sign, weight_mask, weight_mask_bs, chan_mask_a,
+    int rc = fill_splat(gp.s, flow, flow_bs, data, data_bs, data_sign, weight_mask, weight_mask_bs, chan_mask_a,
                         chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, n, c, h, w, grid_unused);
     if (rc) return rc;
-    // eligibility of the routed path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit coordinates
-    // (any width: 16 / 8-byte accesses at 4-byte alignment, mask bytes at any alignment)
-    const bool ok = w >= 4 && w < 32768 && h < 32768;   // 15-bit rows and columns in the record key
+    // eligibility of the gather path: at least one whole 4-pixel group per row, 15-bit rows and columns in the record key
+    // (any width: 16 / 8-byte accesses at 4-byte alignment, mask bytes at any alignment; > 3 channels in groups of 3)
+    const bool ok = w >= 4 && w < 32768 && h < 32768;
     if (!ok) return OFL_E_UNSUPPORTED;
     if (workspace_ints < ofl_splat_tiled_workspace_ints(n, h, w)) return OFL_E_ARG;
-    tp.s.flow_sign = flow_sign; tp.s.xs = xs; tp.s.ys = ys; tp.s.xy_bs = xy_bs;
-    tp.s.dst = dst; tp.s.density = density; tp.s.warped = warped; tp.s.valid = valid; tp.s.mask_chan = mask_chan;
-    tp.s.dst_flags = dst_flags;
-    tp.s.data_b = data_b; tp.s.data_b_bs = data_b_bs;
-    tp.s.round_mode = round_mode;
-    tp.tiles_x = (w + kSpTW - 1) / kSpTW; tp.tiles_y = (h + kSpTH - 1) / kSpTH;
-    tp.tiles_img = (uint32_t)(tp.tiles_x * tp.tiles_y);
-    if ((int64_t)tp.tiles_img * n >= (1ll << 31)) return OFL_E_SHAPE;
-    magic_u32((uint32_t)tp.tiles_x, tp.mx_m, tp.mx_s);
-    magic_u32(tp.tiles_img, tp.mi_m, tp.mi_s);
-    const int64_t chunk = splat_chunk_images(n, h, w), ctiles = chunk * tp.tiles_img;
-    tp.overflow = workspace;
-    tp.sec_count = workspace + 4;
-    tp.cursor = workspace + 8;
-    tp.sec = tp.cursor + ctiles;
-    tp.nsec = (int32_t)splat_sec_blocks(ctiles);
-    tp.prim = reinterpret_cast<float*>(workspace + 8 + (((1 + kSpSlots) * ctiles + 3) & ~(int64_t)3));   // 16-byte aligned columns
-    tp.secp = tp.prim + (int64_t)kSpRecFloats * kSpPrim * ctiles;
+    gp.s.flow_sign = flow_sign; gp.s.xs = xs; gp.s.ys = ys; gp.s.xy_bs = xy_bs;
+    gp.s.dst = dst; gp.s.density = density; gp.s.warped = warped; gp.s.valid = valid; gp.s.mask_chan = mask_chan;
+    gp.s.dst_flags = dst_flags;
+    gp.s.data_b = data_b; gp.s.data_b_bs = data_b_bs;
+    gp.s.round_mode = round_mode;
+    gp.tiles_x = (w + kSpTW - 1) / kSpTW; gp.tiles_y = (h + kSpTH - 1) / kSpTH;
+    gp.tiles_img = (uint32_t)(gp.tiles_x * gp.tiles_y);
+    if ((int64_t)gp.tiles_img * n >= (1ll << 31)) return OFL_E_SHAPE;
+    magic_u32((uint32_t)gp.tiles_x, gp.mx_m, gp.mx_s);
+    magic_u32(gp.tiles_img, gp.mi_m, gp.mi_s);
+    gp.subs_x = (w + kSubW - 1) / kSubW;
+    magic_u32((uint32_t)gp.subs_x, gp.sx_m, gp.sx_s);
+    gp.regs_x = (w + 4 * kSubW - 1) / (4 * kSubW); gp.regs_y = (h + 4 * kSubH - 1) / (4 * kSubH);
+    gp.regs_img = (uint32_t)(gp.regs_x * gp.regs_y);
+    magic_u32((uint32_t)gp.regs_x, gp.rx_m, gp.rx_s);
+    magic_u32(gp.regs_img, gp.ri_m, gp.ri_s);
+    const int64_t chunk = splat_chunk_images(n, h, w), ctiles = chunk * gp.tiles_img;
+    gp.stats = workspace;
+    gp.img_over = workspace + 8;
+    gp.cnt = gp.img_over + ((chunk + 3) & ~(int64_t)3);
+    gp.fb_list = gp.cnt + ((ctiles + 3) & ~(int64_t)3);
+    gp.list = reinterpret_cast<uint32_t*>(gp.fb_list + ((ctiles + 3) & ~(int64_t)3));
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(tp.overflow, 0, 4 * sizeof(int32_t), st);
+    hipError_t e = hipMemsetAsync(gp.stats, 0, 8 * sizeof(int32_t), st);
     if (e != hipSuccess) return (int)e;
     if (dst_flags) {
         e = hipMemsetAsync(dst_flags, 0, (size_t)n * sizeof(int32_t), st);
         if (e != hipSuccess) return (int)e;
     }
-    const SplatParams all = tp.s;
+    const SplatParams all = gp.s;
     const int64_t hw = (int64_t)h * w;
-    // more than 3 channels: groups of 3 (a record holds 3 data channels); density and masks come out of the first group
-    for (int32_t c0 = 0; c0 < c; c0 += 3) {
-    SplatParams full = all;
-    full.c = (c - c0) < 3 ? (c - c0) : 3;
-    full.data = all.data + c0 * hw; full.dst = all.dst + c0 * hw;
-    if (all.data_b) full.data_b = all.data_b + c0 * hw;
-    if (c0 > 0) { full.with_mask_chan = 0; full.density = nullptr; full.warped = nullptr; full.valid = nullptr; full.mask_chan = nullptr; }
-    const int32_t cg = full.c;
-    for (int64_t n0 = 0; n0 < n; n0 += chunk) {          // same stream: the queues of a pass are re-used by the next one
+    for (int64_t n0 = 0; n0 < n; n0 += chunk) {          // (same stream: a pass re-uses the lists of the one before)
         const int64_t nn = (n - n0) < chunk ? (n - n0) : chunk;
-        SplatParams& q = tp.s;
-        q = full;
-        q.n = (int32_t)nn;
-        if (q.flow) q.flow = full.flow + n0 * full.flow_bs;
-        if (q.xs) { q.xs = full.xs + n0 * full.xy_bs; q.ys = full.ys + n0 * full.xy_bs; }
-        q.data = full.data + n0 * full.data_bs;
-        if (q.data_b) q.data_b = full.data_b + n0 * full.data_b_bs;
-        if (q.weight_mask) q.weight_mask = full.weight_mask + n0 * full.weight_mask_bs;
-        if (q.chan_mask_a) q.chan_mask_a = full.chan_mask_a + n0 * full.chan_mask_a_bs;
-        if (q.chan_mask_b) q.chan_mask_b = full.chan_mask_b + n0 * full.chan_mask_b_bs;
-        q.dst = full.dst + n0 * all.dst_bs;
-        if (q.density) q.density = full.density + n0 * hw;
-        if (q.warped) q.warped = full.warped + n0 * hw;
-        if (q.valid) q.valid = full.valid + n0 * hw;
-        if (q.mask_chan) q.mask_chan = full.mask_chan + n0 * hw;
-        if (q.dst_flags) q.dst_flags = full.dst_flags + n0;
-        tp.total = (int64_t)tp.tiles_img * nn;
-        tp.per_xcd = (tp.total + kXcds - 1) / kXcds;
-        e = hipMemsetAsync(tp.sec_count, 0, (size_t)(4 + ctiles) * sizeof(int32_t), st);      // blocks drawn | queue lengths
+        // the lists do not depend on the data: binned once per pass, read by every channel group
+        SplatParams base = all;
+        base.n = (int32_t)nn;
+        if (base.flow) base.flow = all.flow + n0 * all.flow_bs;
+        if (base.xs) { base.xs = all.xs + n0 * all.xy_bs; base.ys = all.ys + n0 * all.xy_bs; }
+        base.data = all.data + n0 * all.data_bs;
+        if (base.data_b) base.data_b = all.data_b + n0 * all.data_b_bs;
+        if (base.weight_mask) base.weight_mask = all.weight_mask + n0 * all.weight_mask_bs;
+        if (base.chan_mask_a) base.chan_mask_a = all.chan_mask_a + n0 * all.chan_mask_a_bs;
+        if (base.chan_mask_b) base.chan_mask_b = all.chan_mask_b + n0 * all.chan_mask_b_bs;
+        base.dst = all.dst + n0 * all.dst_bs;
+        if (base.density) base.density = all.density + n0 * hw;
+        if (base.warped) base.warped = all.warped + n0 * hw;
+        if (base.valid) base.valid = all.valid + n0 * hw;
+        if (base.mask_chan) base.mask_chan = all.mask_chan + n0 * hw;
+        if (base.dst_flags) base.dst_flags = all.dst_flags + n0;
+        gp.s = base;
+        gp.total = (int64_t)gp.tiles_img * nn;
+        gp.per_xcd = (gp.total + kXcds - 1) / kXcds;
+        gp.rtotal = (int64_t)gp.regs_img * nn;
+        gp.rper_xcd = (gp.rtotal + kXcds - 1) / kXcds;
+        // per-image fallback flags and list lengths of this pass
+        e = hipMemsetAsync(gp.img_over, 0, (size_t)(((chunk + 3) & ~(int64_t)3) + ctiles) * sizeof(int32_t), st);
         if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(tp.sec, 0xff, (size_t)ctiles * kSpSlots * sizeof(int32_t), st);   // no blocks yet (-1)
-        if (e != hipSuccess) return (int)e;
-        const unsigned grid = (unsigned)(tp.per_xcd * kXcds);
-        hipLaunchKernelGGL(splat_route_kernel, dim3(grid), dim3(kSpNT), 0, st, tp);
+        hipLaunchKernelGGL(splat_bin_kernel, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
         rc = (int)hipGetLastError();
         if (rc) return rc;
-        switch (cg) {
-            case 1: rc = launch_splat_tile<1>(tp, grid, st); break;
-            case 2: rc = launch_splat_tile<2>(tp, grid, st); break;
-            default: rc = launch_splat_tile<3>(tp, grid, st); break;
+        hipLaunchKernelGGL(splat_stats_kernel, dim3(1), dim3(64), 0, st, gp.img_over, (int32_t)nn, gp.stats);
+        // more than 3 channels: groups of 3 (a record holds 3 data channels); density and masks come out of the first group
+        for (int32_t c0 = 0; c0 < c; c0 += 3) {
+            SplatParams full = base;
+            full.c = (c - c0) < 3 ? (c - c0) : 3;
+            full.data = base.data + c0 * hw; full.dst = base.dst + c0 * hw;
+            if (base.data_b) full.data_b = base.data_b + c0 * hw;
+            if (c0 > 0) { full.with_mask_chan = 0; full.density = nullptr; full.warped = nullptr; full.valid = nullptr; full.mask_chan = nullptr; }
+            const int32_t cg = full.c;
+            gp.s = full;
+            e = hipMemsetAsync(gp.stats + 3, 0, sizeof(int32_t), st);      // tiles this launch hands to the fallback kernel
+            if (e != hipSuccess) return (int)e;
+            const unsigned grid = (unsigned)(gp.per_xcd * kXcds);
+            switch (cg) {
+                case 1: rc = launch_splat_gather<1>(gp, grid, st); break;
+                case 2: rc = launch_splat_gather<2>(gp, grid, st); break;
+                default: rc = launch_splat_gather<3>(gp, grid, st); break;
+            }
+            if (rc) return rc;
+            // two-pass global-atomics path for the images of this pass that were flagged (a list overflowed / a subtile
+            // spread too wide); every block below exits at once for the others
+            SplatParams fb = gp.s;
+            fb.accum = accum_fallback;
+            fb.run_if_set = gp.img_over;
+            fb.any_set = gp.stats;                            // stats[0]: some image of the pass is flagged (splat_stats_kernel)
+            const int planes = 1 + cg + (fb.with_mask_chan ? 1 : 0);
+            hipLaunchKernelGGL(zero_if_set_kernel, dim3(64, (unsigned)nn), dim3(256), 0, st, accum_fallback, (int64_t)planes * hw, gp.img_over);
+            unsigned g2;
+            tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
+            if (g2 > 2048u) g2 = 2048u;                       // (strided: the kernels walk the tiles of the flagged images)
+            switch (cg) {
+                case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
+                        hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
+                case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
+                        hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
+                default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
+                         hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
+            }
         }
-        if (rc) return rc;
-        // two-pass global-atomics path for this pass's images, armed only if the launch was flagged (pool overflow / a
-        // source tile spread too wide); every kernel below exits at once otherwise
-        SplatParams fb = tp.s;
-        fb.accum = accum_fallback;
-        fb.run_if_set = tp.overflow;
-        const int planes = 1 + cg + (fb.with_mask_chan ? 1 : 0);
-        hipLaunchKernelGGL(zero_if_set_kernel, dim3(2048), dim3(256), 0, st, accum_fallback, nn * planes * hw, tp.overflow);
-        unsigned g2;
-        tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
-        switch (cg) {
-            case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
-                    hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
-            case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
-                    hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
-            default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
-                     hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
-        }
-    }
     }
     return (int)hipGetLastError();
 }

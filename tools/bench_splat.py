@@ -36,5 +36,5 @@ for name, bpp, fn in (("apply 's' C=3 +valid", 35, lambda: A.apply(img, target_m
                       ("switch_ref s->t", 18, lambda: A.switch_ref())):
     t = timeit(fn)
     st = _native._last_splat_stats.cpu().tolist()
-    print("sigma %4.1f  %-22s %8.3f ms  %8.1f Mpix/s  %6.1f GB/s (%d B/px)   [launch fallback %d, tiles on LDS atomics %d, queue blocks drawn %d]"
-          % (a.sigma, name, t * 1e3, px / t / 1e6, bpp * px / t / 1e9, bpp, st[0], st[1], st[4]))
+    print("sigma %4.1f  %-22s %8.3f ms  %8.1f Mpix/s  %6.1f GB/s (%d B/px)   [launch fallback %d, tiles on LDS atomics %d, images on the two-pass path %d]"
+          % (a.sigma, name, t * 1e3, px / t / 1e6, bpp * px / t / 1e9, bpp, st[0], st[1], st[2]))
