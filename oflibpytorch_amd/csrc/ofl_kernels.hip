@@ -1399,6 +1399,8 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     // whose cell lies in the tile (cell rows r0 .. r1) become LDS records and join their cell; qcount ends up as the number
     // of records wanted (more than kSpQ: not all were kept).
     // one half step: the hit test of a lane's 4 source pixels, ranks by ballot + popcount, records and cells in LDS
+    // (batching the LDS traffic of both half steps -- all rank atomics, then all record stores, then all slot stores -- was
+    // measured 6 % SLOWER: the longer live ranges cost more than the round trips saved)
     auto process = [&](const SpSrc& q, int sx4, int sy, const f4 (&dat)[NC], uint32_t mc4, int r0, int r1) {
         int cell[4];
         unsigned long long m[4];
@@ -1421,11 +1423,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             for (int k = 0; k < 4; ++k) {
                 const int pos = wbase + __popcll(m[k] & below);
                 wbase += __popcll(m[k]);
-#ifdef OFL_ABL_NOREC
-                if (cell[k] == -12345) {
-#else
                 if (cell[k] >= 0 && pos < kSpQ) {
-#endif
                     const float xv = q.x[k], yv = q.y[k];
                     const float x0 = floorf(xv), y0 = floorf(yv);
                     const float wx0 = (x0 + 1.0f) - xv, wx1 = xv - x0, wy0 = (y0 + 1.0f) - yv, wy1 = yv - y0;   // utils.py:1110-1111
@@ -1445,21 +1443,17 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
         }
     };
     // ---- A: walk the tile's list from entry `first`, 32 subtiles per step (4 source pixels per lane and half step): list ->
-    // flow + weight mask of both halves -> data of the 4-pixel groups that have a pixel in the tile.  The pixels whose cell
-    // lies in the tile (cell rows r0 .. r1) become LDS records and join their cell; qcount ends up as the number of records
-    // wanted (more than kSpQ: not all were kept).
+    // flow, weight mask AND data of both halves in one wave of loads (fetching the data only for the 4-pixel groups that turn
+    // out to have a pixel in the tile saves a third of the bytes but costs a third dependent round trip: +10 % time -- a
+    // tile's life is a chain of round trips, not a bandwidth problem).  The pixels whose cell lies in the tile (cell rows
+    // r0 .. r1) become LDS records and join their cell; qcount ends up as the number of records wanted (more than kSpQ:
+    // not all were kept).
     auto scan = [&](int r0, int r1, int first) {
         OFL_OPAQUE_S(pp);
-#ifdef OFL_ABL_NOSCAN
-        for (int base = first; base < 0; base += kStep) {
-#else
         for (int base = first; base < nlist; base += kStep) {
-#endif
             SpSrc q[2];
             int sx4[2], sy[2];
-#ifdef OFL_SP_EAGER_DATA
             bool inb[2];
-#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = base + u * kHalf + (tid >> 4);
@@ -1469,40 +1463,15 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 sx4[u] = (int)subx * kSubW + sc4 * 4; sy[u] = (int)suby * kSubH + srow;
                 const bool in = have && (sx4[u] < w) && (sy[u] < h);
                 sp_load_src(s, n, sx4[u], sy[u], in, (uint32_t)(sy[u] * w + sx4[u]), hw, q[u]);
-#ifdef OFL_SP_EAGER_DATA
                 inb[u] = in;
-#endif
             }
             f4 dat[2][NC];
             uint32_t mc4[2] = {0x01010101u, 0x01010101u};
-#ifdef OFL_SP_EAGER_DATA
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
                 if (inb[u]) sp_load_data<NC, MCH>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
-            }
-#endif
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                bool anyhit = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int cx = (int)__builtin_amdgcn_fmed3f(floorf(q[u].x[k]), -2.0f, (float)w) - dx0 + 1;
-                    const int cy = (int)__builtin_amdgcn_fmed3f(floorf(q[u].y[k]), -2.0f, (float)h) - dy0 + 1;
-                    anyhit |= ((q[u].on >> k) & 1u) != 0u && (uint32_t)cx < (uint32_t)kCW && cy >= r0 && cy <= r1;
-                }
-#ifndef OFL_SP_EAGER_DATA
-#pragma unroll
-                for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
-#endif
-#ifndef OFL_ABL_NODATA
-#ifdef OFL_SP_EAGER_DATA
-                (void)anyhit;
-#else
-                if (anyhit) sp_load_data<NC, MCH>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
-#endif
-#endif
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) process(q[u], sx4[u], sy[u], dat[u], mc4[u], r0, r1);
@@ -1539,9 +1508,6 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 }
                 break;
             }
-#ifdef OFL_ABL_NOSORT
-            { float t0[2][1 + NCH] = {}; sp_finalize<NC, MCH>(s, t, t0, t.inimg && ly >= r0 && ly < r1, dflags); if (nb > 1) __syncthreads(); continue; }
-#endif
             // ---- S: every cell's records in raster order of their source pixels (ascending key) -- the order in which the
             // reference's scatter_add_ adds them within a corner class.  One or two records need nothing (a + b = b + a, and
             // the sums start from +0); three or four are sorted by a network in registers; a longer list (a compression or
@@ -1604,11 +1570,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
-#ifdef OFL_ABL_NOC
-            if (false) {
-#else
             if (mine) {
-#endif
                 float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
                 auto clear = [&]() {
 #pragma unroll
