@@ -108,6 +108,22 @@ int ofl_warp_bwd_f32(const float* flow, int64_t flow_bs, float flow_sign,
                      int32_t round_mode, void* stream);
 
 /*
+ * The same warp with a flow that covers a WINDOW of the frame -- Flow.apply(target, padding=[top, bottom, left, right]) with a
+ * 't' flow (flow_class.py:901-913, 924-932): the reference zero-pads the flow to the target's size and pads its mask with
+ * False before the warp; here flow [*,2,fh,fw] and flow_mask [*,fh,fw] stay as they are and cover rows foy .. foy + fh - 1,
+ * columns fox .. fox + fw - 1 of the h x w frame of src / dst: outside the window the flow reads 0 and the flow mask False
+ * (no padded copies).  Generic direct-gather kernel; no addend / src_b / flag outputs.  `cut` is a view of dst.
+ */
+int ofl_warp_bwd_win_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                         int32_t fh, int32_t fw, int32_t foy, int32_t fox,
+                         const float* src, int64_t src_bs,
+                         const uint8_t* src_mask, int64_t src_mask_bs,
+                         const uint8_t* flow_mask, int64_t flow_mask_bs,
+                         float* dst, uint8_t* valid,
+                         int32_t n, int32_t c, int32_t h, int32_t w,
+                         int32_t round_mode, void* stream);
+
+/*
  * The same warp for 8-bit images (Flow.apply / apply_flow on uint8 targets, flow_class.py:943-951, utils.py:613-618):
  * src [*,C,H,W] uint8 is read as it is (no float copy); dst is fp32 [N,C,H,W] (dst_is_u8 = 0, any round_mode) or uint8
  * (dst_is_u8 = 1, round_mode must be OFL_ROUND_U8: round half to even, clamp to [0, 255] -- the values the reference's
@@ -214,6 +230,26 @@ int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
                         int32_t* workspace, int64_t workspace_ints, float* accum_fallback,
                         int32_t n, int32_t c, int32_t h, int32_t w,
                         int32_t round_mode, void* stream);
+
+/*
+ * ofl_splat_tiled_f32 with a flow that covers a WINDOW of the frame -- Flow.apply(target, padding=...) with an 's' flow
+ * (flow_class.py:880-895, 906-913): the reference pads the flow with mode 'replicate' and its mask with False.  Here flow
+ * [*,2,fh,fw], weight_mask and chan_mask_b [*,fh,fw] are read through replicate addressing (flow) / False outside the
+ * window (masks; a NULL chan_mask_b is "all True INSIDE the window"; a NULL weight_mask still means every pixel of the frame
+ * contributes: consider_mask=False); data, chan_mask_a and every output have the h x w geometry of the frame.
+ * Same kernels as ofl_splat_tiled_f32 (bit-identical sums), per-pixel loads for the windowed operands.
+ */
+int ofl_splat_tiled_win_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                            int32_t fh, int32_t fw, int32_t foy, int32_t fox,
+                            const float* data, int64_t data_bs, float data_sign,
+                            const uint8_t* weight_mask, int64_t weight_mask_bs,
+                            const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
+                            const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+                            int32_t with_mask_chan, int32_t occlude,
+                            float* dst, float* density, uint8_t* warped, uint8_t* valid, float* mask_chan,
+                            int32_t* workspace, int64_t workspace_ints, float* accum_fallback,
+                            int32_t n, int32_t c, int32_t h, int32_t w,
+                            int32_t round_mode, void* stream);
 
 /*
  * Per-batch-element flag word of a flow field (OR-ed into flags[n]; caller zeroes):

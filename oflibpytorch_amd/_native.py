@@ -15,14 +15,14 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 18              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 19              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
 _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
-            "ofl_flow_extents_f32")
+            "ofl_flow_extents_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32")
 _lib = None
 
 
@@ -79,6 +79,9 @@ def load_library(path: str = None):
     lib.ofl_sample_pts_f32.argtypes = [p, i64, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
+    lib.ofl_warp_bwd_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, p, i64, p, i64, p, p, i32, i32, i32, i32, i32, p]
+    lib.ofl_splat_tiled_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
+                                            p, i64, p, i32, i32, i32, i32, i32, p]
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
     lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
@@ -462,3 +465,62 @@ def flow_extents(vecs, mask, sign: float) -> torch.Tensor:
         _check(lib.ofl_flow_extents_f32(_ptr(v), vbs, _ptr(m), mbs, float(sign), _ptr(ws), _ptr(ext), n, h, w, _stream(dev)),
                "ofl_flow_extents_f32")
     return ext
+
+
+# ------------------------------------------------------------------------------------------------
+# padded apply: the flow covers a window of the target's frame (no padded copies of the flow)
+# ------------------------------------------------------------------------------------------------
+def warp_bwd_win(flow, src, window, *, src_mask=None, flow_mask=None, want_valid=False, round_mode=ROUND_NONE):
+    """ofl_warp_bwd_win_f32: 't' flow [Nf,2,fh,fw] placed at (top, left) = `window` inside the frame of src [Ns,C,H,W]; zero
+    flow / False mask outside.  -> (dst [N,C,H,W] fp32, valid [N,H,W] bool | None)"""
+    lib, dev = load_library(), device(flow, src)
+    c, h, w = src.shape[1:]
+    fh, fw = flow.shape[2:]
+    n = max(flow.shape[0], src.shape[0], 1 if src_mask is None else src_mask.shape[0], 1 if flow_mask is None else flow_mask.shape[0])
+    with _on(dev):
+        f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
+        s, sbs = _planes(src.detach(), dev, torch.float32, n, "source")
+        sm, smbs = (None, 0) if src_mask is None else _planes(src_mask, dev, torch.bool, n, "source mask")
+        fm, fmbs = (None, 0) if flow_mask is None else _planes(flow_mask, dev, torch.bool, n, "flow mask")
+        dst = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+        valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
+        _check(lib.ofl_warp_bwd_win_f32(_ptr(f), fbs, 1.0, fh, fw, int(window[0]), int(window[1]), _ptr(s), sbs, _ptr(sm), smbs,
+                                        _ptr(fm), fmbs, _ptr(dst), _ptr(valid), n, c, h, w, int(round_mode), _stream(dev)),
+               "ofl_warp_bwd_win_f32")
+    return dst, valid
+
+
+def splat_fwd_win(flow, data, window, *, weight_mask=None, chan_mask_a=None, chan_mask_b=None, want_valid=False, occlude=True,
+                  round_mode=ROUND_NONE):
+    """ofl_splat_tiled_win_f32: 's' flow [Nf,2,fh,fw] placed at (top, left) = `window` inside the frame of data [Nd,C,H,W]
+    (replicated outside, masks False outside).  -> (dst [N,C,H,W] fp32, valid [N,H,W] bool | None); None when the frame is
+    not eligible for the gather path (W < 4): the caller pads and takes the plain route."""
+    lib, dev = load_library(), device(flow, data)
+    c, h, w = data.shape[1:]
+    fh, fw = flow.shape[2:]
+    if w < 4 or _splat_path == 1:
+        return None
+    n = max(data.shape[0], flow.shape[0], 1 if weight_mask is None else weight_mask.shape[0],
+            1 if chan_mask_a is None else chan_mask_a.shape[0], 1 if chan_mask_b is None else chan_mask_b.shape[0])
+    with _on(dev):
+        f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
+        d, dbs = _planes(data.detach(), dev, torch.float32, n, "data")
+        wm, wmbs = (None, 0) if weight_mask is None else _planes(weight_mask, dev, torch.bool, n, "mask")
+        ca, cabs = (None, 0) if chan_mask_a is None else _planes(chan_mask_a, dev, torch.bool, n, "mask")
+        cb, cbbs = (None, 0) if chan_mask_b is None else _planes(chan_mask_b, dev, torch.bool, n, "mask")
+        mch = 1 if want_valid else 0
+        dst = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+        valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
+        ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
+        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        rc = lib.ofl_splat_tiled_win_f32(_ptr(f), fbs, 1.0, fh, fw, int(window[0]), int(window[1]), _ptr(d), dbs, 1.0, _ptr(wm), wmbs,
+                                         _ptr(ca), cabs, _ptr(cb), cbbs, mch, 1 if occlude else 0, _ptr(dst), None, None,
+                                         _ptr(valid), None, _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, int(round_mode),
+                                         _stream(dev))
+        if rc == -4:
+            return None
+        _check(rc, "ofl_splat_tiled_win_f32")
+        if collect_splat_stats:
+            global _last_splat_stats
+            _last_splat_stats = ws[:8].clone()
+    return dst, valid

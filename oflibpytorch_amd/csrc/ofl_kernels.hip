@@ -104,6 +104,10 @@ struct WarpParams {
     int32_t lds_bytes, shear;
     int32_t add_is_flow;             // mode 3: the addend is the flow operand itself (same planes): no second fetch
     int64_t dst_bs;                  // LDS path: batch stride of dst (channels of the whole tensor * h * w)
+    // flow WINDOW (generic kernel only; Flow.apply(padding=...) with a 't' flow, flow_class.py:901-913, 924-932): fw != 0 -> flow and
+    // flow_mask are fh x fw frames covering rows foy .., columns fox .. of the h x w frame; outside the window the flow is
+    // zero (F.pad(mode='constant')) and the flow mask False
+    int32_t fh, fw, foy, fox;
 };
 
 constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
@@ -655,9 +659,19 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(const WarpParams p) {
         const int y = ty * kTileH + wave * kRows + r;
         if (x >= w || y >= h) continue;
         const int64_t pix = (int64_t)y * w + x;
-        const float u = fu[pix], v = fv[pix];
+        float u, v;
         bool fmv = true;
-        if (VALID || FLAGS) fmv = fm ? (fm[pix] != 0) : true;
+        if (p.fw != 0) {                                             // padded apply: the flow covers a window of the frame
+            const int fx = x - p.fox, fy = y - p.foy;
+            const bool inside = (uint32_t)fx < (uint32_t)p.fw && (uint32_t)fy < (uint32_t)p.fh;
+            const int64_t fpix = inside ? (int64_t)fy * p.fw + fx : 0;
+            u = inside ? fu[fpix] : 0.0f;
+            v = inside ? fu[(int64_t)p.fh * p.fw + fpix] : 0.0f;
+            if (VALID) fmv = inside && (fm ? (fm[fpix] != 0) : true);
+        } else {
+            u = fu[pix]; v = fv[pix];
+            if (VALID || FLAGS) fmv = fm ? (fm[pix] != 0) : true;
+        }
         if (FLAGS) {
             fflags |= flag_bits(u, v, fmv);
             if (p.src_flags) {
@@ -751,10 +765,22 @@ struct SplatParams {
     int32_t round_mode;
     int32_t tiles_x, tiles_y;
     int64_t total_tiles, per_xcd;
+    // flow WINDOW (Flow.apply(padding=...), flow_class.py:901-913): fw != 0 -> the flow-geometry operands (flow, weight_mask,
+    // chan_mask_b) are fh x fw frames that cover rows foy .., columns fox .. of the h x w frame of the data; outside the
+    // window the flow is its replicated border value (F.pad(mode='replicate')) and both masks are False
+    int32_t fh, fw, foy, fox;
     const int32_t* run_if_set;   // optional device flags int32[n]: the atomics path runs for image i only when run_if_set[i] != 0
     const int32_t* any_set;      // (with run_if_set) one word: some image of the pass is flagged
     int32_t* dst_flags;          // optional int32[N] (2-channel data only): flag word of the OUTPUT read as a flow under `valid`
 };
+
+// flow window (padded apply): offset of frame pixel (x, y) in a flow-geometry plane (clamped: replicate) and whether it is inside
+template <typename SP>
+__device__ __forceinline__ uint32_t sp_win(const SP& s, int x, int y, bool& inside) {
+    const int fx = x - s.fox, fy = y - s.foy;
+    inside = (uint32_t)fx < (uint32_t)s.fw && (uint32_t)fy < (uint32_t)s.fh;
+    return (uint32_t)(min(max(fy, 0), s.fh - 1) * s.fw + min(max(fx, 0), s.fw - 1));
+}
 
 template <int CT>
 __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
@@ -789,8 +815,11 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
         const int64_t pix = (int64_t)y * w + x;
         float xv, yv;
         bool zero = false;
+        bool inside = true;
+        const int64_t fpix = p.fw != 0 ? (int64_t)sp_win(p, x, y, inside) : pix;       // (padded apply: flow-geometry offset)
+        const int64_t fhw = p.fw != 0 ? (int64_t)p.fh * p.fw : hw;
         if (fu) {
-            const float u = fu[pix], v = fu[hw + pix];
+            const float u = fu[fpix], v = fu[fhw + fpix];
             xv = p.flow_sign * u + (float)x;  // get_flow_endpoints utils.py:1056-1057
             yv = p.flow_sign * v + (float)y;
             if (p.occlude) zero = (u < kZeroThr) && (u > -kZeroThr) && (v < kZeroThr) && (v > -kZeroThr);
@@ -798,7 +827,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
             xv = p.xs[n * p.xy_bs + pix];
             yv = p.ys[n * p.xy_bs + pix];
         }
-        const bool wm = wmk ? (wmk[pix] != 0) : true;
+        const bool wm = wmk ? (inside && wmk[fpix] != 0) : true;
         if (!wm || zero) continue;  // weight * 0: contributes exactly nothing (utils.py:1123)
 
         const float x0 = floorf(xv), y0 = floorf(yv);
@@ -814,7 +843,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
         const int iys[2] = {(int)y0s, (int)y1s};
 
         float mval = 0.0f;
-        if (p.with_mask_chan) mval = ((cma ? cma[pix] != 0 : true) && (cmb ? cmb[pix] != 0 : true)) ? 1.0f : 0.0f;
+        if (p.with_mask_chan) mval = ((cma ? cma[pix] != 0 : true) && (p.fw != 0 ? inside : true) && (cmb ? cmb[fpix] != 0 : true)) ? 1.0f : 0.0f;
 
 #pragma unroll
         for (int ky = 0; ky < 2; ++ky) {
@@ -877,10 +906,13 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
         const float dcl = den < kDenMin ? kDenMin : den;  // clamp_min utils.py:1144
         const bool warped = den > 0.0f;                    // utils.py:1197
         bool fill = false;
+        bool inside = true;
+        const int64_t fpix = p.fw != 0 ? (int64_t)sp_win(p, x, y, inside) : pix;       // (padded apply: flow-geometry offset)
+        const int64_t fhw = p.fw != 0 ? (int64_t)p.fh * p.fw : hw;
         if (p.occlude && fu && !warped) {                  // un-occlude utils.py:1198-1203
-            const float u = fu[pix], v = fu[hw + pix];
+            const float u = fu[fpix], v = fu[fhw + fpix];
             const bool zero = (u < kZeroThr) && (u > -kZeroThr) && (v < kZeroThr) && (v > -kZeroThr);
-            const bool wm = wmk ? (wmk[pix] != 0) : true;
+            const bool wm = wmk ? (inside && wmk[fpix] != 0) : true;
             fill = zero && wm;
         }
         float uv[2] = {0.0f, 0.0f};
@@ -898,7 +930,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
         if (p.valid || p.mask_chan) {
             float mch;
             if (fill)
-                mch = ((cma ? cma[pix] != 0 : true) && (cmb ? cmb[pix] != 0 : true)) ? 1.0f : 0.0f;
+                mch = ((cma ? cma[pix] != 0 : true) && (p.fw != 0 ? inside : true) && (cmb ? cmb[fpix] != 0 : true)) ? 1.0f : 0.0f;
             else
                 mch = (den - acc[(int64_t)(1 + C) * hw + pix]) / dcl;
             vld = mch > kValidThr;
@@ -1018,7 +1050,19 @@ __device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy,
     const int wrem = s.w & 3;
     const bool edge = wrem != 0 && inimg && sx4 > s.w - 4;
     const uint32_t pe = edge ? pix - (uint32_t)(4 - wrem) : pix;
-    if (inimg) {
+    if (inimg && s.fw != 0) {
+        // padded apply: per-pixel loads with replicate addressing (not a hot path); the weight mask is False outside the window
+        const uint32_t fhw = (uint32_t)(s.fh * s.fw);
+        wm4 = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bool inside;
+            const uint32_t off = sp_win(s, min(sx4 + k, s.w - 1), sy, inside);
+            a[k] = s.flow[n * s.flow_bs + off]; b[k] = s.flow[n * s.flow_bs + fhw + off];
+            const bool m = s.weight_mask ? (inside && s.weight_mask[n * s.weight_mask_bs + off] != 0) : true;
+            wm4 |= (uint32_t)m << (8 * k);
+        }
+    } else if (inimg) {
         if (s.flow) {
             a = ld4(s.flow + n * s.flow_bs + pe);
             b = ld4(s.flow + n * s.flow_bs + hw + pe);
@@ -1211,9 +1255,23 @@ __device__ __forceinline__ void sp_tile_setup(const SP& s, int tx, int ty, int n
     t.wide = t.dx0 + kSpTW <= w;
     t.fill_ok[0] = t.fill_ok[1] = false;
     if (s.occlude && s.flow && t.inimg) {
-        const f2 a = ld2(s.flow + n * s.flow_bs + t.pix), b = ld2(s.flow + n * s.flow_bs + hw + t.pix);
+        f2 a, b;
         uint32_t wm2 = 0x0101u;
-        if (s.weight_mask) wm2 = ld16(s.weight_mask + n * s.weight_mask_bs + t.pix);
+        if (s.fw != 0) {                                            // padded apply (see sp_win)
+            const uint32_t fhw = (uint32_t)(s.fh * s.fw);
+            wm2 = 0u;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                bool inside;
+                const uint32_t off = sp_win(s, x2 + k, min(y, h - 1), inside);
+                a[k] = s.flow[n * s.flow_bs + off]; b[k] = s.flow[n * s.flow_bs + fhw + off];
+                const bool m = s.weight_mask ? (inside && s.weight_mask[n * s.weight_mask_bs + off] != 0) : true;
+                wm2 |= (uint32_t)m << (8 * k);
+            }
+        } else {
+            a = ld2(s.flow + n * s.flow_bs + t.pix); b = ld2(s.flow + n * s.flow_bs + hw + t.pix);
+            if (s.weight_mask) wm2 = ld16(s.weight_mask + n * s.weight_mask_bs + t.pix);
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             t.fill_ok[k] = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr) && (((wm2 >> (8 * k)) & 0xffu) != 0u);
@@ -1250,7 +1308,12 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
             float mv;
             if (fill) {
                 const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix + k] != 0 : true;
-                const bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix + k] != 0 : true;
+                bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix + k] != 0 : true;
+                if (s.fw != 0) {                                    // padded apply: chan_mask_b lives in the flow window, False outside
+                    bool inside;
+                    const uint32_t off = sp_win(s, (int)((pix + k) % (uint32_t)s.w), (int)((pix + k) / (uint32_t)s.w), inside);
+                    b = inside && (s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + off] != 0 : true);
+                }
                 mv = (a && b) ? 1.0f : 0.0f;
             } else {
                 mv = tot[k][1 + NC] / dcl;
@@ -1333,7 +1396,16 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
     uint32_t ma = 0x01010101u, mb = 0x01010101u;
     if (MCH) {
         if (s.chan_mask_a) ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + px);
-        if (s.chan_mask_b) mb = ld32(s.chan_mask_b + n * s.chan_mask_b_bs + px);
+        if (s.fw != 0) {                                            // padded apply: chan_mask_b lives in the flow window, False outside
+            mb = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool inside;
+                const uint32_t off = sp_win(s, min((int)(px % (uint32_t)w) + k, w - 1), sy, inside);
+                const bool m = inside && (s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + off] != 0 : true);
+                mb |= (uint32_t)m << (8 * k);
+            }
+        } else if (s.chan_mask_b) mb = ld32(s.chan_mask_b + n * s.chan_mask_b_bs + px);
     }
     if (wrem != 0) {
         if (edge) {
@@ -1953,7 +2025,7 @@ int launch_splat_gather(const GatherParams& gp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 18; }   // 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 19; }   // 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -1962,12 +2034,12 @@ __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t v
     return OFL_E_ARG;
 }
 
-__attribute__((visibility("default"))) int ofl_warp_bwd_f32(
+static int warp_bwd_impl(
     const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
     const float* src_b, int64_t src_b_bs, const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
     const float* addend, int64_t addend_bs, float a_sign, float g_sign, float* dst, uint8_t* valid,
     int32_t* flow_flags, int32_t* src_flags, int32_t* dst_flags, int32_t n, int32_t c, int32_t h, int32_t w,
-    int32_t round_mode, void* stream) {
+    int32_t round_mode, void* stream, int32_t fh, int32_t fw, int32_t foy, int32_t fox) {
     if (!flow || !src || !dst) return OFL_E_NULL;
     int rc = check_dims(n, c, h, w, false);
     if (rc) return rc;
@@ -1990,6 +2062,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;   // sheared rows stay within 16 bits (|slope| <= 16 rows per chunk column)
     p.add_is_flow = (addend != nullptr && addend == flow && addend_bs == flow_bs && c == 2) ? 1 : 0;
     p.dst_bs = (int64_t)c * h * w;
+    p.fh = fh; p.fw = fw; p.foy = foy; p.fox = fox;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
     if (dst_flags) {
@@ -1998,7 +2071,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     }
     // LDS-staged fast path: <= 3 channels, at least one whole 4-pixel group per row, 16-bit box coordinates (any width:
     // 16-byte accesses at 4-byte alignment, mask bytes at any alignment)
-    const bool lds_ok = g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760 && (int64_t)h * w < (1ll << 24);
+    const bool lds_ok = g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760 && (int64_t)h * w < (1ll << 24) && fw == 0;
     if (src_b) {   // only the staged 2-channel kernel with a valid mask subtracts on the fly: anything else is the caller's job
         if (!(lds_ok && c == 2 && valid && !addend && !dst_flags && !flow_flags)) return OFL_E_UNSUPPORTED;
         p.src_b = src_b; p.src_b_bs = src_b_bs;
@@ -2040,6 +2113,25 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_f32(
     if (rc == OFL_OK && dst_flags)                                            // generic kernel: a reduction over the output
         launch_flow_flags(dst, (int64_t)2 * h * w, valid, (int64_t)h * w, dst_flags, n, (int64_t)h * w, st);
     return rc;
+}
+
+__attribute__((visibility("default"))) int ofl_warp_bwd_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
+    const float* src_b, int64_t src_b_bs, const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
+    const float* addend, int64_t addend_bs, float a_sign, float g_sign, float* dst, uint8_t* valid,
+    int32_t* flow_flags, int32_t* src_flags, int32_t* dst_flags, int32_t n, int32_t c, int32_t h, int32_t w,
+    int32_t round_mode, void* stream) {
+    return warp_bwd_impl(flow, flow_bs, flow_sign, src, src_bs, src_b, src_b_bs, src_mask, src_mask_bs, flow_mask, flow_mask_bs, addend,
+                         addend_bs, a_sign, g_sign, dst, valid, flow_flags, src_flags, dst_flags, n, c, h, w, round_mode, stream, 0, 0, 0, 0);
+}
+
+__attribute__((visibility("default"))) int ofl_warp_bwd_win_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, int32_t fh, int32_t fw, int32_t foy, int32_t fox,
+    const float* src, int64_t src_bs, const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
+    float* dst, uint8_t* valid, int32_t n, int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream) {
+    if (fh < 1 || fw < 1 || foy < 0 || fox < 0 || foy + fh > h || fox + fw > w) return OFL_E_ARG;
+    return warp_bwd_impl(flow, flow_bs, flow_sign, src, src_bs, nullptr, 0, src_mask, src_mask_bs, flow_mask, flow_mask_bs, nullptr, 0,
+                         1.0f, 1.0f, dst, valid, nullptr, nullptr, nullptr, n, c, h, w, round_mode, stream, fh, fw, foy, fox);
 }
 
 __attribute__((visibility("default"))) int ofl_warp_bwd_u8(
@@ -2194,14 +2286,14 @@ __attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(in
     return splat_pass_words(splat_chunk_images(n, h, w), h, w);
 }
 
-__attribute__((visibility("default"))) int ofl_splat_tiled_f32(
+static int splat_tiled_impl(
     const float* flow, int64_t flow_bs, float flow_sign, const float* xs, const float* ys, int64_t xy_bs,
     const float* data, int64_t data_bs, float data_sign, const float* data_b, int64_t data_b_bs,
     const uint8_t* weight_mask, int64_t weight_mask_bs,
     const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
     int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
     float* mask_chan, int32_t* dst_flags, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n,
-    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream) {
+    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream, int32_t fh, int32_t fw, int32_t foy, int32_t fox) {
     if (!data || !dst || !workspace || !accum_fallback) return OFL_E_NULL;
     if (!flow && !(xs && ys)) return OFL_E_NULL;
     if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
@@ -2224,6 +2316,7 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
     gp.s.dst_flags = dst_flags;
     gp.s.data_b = data_b; gp.s.data_b_bs = data_b_bs;
     gp.s.round_mode = round_mode;
+    gp.s.fh = fh; gp.s.fw = fw; gp.s.foy = foy; gp.s.fox = fox;
     gp.tiles_x = (w + kSpTW - 1) / kSpTW; gp.tiles_y = (h + kSpTH - 1) / kSpTH;
     gp.tiles_img = (uint32_t)(gp.tiles_x * gp.tiles_y);
     if ((int64_t)gp.tiles_img * n >= (1ll << 31)) return OFL_E_SHAPE;
@@ -2320,6 +2413,36 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
         }
     }
     return (int)hipGetLastError();
+}
+
+__attribute__((visibility("default"))) int ofl_splat_tiled_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, const float* xs, const float* ys, int64_t xy_bs,
+    const float* data, int64_t data_bs, float data_sign, const float* data_b, int64_t data_b_bs,
+    const uint8_t* weight_mask, int64_t weight_mask_bs,
+    const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+    int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
+    float* mask_chan, int32_t* dst_flags, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n,
+    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream) {
+    return splat_tiled_impl(flow, flow_bs, flow_sign, xs, ys, xy_bs, data, data_bs, data_sign, data_b, data_b_bs, weight_mask,
+                            weight_mask_bs, chan_mask_a, chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, dst,
+                            density, warped, valid, mask_chan, dst_flags, workspace, workspace_ints, accum_fallback, n, c, h, w,
+                            round_mode, stream, 0, 0, 0, 0);
+}
+
+__attribute__((visibility("default"))) int ofl_splat_tiled_win_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, int32_t fh, int32_t fw, int32_t foy, int32_t fox,
+    const float* data, int64_t data_bs, float data_sign,
+    const uint8_t* weight_mask, int64_t weight_mask_bs,
+    const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+    int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
+    float* mask_chan, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n,
+    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream) {
+    if (!flow) return OFL_E_NULL;
+    if (fh < 1 || fw < 1 || foy < 0 || fox < 0 || foy + fh > h || fox + fw > w) return OFL_E_ARG;
+    return splat_tiled_impl(flow, flow_bs, flow_sign, nullptr, nullptr, 0, data, data_bs, data_sign, nullptr, 0, weight_mask,
+                            weight_mask_bs, chan_mask_a, chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, dst,
+                            density, warped, valid, mask_chan, nullptr, workspace, workspace_ints, accum_fallback, n, c, h, w,
+                            round_mode, stream, fh, fw, foy, fox);
 }
 
 __attribute__((visibility("default"))) int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,

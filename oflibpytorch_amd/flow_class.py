@@ -477,20 +477,15 @@ class Flow(object):
             raise TypeError("Error applying flow: Target needs to be either a flow object or a torch tensor")
         need_valid = return_flow or return_valid_area
 
-        if padding is None:
-            if tuple(target.shape[-2:]) != self.shape[-2:]:
-                raise ValueError("Error applying flow: Flow and target have to have the same shape")
-            flow = self
-        else:
-            # 't': zero padding is irrelevant outside the flow area; 's': replicate avoids artefacts at the
-            # border of the flow area (flow_class.py:906-913).  Padded mask is False, so the un-padded
-            # formulas below hold for the padded flow as they stand.
-            flow = self.pad(padding, mode='constant' if self._ref == 't' else 'replicate')
-
         rm = _native.ROUND_NONE
         if not return_flow and not return_dtype.is_floating_point:
             rm = _native.ROUND_U8 if return_dtype == torch.uint8 else _native.ROUND_RINT
-        warped, valid, dflags = flow._warp(t, tmask, need_valid, consider_mask, rm)
+        if padding is None:
+            if tuple(target.shape[-2:]) != self.shape[-2:]:
+                raise ValueError("Error applying flow: Flow and target have to have the same shape")
+            warped, valid, dflags = self._warp(t, tmask, need_valid, consider_mask, rm)
+        else:
+            warped, valid, dflags = self._warp_padded(t, tmask, need_valid, consider_mask, rm, padding)
 
         if padding is not None and cut:
             win = (slice(padding[0], padding[0] + self.shape[1]), slice(padding[2], padding[2] + self.shape[2]))
@@ -509,6 +504,32 @@ class Flow(object):
         if (return_2d or return_3d) and warped.shape[0] == 1:
             warped = warped[0, 0] if return_2d else warped[0]
         return (warped, valid) if return_valid_area else warped
+
+    def _warp_padded(self, t: torch.Tensor, tmask, need_valid: bool, consider_mask: bool, round_mode: int, padding: list):
+        """`apply` with a target larger than the flow by `padding` (flow_class.py:830-834, 880-895, 901-913, 924-932): the
+        reference pads the flow to the target's size first -- zeros for 't', replicated border for 's', mask False -- and
+        warps the whole frame.  Here the kernels read the un-padded flow through a window (`ofl_warp_bwd_win_f32`,
+        `ofl_splat_tiled_win_f32`): no padded copy of the flow or its mask is made.  The all-zero early exit, narrow frames
+        the gather kernels do not take, and tensors that want a gradient go through the padded copy (rare / plumbing)."""
+        window = (padding[0], padding[2])
+        direct = not self._all_zero(_native.FLAG_NZ_THR) and \
+            not _native._wants_grad(self._vecs, t) and (self._ref == 't' or get_pure_pytorch())
+        if direct:
+            self._require_finite("Error applying flow to a target: ")
+            if self._ref == 't':
+                warped, valid = _native.warp_bwd_win(self._vecs, t, window, src_mask=tmask,
+                                                     flow_mask=self._mask if need_valid else None, want_valid=need_valid,
+                                                     round_mode=round_mode)
+                return warped.to(self._device), (None if valid is None else valid.to(self._device)), None
+            res = _native.splat_fwd_win(self._vecs, t, window, weight_mask=self.mask if consider_mask else None,
+                                        chan_mask_a=tmask, chan_mask_b=self._mask, want_valid=need_valid, occlude=True,
+                                        round_mode=round_mode)
+            if res is not None:
+                return res[0].to(self._device), (None if res[1] is None else res[1].to(self._device)), None
+        # 't': zero padding is irrelevant outside the flow area; 's': replicate avoids artefacts at the border of the flow area
+        # (flow_class.py:906-913).  The padded mask is False, so the un-padded formulas hold for the padded flow as they stand.
+        flow = self.pad(padding, mode='constant' if self._ref == 't' else 'replicate')
+        return flow._warp(t, tmask, need_valid, consider_mask, round_mode)
 
     def _warp(self, t: torch.Tensor, tmask, need_valid: bool, consider_mask: bool, round_mode: int = 0,
               flow_sign: float = 1.0, data_sign: float = 1.0, t_minus: torch.Tensor = None):

@@ -54,6 +54,7 @@ def oracle_native(monkeypatch):
     """Route the package's three native primitives to the CPU oracle (host-logic tests only)."""
     import oracle_backend
     from oflibpytorch_amd import _native
-    for name in ("flow_flags", "warp_bwd", "splat_fwd", "device", "sample_pts", "flow_extents"):
+    for name in ("flow_flags", "warp_bwd", "splat_fwd", "device", "sample_pts", "flow_extents", "warp_bwd_win", "splat_fwd_win",
+                 "_wants_grad"):
         monkeypatch.setattr(_native, name, getattr(oracle_backend, name))
     return oracle_backend

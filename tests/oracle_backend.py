@@ -133,3 +133,35 @@ def sample_pts(flow, pts):
 
 def flow_extents(vecs, mask, sign):
     return torch.tensor(oracle.flow_extents(_np(vecs, np.float32), None if mask is None else _np(mask), sign))
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+def _pad_to(t, window, h, w, mode):
+    import torch.nn.functional as F
+    fh, fw = t.shape[-2:]
+    lrtb = (window[1], w - fw - window[1], window[0], h - fh - window[0])
+    if t.dtype == torch.bool:
+        return F.pad(t.unsqueeze(1), lrtb).squeeze(1)
+    return F.pad(t, lrtb, mode=mode)
+
+
+def warp_bwd_win(flow, src, window, *, src_mask=None, flow_mask=None, want_valid=False, round_mode=0):
+    h, w = src.shape[-2:]
+    fm = torch.ones((flow.shape[0],) + tuple(flow.shape[2:]), dtype=torch.bool) if (flow_mask is None and want_valid) else flow_mask
+    out = warp_bwd(_pad_to(flow, window, h, w, 'constant'), src, src_mask=src_mask,
+                   flow_mask=None if fm is None else _pad_to(fm, window, h, w, None), want_valid=want_valid, round_mode=round_mode)
+    return out[0], out[1]
+
+
+def splat_fwd_win(flow, data, window, *, weight_mask=None, chan_mask_a=None, chan_mask_b=None, want_valid=False, occlude=True,
+                  round_mode=0):
+    h, w = data.shape[-2:]
+    cb = torch.ones((flow.shape[0],) + tuple(flow.shape[2:]), dtype=torch.bool) if chan_mask_b is None else chan_mask_b
+    out = splat_fwd(_pad_to(flow, window, h, w, 'replicate'), data,
+                    weight_mask=None if weight_mask is None else _pad_to(weight_mask, window, h, w, None),
+                    chan_mask_a=chan_mask_a, chan_mask_b=_pad_to(cb, window, h, w, None), want_valid=want_valid, occlude=occlude,
+                    round_mode=round_mode)
+    return out[0], out[1]

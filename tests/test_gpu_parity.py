@@ -676,3 +676,45 @@ def test_tiled_splat_explicit_positions(dev):
     ref, rden = oracle.grid_from_unstructured_data(x.numpy(), y.numpy(), data.numpy(), m.numpy())
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=3e-5, atol=3e-3)
     np.testing.assert_allclose(den.cpu().numpy(), rden, rtol=3e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("ref", ["t", "s"])
+@pytest.mark.parametrize("shape,pad", [((2, 3, 70, 132), [3, 5, 4, 2]), ((1, 2, 40, 61), [0, 7, 9, 0]), ((3, 1, 33, 47), [6, 0, 0, 5]),
+                                       ((2, 3, 150, 260), [11, 13, 17, 19])])
+def test_padded_apply_reads_the_flow_through_a_window(ref, shape, pad, dev):
+    """Flow.apply(target, padding=...) -- the kernels read the un-padded flow through a window (zeros / replicate, mask False
+    outside: ofl_warp_bwd_win_f32, ofl_splat_tiled_win_f32) -- against the same call on a materialised padded flow
+    (`Flow.pad`, the reference's own route, flow_class.py:901-913): bit-identical values and masks, cut or not, with and
+    without `consider_mask`, tensor and Flow targets."""
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import _native
+    n, c, hp, wp = shape
+    h, w = hp - pad[0] - pad[1], wp - pad[2] - pad[3]
+    g = torch.Generator().manual_seed(21)
+    f = _smooth(n, h, w, 3.0, 5, dev)
+    f[0, :, : h // 4] = 0                                            # zero-flow block (occlusion / un-occlude rule)
+    m = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    img = (torch.rand(n, c, hp, wp, generator=g) * 200).to(dev)
+    tm = (torch.rand(n, hp, wp, generator=g) > 0.1).to(dev)
+    fl = ofl.Flow(f, ref, m)
+    padded = fl.pad(pad, mode='constant' if ref == 't' else 'replicate')
+    _native.collect_splat_stats = True
+    for cut in (True, False):
+        for cons in (True, False):
+            got = fl.apply(img, target_mask=tm.clone(), return_valid_area=True, consider_mask=cons, padding=pad, cut=cut)
+            exact = ref == 't' or _native._last_splat_stats.cpu().tolist()[:2] == [0, 0]
+            exp = padded.apply(img, target_mask=tm.clone(), return_valid_area=True, consider_mask=cons)
+            if cut:
+                exp = tuple(e[..., pad[0]:pad[0] + h, pad[2]:pad[2] + w] for e in exp)
+            assert torch.equal(got[1], exp[1]), (cut, cons)
+            if exact:
+                assert torch.equal(got[0], exp[0]), (cut, cons)
+            else:
+                np.testing.assert_allclose(got[0].cpu().numpy(), exp[0].cpu().numpy(), rtol=3e-5, atol=3e-3)
+    tf = ofl.Flow(_smooth(n, hp, wp, 2.0, 6, dev), ref, tm)
+    got = fl.apply(tf, padding=pad, cut=False)
+    exp = padded.apply(tf)
+    assert torch.equal(got.vecs, exp.vecs) and torch.equal(got.mask, exp.mask)
+    got8 = fl.apply((img).to(torch.uint8), padding=pad)              # integer targets: rounded in the kernel
+    exp8 = padded.apply((img).to(torch.uint8))[..., pad[0]:pad[0] + h, pad[2]:pad[2] + w]
+    assert torch.equal(got8, exp8)
