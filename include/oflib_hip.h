@@ -271,15 +271,45 @@ int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
                        int32_t* flags, int32_t n, int32_t h, int32_t w, void* stream);
 
 /*
- * fp16-stored flows (BASELINE config 5): dst[N,2,H,W] fp32 = (float) src, flags[n] |= flag word of that image under
- * `mask` -- the reference's entry conversion `vecs.float()` (utils.py:95,118) and its validation in ONE pass (12 B/px
- * instead of 12 + 9).  The caller zeroes `flags`.  src [*,2,H,W] fp16 with H*W % 4 == 0 and 8-byte aligned planes, dst
- * 16-byte aligned, mask planes 4-byte aligned; otherwise OFL_E_UNSUPPORTED (convert, then ofl_flow_flags_f32).
+ * fp16-STORED FLOWS (BASELINE config 5; SURVEY.md section 8b "fp16-I/O variants").  The reference up-casts every flow to
+ * fp32 on entry (utils.py:95, 118) and computes in fp32; so do these entry points -- the up-conversion is exact and happens
+ * in registers, the arithmetic is the fp32 arithmetic of the plain entry points, and the results are bit-identical to
+ * feeding them the up-cast tensors -- but the fp16 planes are read as they are (half the operand bytes, no conversion pass).
+ *
+ *   ofl_flow_from_f16     validation of an fp16-stored flow: flags[n] |= flag word under `mask` (caller zeroes flags) and,
+ *                         when dst != NULL, dst[N,2,H,W] fp32 = (float) src in the same pass (12 instead of 12 + 9 B/px).
+ *                         dst == NULL: flags only (5 B/px) -- the flow stays in fp16.  src [*,2,H,W] fp16, H*W % 4 == 0,
+ *                         8-byte aligned planes (dst 16-byte, mask 4-byte aligned); otherwise OFL_E_UNSUPPORTED.
+ *   ofl_splat_tiled_f16   ofl_splat_tiled_f32 for a flow splatted by a flow (switch_ref, invert, Flow.apply(Flow) with 's'
+ *                         flows): warper flow_f16 [*,2,H,W] and data data_f16 [*,2,H,W] both fp16; dst [N,2,H,W] fp32, or
+ *                         fp16 when dst_is_f16 (an OPTION for fp16 pipelines: one round-to-nearest-even at the store, and
+ *                         dst_flags then describe the stored values; never the default -- the reference returns fp32).
+ *                         Same gather kernels, same bit-exact sums, same workspace / fallback contract.
+ *   ofl_warp_bwd_h_f32    ofl_warp_bwd_f32 with a 2-channel SOURCE stored in fp16 (the `flow` operand of combine_with mode
+ *                         1 't', flow_class.py:1763), optionally minus an fp32 src_b; fp32 warper, fp32 dst, valid mask.
+ *                         Staged kernel only (W >= 4, H >= 2, H*W < 2^24), else OFL_E_UNSUPPORTED.
  */
 int ofl_flow_from_f16(const void* src_f16, int64_t src_bs,
                       const uint8_t* mask, int64_t mask_bs,
                       float* dst, int32_t* flags,
                       int32_t n, int32_t h, int32_t w, void* stream);
+int ofl_splat_tiled_f16(const void* flow_f16, int64_t flow_bs, float flow_sign,
+                        const void* data_f16, int64_t data_bs, float data_sign,
+                        const uint8_t* weight_mask, int64_t weight_mask_bs,
+                        const uint8_t* chan_mask_a, int64_t chan_mask_a_bs,
+                        const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+                        int32_t with_mask_chan, int32_t occlude,
+                        void* dst, int32_t dst_is_f16, uint8_t* valid, int32_t* dst_flags,
+                        int32_t* workspace, int64_t workspace_ints, float* accum_fallback,
+                        int32_t n, int32_t h, int32_t w, void* stream);
+int ofl_warp_bwd_h_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                       const void* src_f16, int64_t src_bs,
+                       const float* src_b, int64_t src_b_bs,
+                       const uint8_t* src_mask, int64_t src_mask_bs,
+                       const uint8_t* flow_mask, int64_t flow_mask_bs,
+                       float* dst, uint8_t* valid,
+                       int32_t n, int32_t h, int32_t w, void* stream);
+
 
 
 /* ------------------------------------------------------------------------------------------------

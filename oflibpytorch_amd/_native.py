@@ -15,14 +15,15 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 19              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 20              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
 _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
-            "ofl_flow_extents_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32")
+            "ofl_flow_extents_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
+            "ofl_warp_bwd_h_f32")
 _lib = None
 
 
@@ -79,6 +80,8 @@ def load_library(path: str = None):
     lib.ofl_sample_pts_f32.argtypes = [p, i64, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
+    lib.ofl_splat_tiled_f16.argtypes = [p, i64, f32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, i32, p, p, p, i64, p, i32, i32, i32, p]
+    lib.ofl_warp_bwd_h_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, p, p, i32, i32, i32, p]
     lib.ofl_warp_bwd_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, p, i64, p, i64, p, p, i32, i32, i32, i32, i32, p]
     lib.ofl_splat_tiled_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                             p, i64, p, i32, i32, i32, i32, i32, p]
@@ -180,6 +183,17 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
     """Flag word per batch element (bits: FLAG_*), int32 tensor [N] on the HIP device (no host sync)."""
     lib, dev = load_library(), device(vecs, mask)
     n, _, h, w = vecs.shape
+    if vecs.dtype == torch.float16 and vecs.device.type == 'cuda':       # fp16 storage: flags without an fp32 copy (5 B/px)
+        with _on(dev):
+            v, vbs = _planes(vecs.detach(), dev, torch.float16, n, "flow")
+            if vbs != 0 or n == 1:
+                m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+                flags = torch.zeros(n, dtype=torch.int32, device=dev)
+                rc = lib.ofl_flow_from_f16(_ptr(v), vbs, _ptr(m), mbs, None, _ptr(flags), n, h, w, _stream(dev))
+                if rc != -4:
+                    _check(rc, "ofl_flow_from_f16")
+                    return flags
+        vecs = vecs.float()
     with _on(dev):
         v, vbs = _planes(vecs.detach(), dev, torch.float32, n, "flow")
         m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
@@ -215,6 +229,16 @@ def warp_bwd(flow, src, **kw):
     """G-family primitive; see `_warp_bwd_raw` for the arguments.  When autograd is recording and the flow, the source,
     `src_b` or the addend requires a gradient, the launch goes through `_autograd.WarpFn` (backward kernels:
     ofl_warp_bwd_grad_f32) -- the reference's outputs are differentiable wrt flow and target (utils.py:555)."""
+    if flow.dtype == torch.float16:
+        flow = flow.float()                       # (the warper itself is read as fp32: exact up-conversion, utils.py:118)
+    if src.dtype == torch.float16:
+        res = None if _wants_grad(flow, src, kw.get("addend"), kw.get("src_b")) else _warp_bwd_half_src(flow, src, **kw)
+        if res is not None:
+            return res
+        src = src.float()
+    for key in ("addend", "src_b"):
+        if kw.get(key) is not None and kw[key].dtype == torch.float16:
+            kw[key] = kw[key].float()
     if _wants_grad(flow, src, kw.get("addend"), kw.get("src_b")):
         from . import _autograd
         return _autograd.warp(flow, src, **kw)
@@ -225,11 +249,89 @@ def warp_bwd(flow, src, **kw):
 def splat_fwd(flow, data, **kw):
     """P-family primitive; see `_splat_fwd_raw`.  Differentiable wrt flow (or xs, ys), data and data_b through
     `_autograd.SplatFn` (ofl_splat_grad_f32) when autograd is recording (utils.py:1079-1080, 1167)."""
+    out_half = bool(kw.pop("out_half", False))
+    half_f, half_d = flow is not None and flow.dtype == torch.float16, data.dtype == torch.float16
+    if half_f or half_d:
+        res = None
+        if half_f and half_d and not _wants_grad(flow, data, kw.get("data_b")):
+            res = _splat_fwd_half(flow, data, out_half=out_half, **kw)
+        if res is not None:
+            return res
+        flow = flow.float() if half_f else flow          # (exact up-conversion, utils.py:118)
+        data = data.float() if half_d else data
+    if kw.get("data_b") is not None and kw["data_b"].dtype == torch.float16:
+        kw["data_b"] = kw["data_b"].float()
     if _wants_grad(flow, data, kw.get("xs"), kw.get("ys"), kw.get("data_b")):
         from . import _autograd
         return _autograd.splat(flow, data, **kw)
     with _on(device(flow, data, kw.get("xs"))):
         return _splat_fwd_raw(flow, data, **kw)
+
+
+def _warp_bwd_half_src(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None, a_sign=1.0,
+                       g_sign=1.0, round_mode=ROUND_NONE, want_flags=False, want_src_flags=False, want_dst_flags=False,
+                       src_b=None, out_uint8=False):
+    """ofl_warp_bwd_h_f32: a flow stored in fp16 gathered straight from its halves (2 channels, valid mask wanted, optional
+    fp32 src_b).  None when this launch is not of that kind: the caller up-converts and takes the fp32 kernel."""
+    c, h, w = src.shape[1:]
+    if not (c == 2 and want_valid and addend is None and round_mode == ROUND_NONE and not want_flags and not want_dst_flags
+            and src.device.type == 'cuda'):
+        return None
+    lib, dev = load_library(), device(flow, src)
+    n = max(flow.shape[0], src.shape[0], 1 if src_b is None else src_b.shape[0], 1 if src_mask is None else src_mask.shape[0],
+            1 if flow_mask is None else flow_mask.shape[0])
+    with _on(dev):
+        f, fbs = _planes(flow, dev, torch.float32, n, "flow")
+        s16, sbs = _planes(src, dev, torch.float16, n, "source")
+        s2, s2bs = (None, 0) if src_b is None else _planes(src_b, dev, torch.float32, n, "source")
+        sm, smbs = (None, 0) if src_mask is None else _planes(src_mask, dev, torch.bool, n, "source mask")
+        fm, fmbs = (None, 0) if flow_mask is None else _planes(flow_mask, dev, torch.bool, n, "flow mask")
+        dst = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+        valid = torch.empty((n, h, w), dtype=torch.bool, device=dev)
+        rc = lib.ofl_warp_bwd_h_f32(_ptr(f), fbs, float(flow_sign), _ptr(s16), sbs, _ptr(s2), s2bs, _ptr(sm), smbs, _ptr(fm), fmbs,
+                                    _ptr(dst), _ptr(valid), n, h, w, _stream(dev))
+        if rc == -4:
+            return None
+        _check(rc, "ofl_warp_bwd_h_f32")
+    return dst, valid, None, None
+
+
+def _splat_fwd_half(flow, data, *, out_half=False, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None,
+                    chan_mask_a=None, chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False,
+                    round_mode=ROUND_NONE, want_mask_chan=False, want_dst_flags=False, data_b=None):
+    """ofl_splat_tiled_f16: warper and data both stored in fp16 (a flow splatted by a flow: switch_ref / invert /
+    Flow.apply(Flow) on fp16 storage); fp32 or (out_half) fp16 result.  None when the launch is not of that kind."""
+    c, h, w = data.shape[1:]
+    if not (c == 2 and xs is None and data_b is None and round_mode == ROUND_NONE and not want_density and not want_warped
+            and not want_mask_chan and w >= 4 and _splat_path != 1 and flow.device.type == 'cuda' and data.device.type == 'cuda'):
+        return None
+    lib, dev = load_library(), device(flow, data)
+    n = max(data.shape[0], flow.shape[0], 1 if weight_mask is None else weight_mask.shape[0],
+            1 if chan_mask_a is None else chan_mask_a.shape[0], 1 if chan_mask_b is None else chan_mask_b.shape[0])
+    with _on(dev):
+        f, fbs = _planes(flow, dev, torch.float16, n, "flow")
+        d, dbs = _planes(data, dev, torch.float16, n, "data")
+        wm, wmbs = (None, 0) if weight_mask is None else _planes(weight_mask, dev, torch.bool, n, "mask")
+        ca, cabs = (None, 0) if chan_mask_a is None else _planes(chan_mask_a, dev, torch.bool, n, "mask")
+        cb, cbbs = (None, 0) if chan_mask_b is None else _planes(chan_mask_b, dev, torch.bool, n, "mask")
+        mch = 1 if want_valid else 0
+        dst = torch.empty((n, 2, h, w), dtype=torch.float16 if out_half else torch.float32, device=dev)
+        valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
+        dflags = torch.empty((n,), dtype=torch.int32, device=dev) if want_dst_flags else None
+        ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
+        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        rc = lib.ofl_splat_tiled_f16(_ptr(f), fbs, float(flow_sign), _ptr(d), dbs, float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs,
+                                     _ptr(cb), cbbs, mch, 1 if occlude else 0, _ptr(dst), 1 if out_half else 0, _ptr(valid),
+                                     _ptr(dflags), _ptr(ws), ws.numel(), _ptr(accum), n, h, w, _stream(dev))
+        if rc == -4:
+            return None
+        _check(rc, "ofl_splat_tiled_f16")
+        if collect_splat_stats:
+            global _last_splat_stats
+            _last_splat_stats = ws[:8].clone()
+    if want_dst_flags:
+        return dst, valid, None, None, dflags
+    return dst, valid, None, None
 
 
 def _warp_bwd_raw(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,

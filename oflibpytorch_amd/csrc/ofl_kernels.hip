@@ -162,6 +162,19 @@ __device__ __forceinline__ void st4(uint8_t* p, f4 v) {            // (values al
     st32(p, (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24));
 }
 __device__ __forceinline__ void st2(float* p, f2 v) { *reinterpret_cast<f2u*>(p) = v; }
+// flows stored in fp16 (BASELINE config 5): 4 / 2 / 1 values <-> floats.  The up-conversion is exact (the reference's
+// `vecs.float()`, utils.py:95,118); a store rounds to nearest even (an OPTION of the fp16 entry points, never the default)
+typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(2)));
+typedef _Float16 h2u __attribute__((ext_vector_type(2), aligned(2)));
+__device__ __forceinline__ f4 ld4(const _Float16* p) { const h4u v = *reinterpret_cast<const h4u*>(p); return (f4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+__device__ __forceinline__ f2 ld2(const _Float16* p) { const h2u v = *reinterpret_cast<const h2u*>(p); return (f2){(float)v[0], (float)v[1]}; }
+__device__ __forceinline__ float ld1(const _Float16* p) { return (float)*p; }
+__device__ __forceinline__ void st4(_Float16* p, f4 v) { *reinterpret_cast<h4u*>(p) = (h4u){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; }
+__device__ __forceinline__ void st2(_Float16* p, f2 v) { *reinterpret_cast<h2u*>(p) = (h2u){(_Float16)v[0], (_Float16)v[1]}; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(_Float16* p, float v) { *p = (_Float16)v; }
+template <typename T> __device__ __forceinline__ float stored_as(float v) { return v; }          // the value a store of type T keeps
+template <> __device__ __forceinline__ float stored_as<_Float16>(float v) { return (float)(_Float16)v; }
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return reinterpret_cast<const U16u*>(p)->v; }
 __device__ __forceinline__ void st32(uint8_t* p, uint32_t v) { reinterpret_cast<U32u*>(p)->v = v; }
@@ -782,7 +795,7 @@ __device__ __forceinline__ uint32_t sp_win(const SP& s, int x, int y, bool& insi
     return (uint32_t)(min(max(fy, 0), s.fh - 1) * s.fw + min(max(fx, 0), s.fw - 1));
 }
 
-template <int CT>
+template <int CT, typename TF = float>
 __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
     // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid that leaves at once when no
     // image of the pass is flagged; otherwise one block per tile, XCD-aware
@@ -800,8 +813,8 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
     const int planes = 1 + C + (p.with_mask_chan ? 1 : 0);
     const float wmax = (float)(w - 1), hmax = (float)(h - 1);
 
-    const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
-    const float* __restrict__ db = p.data + n * p.data_bs;
+    const TF* __restrict__ fu = p.flow ? reinterpret_cast<const TF*>(p.flow) + n * p.flow_bs : nullptr;
+    const TF* __restrict__ db = reinterpret_cast<const TF*>(p.data) + n * p.data_bs;
     const float* __restrict__ dbb = p.data_b ? p.data_b + n * p.data_b_bs : nullptr;
     const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
     const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
@@ -819,7 +832,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
         const int64_t fpix = p.fw != 0 ? (int64_t)sp_win(p, x, y, inside) : pix;       // (padded apply: flow-geometry offset)
         const int64_t fhw = p.fw != 0 ? (int64_t)p.fh * p.fw : hw;
         if (fu) {
-            const float u = fu[fpix], v = fu[fhw + fpix];
+            const float u = ld1(fu + fpix), v = ld1(fu + fhw + fpix);
             xv = p.flow_sign * u + (float)x;  // get_flow_endpoints utils.py:1056-1057
             yv = p.flow_sign * v + (float)y;
             if (p.occlude) zero = (u < kZeroThr) && (u > -kZeroThr) && (v < kZeroThr) && (v > -kZeroThr);
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
 #pragma unroll
                 for (int ch = 0; ch < (CT ? CT : 1); ++ch)
                     for (int cc = ch; cc < C; cc += (CT ? C : 1))
-                        atomicAdd(&acc[(int64_t)(1 + cc) * hw + pos], wgt * (p.data_sign * (dbb ? db[(int64_t)cc * hw + pix] - dbb[(int64_t)cc * hw + pix] : db[(int64_t)cc * hw + pix])));
+                        atomicAdd(&acc[(int64_t)(1 + cc) * hw + pos], wgt * (p.data_sign * (dbb ? ld1(db + (int64_t)cc * hw + pix) - dbb[(int64_t)cc * hw + pix] : ld1(db + (int64_t)cc * hw + pix))));
                 // mask channel: the reference accumulates wgt * mval next to the density.  All contributors of a
                 // pixel being valid is the common case and must give ratio == 1 exactly, whatever order the
                 // atomics land in -- so accumulate the INVALID weight instead and form den - inv in pass 2.
@@ -870,7 +883,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
 // ------------------------------------------------------------------------------------------------
 // forward splat, pass 2 (ofl_splat_finalize_f32)
 // ------------------------------------------------------------------------------------------------
-template <int CT>
+template <int CT, typename TF = float, typename TO = float>
 __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p) {
     // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid that leaves at once when no
     // image of the pass is flagged; otherwise one block per tile, XCD-aware
@@ -887,14 +900,14 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
     const int C = CT ? CT : p.c;
     const int planes = 1 + C + (p.with_mask_chan ? 1 : 0);
 
-    const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
-    const float* __restrict__ db = p.data + n * p.data_bs;
+    const TF* __restrict__ fu = p.flow ? reinterpret_cast<const TF*>(p.flow) + n * p.flow_bs : nullptr;
+    const TF* __restrict__ db = reinterpret_cast<const TF*>(p.data) + n * p.data_bs;
     const float* __restrict__ dbb = p.data_b ? p.data_b + n * p.data_b_bs : nullptr;
     const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
     const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
     const float* __restrict__ acc = p.accum + (int64_t)n * planes * hw;
-    float* __restrict__ dst = p.dst + (int64_t)n * p.dst_bs;
+    TO* __restrict__ dst = reinterpret_cast<TO*>(p.dst) + (int64_t)n * p.dst_bs;
     int dflags = 0;
 
 #pragma unroll
@@ -910,7 +923,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
         const int64_t fpix = p.fw != 0 ? (int64_t)sp_win(p, x, y, inside) : pix;       // (padded apply: flow-geometry offset)
         const int64_t fhw = p.fw != 0 ? (int64_t)p.fh * p.fw : hw;
         if (p.occlude && fu && !warped) {                  // un-occlude utils.py:1198-1203
-            const float u = fu[fpix], v = fu[fhw + fpix];
+            const float u = ld1(fu + fpix), v = ld1(fu + fhw + fpix);
             const bool zero = (u < kZeroThr) && (u > -kZeroThr) && (v < kZeroThr) && (v > -kZeroThr);
             const bool wm = wmk ? (inside && wmk[fpix] != 0) : true;
             fill = zero && wm;
@@ -919,9 +932,9 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 #pragma unroll
         for (int ch = 0; ch < (CT ? CT : 1); ++ch)
             for (int cc = ch; cc < C; cc += (CT ? C : 1)) {
-                float val = fill ? p.data_sign * (dbb ? db[(int64_t)cc * hw + pix] - dbb[(int64_t)cc * hw + pix] : db[(int64_t)cc * hw + pix]) : acc[(int64_t)(1 + cc) * hw + pix] / dcl;
-                val = apply_round(val, p.round_mode);
-                dst[(int64_t)cc * hw + pix] = val;
+                float val = fill ? p.data_sign * (dbb ? ld1(db + (int64_t)cc * hw + pix) - dbb[(int64_t)cc * hw + pix] : ld1(db + (int64_t)cc * hw + pix)) : acc[(int64_t)(1 + cc) * hw + pix] / dcl;
+                val = stored_as<TO>(apply_round(val, p.round_mode));
+                st1(dst + (int64_t)cc * hw + pix, val);
                 if (cc < 2) uv[cc] = val;
             }
         if (p.density) p.density[(int64_t)n * hw + pix] = den;
@@ -1042,8 +1055,9 @@ __device__ __forceinline__ void sp_finish_src(const SP& s, int sx4, int sy, bool
     }
 }
 
-template <typename SP>
+template <typename TF = float, typename SP>
 __device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy, bool inimg, uint32_t pix, uint32_t hw, SpSrc& q) {
+    const TF* __restrict__ flw = reinterpret_cast<const TF*>(s.flow);     // (fp16 variants: the flow planes hold halves)
     f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     uint32_t wm4 = 0x01010101u;
     // the last group of a row of an image whose width is not a multiple of 4: fetch the last whole group and rotate
@@ -1058,14 +1072,14 @@ __device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy,
         for (int k = 0; k < 4; ++k) {
             bool inside;
             const uint32_t off = sp_win(s, min(sx4 + k, s.w - 1), sy, inside);
-            a[k] = s.flow[n * s.flow_bs + off]; b[k] = s.flow[n * s.flow_bs + fhw + off];
+            a[k] = ld1(flw + n * s.flow_bs + off); b[k] = ld1(flw + n * s.flow_bs + fhw + off);
             const bool m = s.weight_mask ? (inside && s.weight_mask[n * s.weight_mask_bs + off] != 0) : true;
             wm4 |= (uint32_t)m << (8 * k);
         }
     } else if (inimg) {
         if (s.flow) {
-            a = ld4(s.flow + n * s.flow_bs + pe);
-            b = ld4(s.flow + n * s.flow_bs + hw + pe);
+            a = ld4(flw + n * s.flow_bs + pe);
+            b = ld4(flw + n * s.flow_bs + hw + pe);
         } else {
             a = ld4(s.xs + n * s.xy_bs + pe);
             b = ld4(s.ys + n * s.xy_bs + pe);
@@ -1088,6 +1102,7 @@ __device__ __forceinline__ int row_pk_max_dpp(int v) {
 
 constexpr int kBinLocal = 64;   // destination tiles one 64 x 16 source region aggregates in LDS (more: straight to the global counters)
 
+template <typename TF>
 __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     __shared__ int red[4][2];
     __shared__ int lcount[kBinLocal], lbase[kBinLocal];
@@ -1101,7 +1116,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     const int sx4 = rx * (4 * kSubW) + sub * kSubW + c4 * 4, sy = ry * (4 * kSubH) + wave * kSubH + r;
     const bool inimg = (sx4 < w) && (sy < h);
     SpSrc q;
-    sp_load_src(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
+    sp_load_src<TF>(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
     if (tid < kBinLocal) lcount[tid] = 0;
     // destination pixels the four corners of this thread's end points touch (clamped corners carry weight 0,
     // utils.py:1106-1111: they touch nothing)
@@ -1240,8 +1255,9 @@ struct SpTile {
     bool fill_ok[2];         // un-occlude fill candidates (utils.py:1198-1203)
 };
 
-template <typename SP>
+template <typename TF = float, typename SP>
 __device__ __forceinline__ void sp_tile_setup(const SP& s, int tx, int ty, int n, SpTile& t) {
+    const TF* __restrict__ flw = reinterpret_cast<const TF*>(s.flow);
     const int tid = threadIdx.x, w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
     t.n = n; t.dx0 = tx * kSpTW; t.dy0 = ty * kSpTH;
@@ -1264,12 +1280,12 @@ __device__ __forceinline__ void sp_tile_setup(const SP& s, int tx, int ty, int n
             for (int k = 0; k < 2; ++k) {
                 bool inside;
                 const uint32_t off = sp_win(s, x2 + k, min(y, h - 1), inside);
-                a[k] = s.flow[n * s.flow_bs + off]; b[k] = s.flow[n * s.flow_bs + fhw + off];
+                a[k] = ld1(flw + n * s.flow_bs + off); b[k] = ld1(flw + n * s.flow_bs + fhw + off);
                 const bool m = s.weight_mask ? (inside && s.weight_mask[n * s.weight_mask_bs + off] != 0) : true;
                 wm2 |= (uint32_t)m << (8 * k);
             }
         } else {
-            a = ld2(s.flow + n * s.flow_bs + t.pix); b = ld2(s.flow + n * s.flow_bs + hw + t.pix);
+            a = ld2(flw + n * s.flow_bs + t.pix); b = ld2(flw + n * s.flow_bs + hw + t.pix);
             if (s.weight_mask) wm2 = ld16(s.weight_mask + n * s.weight_mask_bs + t.pix);
         }
 #pragma unroll
@@ -1280,7 +1296,7 @@ __device__ __forceinline__ void sp_tile_setup(const SP& s, int tx, int ty, int n
 
 // normalise, masks, un-occlude fill, store (tot: density, channels, mask channel).  EVERY thread of the block calls it
 // (`mine`: this thread's row is being finalized), so that lane pairs can exchange their halves.
-template <int NC, bool MCH, typename SP>
+template <int NC, bool MCH, typename TF = float, typename TO = float, typename SP>
 __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const float (&tot)[2][1 + NC + (MCH ? 1 : 0)], bool mine, int& dflags) {
     const int n = t.n, tid = threadIdx.x;
     const uint32_t hw = (uint32_t)(s.h * s.w);
@@ -1289,7 +1305,8 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
     // thread and tile, 2 GB of scratch writes per launch (rocprofv3 WRITE_SIZE: profiles/r2_splat_gather_first_cut_pmc.txt)
     uint32_t pix = t.pix;
     asm volatile("" : "+v"(pix));
-    const float* __restrict__ db = s.data + n * s.data_bs;
+    static_assert(std::is_same<TO, float>::value || NC == 2, "fp16 outputs are flows");
+    const TF* __restrict__ db = reinterpret_cast<const TF*>(s.data) + n * s.data_bs;
     const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
     f2 den2, out[NC], mch2;
     uint32_t warped2 = 0, valid2 = 0;
@@ -1303,7 +1320,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
         warped2 |= (uint32_t)warped << (8 * k);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            out[c][k] = apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? db[c * hw + pix + k] - dbb[c * hw + pix + k] : db[c * hw + pix + k]) : tot[k][1 + c] / dcl, s.round_mode);
+            out[c][k] = stored_as<TO>(apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)) : tot[k][1 + c] / dcl, s.round_mode));
         if (MCH) {
             float mv;
             if (fill) {
@@ -1327,7 +1344,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
         for (int k = 0; k < 2; ++k)
             if (k == 1 || !t.solo) dflags |= flag_bits(out[0][k], out[NC - 1][k], MCH ? ((valid2 >> (8 * k)) & 1u) != 0u : true);
     }
-    float* __restrict__ dst = s.dst + (int64_t)n * s.dst_bs;
+    TO* __restrict__ dst = reinterpret_cast<TO*>(s.dst) + (int64_t)n * s.dst_bs;
     if (t.wide) {
         // lanes 2j / 2j + 1 own pixels 4j .. 4j + 1 / 4j + 2 .. 4j + 3 of one row: the even lane stores the even planes of
         // the 4-pixel group, the odd lane the odd ones -- 16 bytes per lane instead of 8 (partial-line stores are the
@@ -1335,11 +1352,11 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
         const bool odd = (tid & 1) != 0;
         const uint32_t pq = pix - (odd ? 2u : 0u);               // first pixel of the group
         // plane A goes out through the even lane, plane B through the odd one; each gets the partner's half by DPP
-        auto emit = [&](const f2& pa, float* ptra, bool a_on, const f2& pb, float* ptrb, bool b_on) {
+        auto emit = [&](const f2& pa, auto* ptra, bool a_on, const f2& pb, auto* ptrb, bool b_on) {
             const f2 give = odd ? pa : pb, keep = odd ? pb : pa;
             const f2 got = {swap1(give[0]), swap1(give[1])};
             const f4 v = odd ? (f4){got[0], got[1], keep[0], keep[1]} : (f4){keep[0], keep[1], got[0], got[1]};
-            if (mine && (odd ? b_on : a_on)) st4((odd ? ptrb : ptra) + pq, v);
+            if (mine && (odd ? b_on : a_on)) { if (odd) st4(ptrb + pq, v); else st4(ptra + pq, v); }
         };
         float* dpl = s.density ? s.density + (int64_t)n * hw : nullptr;
         float* mpl = (MCH && s.mask_chan) ? s.mask_chan + (int64_t)n * hw : nullptr;
@@ -1370,7 +1387,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
             if (MCH && s.mask_chan) st2(s.mask_chan + (int64_t)n * hw + pix, mch2);
         } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) dst[c * hw + pix + 1] = out[c][1];
+            for (int c = 0; c < NC; ++c) st1(dst + c * hw + pix + 1, out[c][1]);
             if (s.density) s.density[(int64_t)n * hw + pix + 1] = den2[1];
             if (s.warped) s.warped[(int64_t)n * hw + pix + 1] = (uint8_t)(warped2 >> 8);
             if (MCH && s.valid) s.valid[(int64_t)n * hw + pix + 1] = (uint8_t)(valid2 >> 8);
@@ -1380,10 +1397,10 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
 }
 
 // data (x data_sign applied later) and mask-channel bits of one 4-pixel group of a source subtile
-template <int NC, bool MCH, typename SP>
+template <int NC, bool MCH, typename TF = float, typename SP>
 __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy, uint32_t hw, f4 (&dat)[NC], uint32_t& mc4) {
     const int w = s.w;
-    const float* __restrict__ db = s.data + n * s.data_bs;
+    const TF* __restrict__ db = reinterpret_cast<const TF*>(s.data) + n * s.data_bs;
     const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
     const int wrem = w & 3;
     const bool edge = wrem != 0 && sx4 > w - 4;                   // row-end group: last whole group, rotated
@@ -1425,7 +1442,7 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
 typedef const GatherParams __attribute__((address_space(4))) GatherParamsK;
 #define OFL_OPAQUE_S(ptr_) asm volatile("" : "+s"(ptr_))
 
-template <int NC, bool MCH>
+template <int NC, bool MCH, typename TF = float, typename TO = float>
 __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const GatherParams p_by_value_unused) {
     GatherParamsK* pp = (GatherParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
@@ -1462,7 +1479,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     const int nlist = min(p.cnt[tile], kBinCap);
     OFL_OPAQUE_S(pp);
     SpTile t;
-    sp_tile_setup(s, tx, ty, n, t);
+    sp_tile_setup<TF>(s, tx, ty, n, t);
     const int dx0 = t.dx0, dy0 = t.dy0, ly = t.ly, lx2 = t.lx2;
     int dflags = 0;
     const int sl = tid & 15, srow = sl >> 2, sc4 = sl & 3;
@@ -1534,7 +1551,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
                 sx4[u] = (int)subx * kSubW + sc4 * 4; sy[u] = (int)suby * kSubH + srow;
                 const bool in = have && (sx4[u] < w) && (sy[u] < h);
-                sp_load_src(s, n, sx4[u], sy[u], in, (uint32_t)(sy[u] * w + sx4[u]), hw, q[u]);
+                sp_load_src<TF>(s, n, sx4[u], sy[u], in, (uint32_t)(sy[u] * w + sx4[u]), hw, q[u]);
                 inb[u] = in;
             }
             f4 dat[2][NC];
@@ -1543,7 +1560,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             for (int u = 0; u < 2; ++u) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
-                if (inb[u]) sp_load_data<NC, MCH>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
+                if (inb[u]) sp_load_data<NC, MCH, TF>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) process(q[u], sx4[u], sy[u], dat[u], mc4[u], r0, r1);
@@ -1690,7 +1707,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                     for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
             }
             OFL_OPAQUE_S(pp);
-            sp_finalize<NC, MCH>(s, t, tot, mine, dflags);
+            sp_finalize<NC, MCH, TF, TO>(s, t, tot, mine, dflags);
             if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
         }
         if (!redo) break;
@@ -1716,7 +1733,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
 // (plane 0 density, then the data channels; the mask channel accumulates the INVALID weight, so that an all-valid pixel is
 // exactly 1 in any order).  Tolerance instead of bit-exactness for these tiles; masks stay exact.  A persistent grid walks
 // the list of such tiles the gather kernel left (usually empty: the kernel ends at once).
-template <int NC, bool MCH>
+template <int NC, bool MCH, typename TF = float, typename TO = float>
 __global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const GatherParams p) {
     constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0);
     __shared__ float acc[(1 + NCH) * kPx];
@@ -1736,7 +1753,7 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const Gathe
         const uint32_t* __restrict__ lst = p.list + dtile * kBinCap;
         const int nlist = min(p.cnt[dtile], kBinCap);
         SpTile t;
-        sp_tile_setup(s, tx, ty, n, t);
+        sp_tile_setup<TF>(s, tx, ty, n, t);
         __syncthreads();
         for (int i = tid; i < (1 + NCH) * kPx; i += kSpNT2) acc[i] = 0.0f;
         __syncthreads();
@@ -1749,12 +1766,12 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const Gathe
             const int sx4 = (int)subx * kSubW + sc4 * 4, sy = (int)suby * kSubH + srow;
             const bool in = have && (sx4 < w) && (sy < h);
             SpSrc q;
-            sp_load_src(s, n, sx4, sy, in, (uint32_t)(sy * w + sx4), hw, q);
+            sp_load_src<TF>(s, n, sx4, sy, in, (uint32_t)(sy * w + sx4), hw, q);
             f4 dat[NC];
             uint32_t mc4 = 0x01010101u;
 #pragma unroll
             for (int c = 0; c < NC; ++c) dat[c] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (q.on != 0u) sp_load_data<NC, MCH>(s, n, sx4, sy, hw, dat, mc4);
+            if (q.on != 0u) sp_load_data<NC, MCH, TF>(s, n, sx4, sy, hw, dat, mc4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!((q.on >> k) & 1u)) continue;
@@ -1787,7 +1804,7 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const Gathe
             for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
             if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];      // density - invalid weight
         }
-        sp_finalize<NC, MCH>(s, t, tot, t.inimg, dflags);
+        sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg, dflags);
         if (NC == 2 && s.dst_flags) {
             dflags = wave_or_flags(dflags);
             if (lane == 0) flag_or(&s.dst_flags[n], dflags);
@@ -1884,7 +1901,7 @@ __global__ __launch_bounds__(256) void flow_f16_kernel(const _Float16* __restric
             if (i < hw4) {
                 const f4 u = {(float)a[r][0], (float)a[r][1], (float)a[r][2], (float)a[r][3]};
                 const f4 v = {(float)b[r][0], (float)b[r][1], (float)b[r][2], (float)b[r][3]};
-                reinterpret_cast<f4*>(du)[i] = u; reinterpret_cast<f4*>(du + hw)[i] = v;
+                if (dst) { reinterpret_cast<f4*>(du)[i] = u; reinterpret_cast<f4*>(du + hw)[i] = v; }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) f |= flag_bits(u[k], v[k], ((m4[r] >> (8 * k)) & 0xffu) != 0u);
             }
@@ -2006,16 +2023,22 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 }
 
 
-template <int NC, bool MCH>
+template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((splat_gather_kernel<NC, MCH>), dim3(grid), dim3(kSpNT2), 0, st, gp);
-    hipLaunchKernelGGL((splat_tile_fallback_kernel<NC, MCH>), dim3(512), dim3(kSpNT2), 0, st, gp);
+    hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    hipLaunchKernelGGL((splat_tile_fallback_kernel<NC, MCH, TF, TO>), dim3(512), dim3(kSpNT2), 0, st, gp);
     return (int)hipGetLastError();
 }
 
 template <int NC>
 int launch_splat_gather(const GatherParams& gp, unsigned grid, hipStream_t st) {
     return gp.s.with_mask_chan ? launch_splat_gather2<NC, true>(gp, grid, st) : launch_splat_gather2<NC, false>(gp, grid, st);
+}
+
+// fp16-stored flows as warper AND data (2 channels): elem 1 = fp32 outputs, 2 = fp16 outputs
+int launch_splat_gather_half(const GatherParams& gp, unsigned grid, hipStream_t st, int elem) {
+    if (gp.s.with_mask_chan) return elem == 2 ? launch_splat_gather2<2, true, _Float16, _Float16>(gp, grid, st) : launch_splat_gather2<2, true, _Float16, float>(gp, grid, st);
+    return elem == 2 ? launch_splat_gather2<2, false, _Float16, _Float16>(gp, grid, st) : launch_splat_gather2<2, false, _Float16, float>(gp, grid, st);
 }
 
 }  // namespace
@@ -2025,7 +2048,7 @@ int launch_splat_gather(const GatherParams& gp, unsigned grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 19; }   // 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 20; }   // 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -2188,6 +2211,38 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_u8(
     return OFL_OK;
 }
 
+// flows stored in fp16 as the SOURCE of a backward warp (2 channels; BASELINE config 5: the `flow` operand of combine_with
+// mode 1 't' is gathered straight from its fp16 planes, optionally minus an fp32 src_b): staged kernel only
+__attribute__((visibility("default"))) int ofl_warp_bwd_h_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, const void* src_f16, int64_t src_bs, const float* src_b, int64_t src_b_bs,
+    const uint8_t* src_mask, int64_t src_mask_bs, const uint8_t* flow_mask, int64_t flow_mask_bs,
+    float* dst, uint8_t* valid, int32_t n, int32_t h, int32_t w, void* stream) {
+    if (!flow || !src_f16 || !dst || !valid) return OFL_E_NULL;
+    int rc = check_dims(n, 2, h, w, false);
+    if (rc) return rc;
+    if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
+    if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
+    if (!(g_warp_path != 1 && w >= 4 && h >= 2 && w < 32760 && h < 32760 && (int64_t)h * w < (1ll << 24))) return OFL_E_UNSUPPORTED;
+    WarpParams p = {};
+    p.flow = flow; p.flow_bs = flow_bs; p.src = static_cast<const float*>(src_f16); p.src_bs = src_bs;
+    p.src_b = src_b; p.src_b_bs = src_b_bs;
+    p.src_mask = src_mask; p.src_mask_bs = src_mask_bs; p.flow_mask = flow_mask; p.flow_mask_bs = flow_mask_bs;
+    p.dst = dst; p.valid = valid;
+    p.n = n; p.c = 2; p.h = h; p.w = w;
+    p.flow_sign = flow_sign; p.a_sign = 1.0f; p.g_sign = 1.0f; p.round_mode = OFL_ROUND_NONE;
+    p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
+    p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
+    p.rcp_wm1 = 1.0f / p.wm1; p.rcp_hm1 = 1.0f / p.hm1;
+    p.lds_bytes = kLdsBytes;
+    p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;
+    p.dst_bs = (int64_t)2 * h * w;
+    const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_b) hipLaunchKernelGGL((warp_bwd_lds_kernel<2, true, false, false, true, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
+    else hipLaunchKernelGGL((warp_bwd_lds_kernel<2, true, false, false, false, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
+    return (int)hipGetLastError();
+}
+
 static int fill_splat(SplatParams& p, const float* flow, int64_t flow_bs, const float* data, int64_t data_bs,
                       float data_sign, const uint8_t* weight_mask, int64_t weight_mask_bs,
                       const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b,
@@ -2293,8 +2348,10 @@ static int splat_tiled_impl(
     const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
     int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
     float* mask_chan, int32_t* dst_flags, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n,
-    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream, int32_t fh, int32_t fw, int32_t foy, int32_t fox) {
+    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream, int32_t fh, int32_t fw, int32_t foy, int32_t fox, int elem = 0) {
+    const bool half_in = elem != 0;       // flow and data planes hold fp16 (2 channels, no window, no xs / ys, no data_b, no rounding)
     if (!data || !dst || !workspace || !accum_fallback) return OFL_E_NULL;
+    if (half_in && (c != 2 || !flow || xs || ys || data_b || fw != 0 || round_mode != 0)) return OFL_E_UNSUPPORTED;
     if (!flow && !(xs && ys)) return OFL_E_NULL;
     if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     if ((valid || mask_chan) && !with_mask_chan) return OFL_E_ARG;
@@ -2348,14 +2405,17 @@ static int splat_tiled_impl(
         // the lists do not depend on the data: binned once per pass, read by every channel group
         SplatParams base = all;
         base.n = (int32_t)nn;
-        if (base.flow) base.flow = all.flow + n0 * all.flow_bs;
+        // (fp16 variants: the flow / data / dst pointers address halves -- advance them in their own element size)
+        auto adv_in = [&](const float* ptr, int64_t elems) { return half_in ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(ptr) + elems) : ptr + elems; };
+        auto adv_out = [&](float* ptr, int64_t elems) { return elem == 2 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(ptr) + elems) : ptr + elems; };
+        if (base.flow) base.flow = adv_in(all.flow, n0 * all.flow_bs);
         if (base.xs) { base.xs = all.xs + n0 * all.xy_bs; base.ys = all.ys + n0 * all.xy_bs; }
-        base.data = all.data + n0 * all.data_bs;
+        base.data = adv_in(all.data, n0 * all.data_bs);
         if (base.data_b) base.data_b = all.data_b + n0 * all.data_b_bs;
         if (base.weight_mask) base.weight_mask = all.weight_mask + n0 * all.weight_mask_bs;
         if (base.chan_mask_a) base.chan_mask_a = all.chan_mask_a + n0 * all.chan_mask_a_bs;
         if (base.chan_mask_b) base.chan_mask_b = all.chan_mask_b + n0 * all.chan_mask_b_bs;
-        base.dst = all.dst + n0 * all.dst_bs;
+        base.dst = adv_out(all.dst, n0 * all.dst_bs);
         if (base.density) base.density = all.density + n0 * hw;
         if (base.warped) base.warped = all.warped + n0 * hw;
         if (base.valid) base.valid = all.valid + n0 * hw;
@@ -2369,7 +2429,8 @@ static int splat_tiled_impl(
         // per-image fallback flags and list lengths of this pass
         e = hipMemsetAsync(gp.img_over, 0, (size_t)(((chunk + 3) & ~(int64_t)3) + ctiles) * sizeof(int32_t), st);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(splat_bin_kernel, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
+        if (half_in) hipLaunchKernelGGL(splat_bin_kernel<_Float16>, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
+        else hipLaunchKernelGGL(splat_bin_kernel<float>, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
         rc = (int)hipGetLastError();
         if (rc) return rc;
         hipLaunchKernelGGL(splat_stats_kernel, dim3(1), dim3(64), 0, st, gp.img_over, (int32_t)nn, gp.stats);
@@ -2385,7 +2446,8 @@ static int splat_tiled_impl(
             e = hipMemsetAsync(gp.stats + 3, 0, sizeof(int32_t), st);      // tiles this launch hands to the fallback kernel
             if (e != hipSuccess) return (int)e;
             const unsigned grid = (unsigned)(gp.per_xcd * kXcds);
-            switch (cg) {
+            if (half_in) rc = launch_splat_gather_half(gp, grid, st, elem);
+            else switch (cg) {
                 case 1: rc = launch_splat_gather<1>(gp, grid, st); break;
                 case 2: rc = launch_splat_gather<2>(gp, grid, st); break;
                 default: rc = launch_splat_gather<3>(gp, grid, st); break;
@@ -2402,7 +2464,11 @@ static int splat_tiled_impl(
             unsigned g2;
             tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
             if (g2 > 2048u) g2 = 2048u;                       // (strided: the kernels walk the tiles of the flagged images)
-            switch (cg) {
+            if (half_in) {
+                hipLaunchKernelGGL((splat_fwd_kernel<2, _Float16>), dim3(g2), dim3(256), 0, st, fb);
+                if (elem == 2) hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, _Float16>), dim3(g2), dim3(256), 0, st, fb);
+                else hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, float>), dim3(g2), dim3(256), 0, st, fb);
+            } else switch (cg) {
                 case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
                         hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
                 case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
@@ -2427,6 +2493,21 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_f32(
                             weight_mask_bs, chan_mask_a, chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, dst,
                             density, warped, valid, mask_chan, dst_flags, workspace, workspace_ints, accum_fallback, n, c, h, w,
                             round_mode, stream, 0, 0, 0, 0);
+}
+
+__attribute__((visibility("default"))) int ofl_splat_tiled_f16(
+    const void* flow_f16, int64_t flow_bs, float flow_sign, const void* data_f16, int64_t data_bs, float data_sign,
+    const uint8_t* weight_mask, int64_t weight_mask_bs,
+    const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
+    int32_t with_mask_chan, int32_t occlude, void* dst, int32_t dst_is_f16, uint8_t* valid, int32_t* dst_flags,
+    int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n, int32_t h, int32_t w, void* stream) {
+    if (!flow_f16 || !data_f16) return OFL_E_NULL;
+    if (!aligned_to(flow_f16, 2) || !aligned_to(data_f16, 2)) return OFL_E_ARG;
+    return splat_tiled_impl(static_cast<const float*>(flow_f16), flow_bs, flow_sign, nullptr, nullptr, 0,
+                            static_cast<const float*>(data_f16), data_bs, data_sign, nullptr, 0, weight_mask, weight_mask_bs,
+                            chan_mask_a, chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude,
+                            static_cast<float*>(dst), nullptr, nullptr, valid, nullptr, dst_flags, workspace, workspace_ints,
+                            accum_fallback, n, 2, h, w, 0, stream, 0, 0, 0, 0, dst_is_f16 ? 2 : 1);
 }
 
 __attribute__((visibility("default"))) int ofl_splat_tiled_win_f32(
@@ -2462,12 +2543,12 @@ __attribute__((visibility("default"))) int ofl_flow_from_f16(const void* src_f16
                                                              const uint8_t* mask, int64_t mask_bs, float* dst,
                                                              int32_t* flags, int32_t n, int32_t h, int32_t w,
                                                              void* stream) {
-    if (!src_f16 || !dst || !flags) return OFL_E_NULL;
+    if (!src_f16 || !flags) return OFL_E_NULL;                    // (dst NULL: flags only -- the flow stays in fp16)
     int rc = check_dims(n, 2, h, w, false);
     if (rc) return rc;
     if (n > 65535) return OFL_E_SHAPE;
     const int64_t hw = (int64_t)h * w;
-    if ((hw % 4) != 0 || !aligned_to(src_f16, 8) || (src_bs % 4) != 0 || !aligned_to(dst, 16) ||
+    if ((hw % 4) != 0 || !aligned_to(src_f16, 8) || (src_bs % 4) != 0 || (dst && !aligned_to(dst, 16)) ||
         (mask && (!aligned_to(mask, 4) || (mask_bs % 4) != 0)))
         return OFL_E_UNSUPPORTED;
     int64_t bx = (hw / 4 + 1023) / 1024, cap = 512 / n;

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import _native, distributed
 from .utils import (get_valid_vecs, get_valid_ref, get_valid_mask, get_valid_device, get_valid_padding,
                     get_valid_shape, get_pure_pytorch, move_axis, from_matrix, from_transforms, resize_flow,
-                    apply_flow, _flags_to_host, _griddata_unavailable, track_pts)
+                    apply_flow, _flags_to_host, _griddata_unavailable, track_pts, get_half_flow_outputs)
 
 FlowAlias = 'Flow'
 _VALID_THR = 0.99999   # flow_class.py:922
@@ -36,18 +36,41 @@ class Flow(object):
     # ------------------------------------------------------------------------------------------
     # construction / properties (flow_class.py:37-236)
     # ------------------------------------------------------------------------------------------
+    # -- vector storage -------------------------------------------------------------------------
+    # `_vecs` is what the reference holds: N-2-H-W fp32.  A flow handed over as an fp16 tensor on a HIP device (BASELINE
+    # config 5) STAYS in fp16 (`_half`): the kernels that take fp16 operands read it directly (ofl_splat_tiled_f16,
+    # ofl_warp_bwd_h_f32: exact up-conversion in registers, fp32 arithmetic, the reference's `vecs.float()` of utils.py:95,118
+    # without the fp32 copy), and the fp32 tensor is only made when somebody asks for it (`.vecs`, arithmetic, ...).
+    @property
+    def _vecs(self) -> torch.Tensor:
+        if self._v32 is None:
+            self._v32 = self._half.float()
+        return self._v32
+
+    @_vecs.setter
+    def _vecs(self, t: torch.Tensor):
+        if t.dtype == torch.float16 and t.device.type == 'cuda':
+            self._half, self._v32 = t, None
+        else:
+            self._half, self._v32 = None, t
+
+    @property
+    def _fv(self) -> torch.Tensor:
+        """The vectors as stored: fp16 if the flow was handed over (or, by option, produced) in fp16, else fp32."""
+        return self._half if self._half is not None else self._v32
+
     def __init__(self, flow_vectors, ref: str = None, mask=None, device=None):
         self._flag_cache = None
         self._pending_flags = None
         self._mask = None
         self._vecs = get_valid_vecs(flow_vectors, error_string="Error setting flow vectors: ", _check_finite=False,
                                     _keep_half=True)
-        self._device = self._vecs.device
+        self._device = self._fv.device
         try:
             self.ref = ref
             if mask is not None:
                 m = get_valid_mask(mask, desired_shape=self.shape, error_string="Error setting flow mask: ")
-                self._mask = m.to(self._vecs.device)
+                self._mask = m.to(self._fv.device)
         except (TypeError, ValueError):
             self._mask = None
             self._from_half()
@@ -60,9 +83,8 @@ class Flow(object):
     def _from_half(self):
         """fp16-stored vectors on a HIP device (BASELINE config 5): the reference's `.float()` (utils.py:95,118) and the
         validation reduction run as one kernel, now that the mask is known."""
-        if self._vecs.dtype == torch.float16:
-            self._vecs, flags = _native.flow_from_half(self._vecs, self._mask)
-            self._set_pending_flags(flags)
+        if self._half is not None:
+            self._set_pending_flags(_native.flow_flags(self._half, self._mask))     # (flags only: 5 B/px, the flow stays fp16)
 
     @classmethod
     def _wrap(cls, vecs: torch.Tensor, ref: str, mask, device=None, flags: torch.Tensor = None,
@@ -73,8 +95,8 @@ class Flow(object):
         obj._vecs, obj._ref, obj._mask = vecs, ref, mask
         obj._device = vecs.device if device is None else device
         obj._flag_cache, obj._pending_flags = None, None
-        if obj._vecs.device != obj._device:
-            obj._vecs = obj._vecs.to(obj._device)
+        if obj._fv.device != obj._device:
+            obj._vecs = obj._fv.to(obj._device)
         if obj._mask is not None and obj._mask.device != obj._device:
             obj._mask = obj._mask.to(obj._device)
         if flags is not None:
@@ -113,7 +135,7 @@ class Flow(object):
         """Cache key of the flag word: tensor versions (in-place edits invalidate it).  Tensors created under
         torch.inference_mode() carry no version counter (reading `_version` raises); they cannot be modified in place
         outside inference mode, so their identity stands in."""
-        return (_ver(self._vecs), None if self._mask is None else (id(self._mask), _ver(self._mask)))
+        return (_ver(self._fv), None if self._mask is None else (id(self._mask), _ver(self._mask)))
 
     def _flags_known(self) -> bool:
         key = self._key()
@@ -126,7 +148,7 @@ class Flow(object):
             if self._pending_flags is not None and self._pending_flags[0] == key:
                 dev_flags = self._pending_flags[1]
             else:
-                dev_flags = _native.flow_flags(self._vecs, self._mask)
+                dev_flags = _native.flow_flags(self._fv, self._mask)
             self._pending_flags = None
             if distributed.is_enabled():
                 # batch sharding: the OR over every rank's shard is formed on the device (one small all-reduce) and read
@@ -150,7 +172,7 @@ class Flow(object):
             local = 0
             for f in flags:
                 local |= f
-            glob = distributed.reduce_flags(local, self._vecs.device)
+            glob = distributed.reduce_flags(local, self._fv.device)
             self._flag_cache = (self._flag_cache[0], self._flag_cache[1], (distributed.is_enabled(), glob))
         return self._flag_cache[2][1]
 
@@ -195,7 +217,7 @@ class Flow(object):
     def mask(self) -> torch.Tensor:
         """Validity mask N-H-W bool (flow_class.py:159-172).  An all-True default is materialised on first use."""
         if self._mask is None:
-            self._mask = torch.ones(self.shape, dtype=torch.bool, device=self._vecs.device)
+            self._mask = torch.ones(self.shape, dtype=torch.bool, device=self._fv.device)
             self._flag_cache = None if self._flag_cache is None else (self._key(), self._flag_cache[1])
         return self._mask
 
@@ -205,7 +227,7 @@ class Flow(object):
             self._mask = None
         else:
             m = get_valid_mask(input_mask, desired_shape=self.shape, error_string="Error setting flow mask: ")
-            self._mask = m.to(self._vecs.device)
+            self._mask = m.to(self._fv.device)
         self._flag_cache, self._pending_flags = None, None
 
     @property
@@ -220,12 +242,12 @@ class Flow(object):
 
     @device.setter
     def device(self, input_device=None):
-        device = self._vecs.device if input_device is None else get_valid_device(input_device)
+        device = self._fv.device if input_device is None else get_valid_device(input_device)
         self._device = device
-        if self._vecs.device != device:
-            self._vecs = self._vecs.to(device)
+        if self._fv.device != device:
+            self._vecs = self._fv.to(device) if device.type == 'cuda' else self._vecs.to(device)
             self._flag_cache = None if self._flag_cache is None else \
-                ((_ver(self._vecs), self._flag_cache[0][1]), self._flag_cache[1])
+                ((_ver(self._fv), self._flag_cache[0][1]), self._flag_cache[1])
         if self._mask is not None and self._mask.device != device:
             flags = None if self._flag_cache is None else self._flag_cache[1]
             self._mask = self._mask.to(device)
@@ -235,7 +257,7 @@ class Flow(object):
     @property
     def shape(self) -> tuple:
         """(N, H, W) (flow_class.py:228-236)"""
-        return (self._vecs.shape[0],) + tuple(self._vecs.shape[2:])
+        return (self._fv.shape[0],) + tuple(self._fv.shape[2:])
 
     @classmethod
     def zero(cls, shape, ref: str = None, mask=None, device=None) -> FlowAlias:
@@ -262,7 +284,7 @@ class Flow(object):
     def copy(self) -> FlowAlias:
         """flow_class.py:376-383.  The copy aliases the same (already validated) tensors: its flag word is inherited
         instead of recomputed (no launch, no host sync)."""
-        return Flow._wrap(self._vecs, self._ref, self._mask, self._device, like=self)
+        return Flow._wrap(self._fv, self._ref, self._mask, self._device, like=self)
 
     def to_device(self, device) -> FlowAlias:
         device = get_valid_device(device)
@@ -446,7 +468,7 @@ class Flow(object):
         return_dtype, return_2d, return_3d = torch.float, False, False
         if isinstance(target, Flow):
             return_flow = True
-            t, tmask = target._vecs, target._mask
+            t, tmask = target._fv, target._mask
         elif isinstance(target, torch.Tensor):
             return_flow = False
             if target.dim() == 4:
@@ -566,7 +588,7 @@ class Flow(object):
             return warped, valid, None
         dflags = None
         if self._ref == 't':
-            warped, valid, _, _ = _native.warp_bwd(self._vecs, t, src_mask=tmask,
+            warped, valid, _, _ = _native.warp_bwd(self._fv, t, src_mask=tmask,
                                                    flow_mask=self._mask if need_valid else None,
                                                    want_valid=need_valid, round_mode=round_mode, src_b=t_minus,
                                                    out_uint8=not get_pure_pytorch())   # (:943-949: only then is it cast back)
@@ -574,10 +596,11 @@ class Flow(object):
             # a warped FLOW (2 channels, with its valid mask) brings its flag word along: the splat produces it as a
             # by-product, so that using the result as a warper needs no validation pass of its own
             want_f = need_valid and t.shape[1] == 2 and round_mode == 0
-            res = _native.splat_fwd(self._vecs, t, weight_mask=self._mask if consider_mask else None,
+            res = _native.splat_fwd(self._fv, t, weight_mask=self._mask if consider_mask else None,
                                     chan_mask_a=tmask, chan_mask_b=self._mask,
                                     want_valid=need_valid, occlude=True, round_mode=round_mode,
-                                    flow_sign=flow_sign, data_sign=data_sign, want_dst_flags=want_f, data_b=t_minus)
+                                    flow_sign=flow_sign, data_sign=data_sign, want_dst_flags=want_f, data_b=t_minus,
+                                    out_half=get_half_flow_outputs())
             warped, valid = res[0], res[1]
             dflags = res[4] if want_f else None
         return warped.to(self._device), (None if valid is None else valid.to(self._device)), dflags
@@ -615,7 +638,7 @@ class Flow(object):
     def switch_ref(self, mode: str = None) -> FlowAlias:
         mode = 'valid' if mode is None else mode
         if mode == 'invalid':
-            return Flow._wrap(self._vecs, 't' if self._ref == 's' else 's', self._mask, self._device, like=self)
+            return Flow._wrap(self._fv, 't' if self._ref == 's' else 's', self._mask, self._device, like=self)
         if mode != 'valid':
             raise ValueError("Error switching flow reference: Mode not recognised, should be 'valid' or 'invalid'")
         if self._all_zero(_native.FLAG_NZ_MASKED):                                   # flow_class.py:1046
@@ -626,14 +649,14 @@ class Flow(object):
             return out
         # (-as_s).apply(as_s) with as_s = this flow read as 's' (flow_class.py:1060-1062): one splat P(-f, f||[m], m),
         # the negation folded into the kernel's end points
-        warped, valid, dflags = self.switch_ref(mode='invalid')._warp(self._vecs, self._mask, True, True, flow_sign=-1.0)
+        warped, valid, dflags = self.switch_ref(mode='invalid')._warp(self._fv, self._mask, True, True, flow_sign=-1.0)
         return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
 
     def invert(self, ref: str = None) -> FlowAlias:
         ref = self._ref if ref is None else get_valid_ref(ref)
         if self._ref == 's':
             if ref == 's':                                      # self.apply(-self): P(f, -f||[m], m)
-                warped, valid, dflags = self._warp(self._vecs, self._mask, True, True, data_sign=-1.0)
+                warped, valid, dflags = self._warp(self._fv, self._mask, True, True, data_sign=-1.0)
                 return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
             return self._negated('t')
         if ref == 's':
@@ -641,8 +664,8 @@ class Flow(object):
         # self.invert('s').switch_ref(): with g = -f read as 's', g.apply(g) = P(-f, -f||[m], m)   (flow_class.py:1084-1086)
         if self._all_zero(_native.FLAG_NZ_MASKED):              # switch_ref's early exit (:1046) on g
             return self._negated('t')
-        warped, valid, dflags = Flow._wrap(self._vecs, 's', self._mask, self._device, like=self)._warp(
-            self._vecs, self._mask, True, True, flow_sign=-1.0, data_sign=-1.0)
+        warped, valid, dflags = Flow._wrap(self._fv, 's', self._mask, self._device, like=self)._warp(
+            self._fv, self._mask, True, True, flow_sign=-1.0, data_sign=-1.0)
         return Flow._wrap(warped, 't', valid, self._device, flags=dflags)
 
     # ------------------------------------------------------------------------------------------
@@ -767,7 +790,7 @@ class Flow(object):
             inv = self.invert()
             if inv._all_zero(_native.FLAG_NZ_THR):
                 return inv.apply(flow - self)
-            warped, valid, _ = inv._warp(flow._vecs, flow._and_masks(self._mask), True, True, t_minus=self._vecs)
+            warped, valid, _ = inv._warp(flow._fv, flow._and_masks(self._mask), True, True, t_minus=self._vecs)
             return Flow._wrap(warped, 't', valid, self._device)
         if ref == 's':                                                               # mode 2, :1768
             # self.apply(flow - self): the difference (and the AND of the two masks) is formed inside the splat

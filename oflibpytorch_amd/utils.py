@@ -41,6 +41,22 @@ def unset_pure_pytorch(warn: bool = None):
               "significantly slower, but more accurate")
 
 
+HALF_FLOW_OUTPUTS = False  # extension (off: the reference returns fp32 flows): see set_half_flow_outputs
+
+
+def get_half_flow_outputs() -> bool:
+    return HALF_FLOW_OUTPUTS
+
+
+def set_half_flow_outputs(on: bool = True):
+    """Extension for fp16-stored pipelines (BASELINE config 5): when on, an operation whose flow operands are ALL stored
+    in fp16 on a HIP device and whose result is a flow (`switch_ref`, `invert`, `Flow.apply(Flow)` of 's' flows) stores
+    that result in fp16 as well (fp32 arithmetic, one round-to-nearest-even at the store; `.vecs` still hands out fp32).
+    Off by default: the reference up-casts on entry and returns fp32 flows (utils.py:95, 118)."""
+    global HALF_FLOW_OUTPUTS
+    HALF_FLOW_OUTPUTS = bool(on)
+
+
 def _griddata_unavailable(what: str):
     raise NotImplementedError("oflibpytorch_amd: %s with PURE_PYTORCH unset needs scipy.interpolate.griddata, which "
                               "is outside the MI355X hot path; call set_pure_pytorch()" % what)

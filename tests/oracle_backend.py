@@ -90,7 +90,7 @@ def warp_bwd(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_va
 
 def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, weight_mask=None, chan_mask_a=None,
               chan_mask_b=None, want_valid=False, occlude=True, want_density=False, want_warped=False, round_mode=0,
-              want_mask_chan=False, want_dst_flags=False, data_b=None):
+              want_mask_chan=False, want_dst_flags=False, data_b=None, out_half=False):
     _no_grad(flow, data, xs, ys, data_b)
     d = _np(data, np.float32)
     if data_b is not None:

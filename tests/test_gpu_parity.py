@@ -718,3 +718,57 @@ def test_padded_apply_reads_the_flow_through_a_window(ref, shape, pad, dev):
     got8 = fl.apply((img).to(torch.uint8), padding=pad)              # integer targets: rounded in the kernel
     exp8 = padded.apply((img).to(torch.uint8))[..., pad[0]:pad[0] + h, pad[2]:pad[2] + w]
     assert torch.equal(got8, exp8)
+
+
+@pytest.mark.parametrize("shape", [(3, 70, 132), (2, 37, 50), (2, 64, 96), (1, 33, 47)])
+def test_fp16_stored_flows_are_read_directly(shape, dev):
+    """BASELINE config 5 storage: a Flow handed over in fp16 keeps its halves; `switch_ref`, `invert`, `Flow.apply(Flow)` ('s':
+    ofl_splat_tiled_f16) and `combine_with` mode 1 't' (ofl_warp_bwd_h_f32: the fp16 flow is the gathered source) read them
+    directly.  Everything must be bit-identical to the same calls on the up-cast fp32 tensors -- the reference's `.float()`
+    on entry (utils.py:95, 118) -- values, masks, references and flag words."""
+    import oflibpytorch_amd as ofl
+    n, h, w = shape
+    g = torch.Generator().manual_seed(9)
+    f16 = _smooth(n, h, w, 2.5, 31, dev).half()
+    f16[0, :, : h // 3] = 0
+    g16 = _smooth(n, h, w, 1.5, 32, dev).half()
+    m = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    m2 = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    for ref in 'st':
+        a16, a32 = ofl.Flow(f16, ref, m), ofl.Flow(f16.float(), ref, m)
+        b16, b32 = ofl.Flow(g16, ref, m2), ofl.Flow(g16.float(), ref, m2)
+        assert a16._half is not None and a16._v32 is None            # no fp32 copy was made at construction
+        assert a16._flags() == a32._flags()
+        pairs = [(a16.switch_ref(), a32.switch_ref()), (a16.invert(), a32.invert()),
+                 (a16.invert('s' if ref == 't' else 't'), a32.invert('s' if ref == 't' else 't')),
+                 (a16.apply(b16), a32.apply(b32))]
+        pairs += [(a16.combine_with(b16, mode), a32.combine_with(b32, mode)) for mode in (1, 2, 3)]
+        for x, y in pairs:
+            assert x.ref == y.ref and x.vecs.dtype == torch.float32
+            assert torch.equal(x.vecs, y.vecs) and torch.equal(x.mask, y.mask)
+            assert x._flags() == y._flags()
+    assert a16.vecs.dtype == torch.float32 and torch.equal(a16.vecs, f16.float())     # `.vecs` hands out fp32, like the reference
+
+
+def test_fp16_flow_outputs_are_an_option(dev):
+    """`set_half_flow_outputs(True)`: a flow produced from fp16-stored flows by the splat family is STORED in fp16 (fp32
+    arithmetic, one round-to-nearest-even at the store) and stays in fp16 down a chain; values = the fp32 result rounded to
+    fp16, masks identical, flag words those of the stored values.  Off by default."""
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 96, 160
+    f16 = _smooth(n, h, w, 2.5, 41, dev).half()
+    m = (torch.rand(n, h, w, generator=torch.Generator().manual_seed(4)) > 0.15).to(dev)
+    ref32 = ofl.Flow(f16, 's', m).switch_ref()
+    assert ref32._half is None
+    try:
+        ofl.set_half_flow_outputs(True)
+        out = ofl.Flow(f16, 's', m).switch_ref()
+        assert out._half is not None and out._v32 is None and out.ref == 't'
+        assert torch.equal(out._half, ref32.vecs.half()) and torch.equal(out.mask, ref32.mask)
+        assert out._flags() == ofl.Flow(ref32.vecs.half(), 't', ref32.mask)._flags()
+        again = out.invert()                                          # the chain stays in fp16 storage
+        assert again._half is not None
+        assert torch.equal(again._half, ofl.Flow(out._half.float(), 't', out.mask).invert().vecs.half())
+    finally:
+        ofl.set_half_flow_outputs(False)
+    assert ofl.Flow(f16, 's', m).switch_ref()._half is None
