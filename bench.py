@@ -283,7 +283,7 @@ def main():
                        "batch_per_gpu": n, "global_batch": global_batch, "height": h, "width": w,
                        "parallelism": "batch-sharded x%d (no data-path collective)" % world,
                        "bytes_per_px": BYTES_APPLY + BYTES_COMBINE},
-            "roofline": {"bound": "hbm", "kernel": "warp_bwd_lds_kernel<3,valid> (Flow.apply 't')",
+            "roofline": {"bound": "hbm", "kernel": "warp_bwd_lds_column_kernel<4,3,valid> (Flow.apply 't')",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": args.traffic_bytes,

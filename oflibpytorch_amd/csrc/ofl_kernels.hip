@@ -205,6 +205,10 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
 constexpr int kLdsNT = 128, kLdsTWQ = 8, kLdsTH = kLdsNT / kLdsTWQ, kLdsIters = 3;
+#ifndef OFL_WARP_T
+#define OFL_WARP_T 4
+#endif
+constexpr int kLdsT = OFL_WARP_T;    // tiles per block of the column kernel (warp_bwd_lds_column_kernel); 2: the pair kernel only
 constexpr int kLdsBytes = 26624;   // 6 blocks (12 waves) per CU
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -280,9 +284,13 @@ struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits, interior; 
 __device__ __forceinline__ int lds_shear(int c, int sq) { return __mul24(c, sq) >> 8; }
 
 // slope estimate from the flow at the two ends of the row between the block's two tiles (scalar loads: uniform addresses)
+__device__ __forceinline__ int lds_slope_row(const WarpParams& p, const float* __restrict__ fu, uint32_t hw, int tx, int row);
 __device__ __forceinline__ int lds_slope(const WarpParams& p, const float* __restrict__ fu, uint32_t hw, int tx, int ty2) {
+    return lds_slope_row(p, fu, hw, tx, ty2 * (2 * kLdsTH) + kLdsTH);
+}
+__device__ __forceinline__ int lds_slope_row(const WarpParams& p, const float* __restrict__ fu, uint32_t hw, int tx, int row) {
     const int w = p.w, h = p.h;
-    const int y = min(ty2 * (2 * kLdsTH) + kLdsTH, h - 1), xa = min(tx * (kLdsTWQ * 4), w - 1), xb = min(xa + kLdsTWQ * 4 - 1, w - 1);
+    const int y = min(row, h - 1), xa = min(tx * (kLdsTWQ * 4), w - 1), xb = min(xa + kLdsTWQ * 4 - 1, w - 1);
     const float ul = fu[y * w + xa], ur = fu[y * w + xb], vl = fu[hw + y * w + xa], vr = fu[hw + y * w + xb];
     const float dx = (float)(xb - xa) - p.flow_sign * (ur - ul), dy = -p.flow_sign * (vr - vl);
     float q = 1024.0f * dy / dx;                                   // 256 * dy / (dx / 4)
@@ -641,6 +649,90 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     lds_gather<NC, VALID, SUB, TS>(p, hw, sb, sm, TB, BB, smem, outv, sbb);
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
     lds_store<NC, VALID, ADD, DF, TD>(p, tx, tyB, n, hw, fmB, outv, aB, &dflags);
+    if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
+}
+
+// The same pipeline over T vertically adjacent tiles (T >= 3; the hand-scheduled two-tile kernel above stays the one for
+// T = 2: written as this loop it leaves its small arrays in scratch).  The two dependent round trips of a tile (flow, then
+// its staged box) and the drain of its stores are paid once per BLOCK: a taller column of tiles amortises them over more
+// pixels with the same registers and the same LDS -- flow two tiles ahead, staging loads one tile ahead, stores behind.
+template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float>
+__global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p) {
+    constexpr int NW = kLdsNT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[2][NW][4];
+    int tx, tyg, n;                      // the grid counts tile GROUPS: tiles_y = ceil(h / (T * kLdsTH))
+    if (!decode_tile(p, tx, tyg, n)) return;
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const TS* __restrict__ sb = reinterpret_cast<const TS*>(p.src) + n * p.src_bs;      // (uint8 variants: p.src / p.dst point at bytes)
+    const float* __restrict__ sbb = SUB ? p.src_b + n * p.src_b_bs : nullptr;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
+    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
+    // flow + flow mask of a tile (16-byte non-temporal loads); issued two tiles ahead of their use
+    f4 uu[T], vv[T];
+    uint32_t fmk[T];
+    int fflags = 0;
+    auto load_flow = [&](int k) {
+        const uint32_t pix = (uint32_t)(min((tyg * T + k) * kLdsTH + ly, h - 1) * w + xq);
+        uu[k] = ld4nt(fu + pix); vv[k] = ld4nt(fu + hw + pix);
+        fmk[k] = 0x01010101u;
+        if ((VALID || p.flow_flags) && fm) fmk[k] = ld32(fm + pix);
+    };
+    auto note_flags = [&](int k) {       // finiteness / zero tests of the flow operand as a by-product (wave-uniform branch)
+        if (p.flow_flags && (x4 < w) && ((tyg * T + k) * kLdsTH + ly < h)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fflags |= flag_bits(uu[k][q], vv[k][q], ((fmk[k] >> (8 * q)) & 0xffu) != 0u);
+        }
+    };
+    load_flow(0);
+    if (T > 1) load_flow(1);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    LdsCoords Tc[T];
+    LdsBox Bx[T];
+    LdsStage<NC> S;
+    // the shear slope is estimated per tile (a column is too tall for one estimate); all of them up front: the scalar loads
+    // must not sit between a tile's flow and its box
+    int sq[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) sq[k] = p.shear ? lds_slope_row(p, fu, hw, tx, (tyg * T + k) * kLdsTH + kLdsTH / 2) : 0;
+    note_flags(0);
+    lds_coords_box(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
+    lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[0], S, sbb);          // staging loads of tile 0 fly ...
+    // the vmcnt queue is in order: the addend (an L2 hit when it is the flow itself) is fetched BEFORE the next tile's staging
+    // loads / this tile's stores, so that waiting for it never waits for them
+    // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
+    constexpr bool EARLY = ADD && NC <= 2;
+    const bool reuse = EARLY && NC == 2 && p.add_is_flow;                 // block-uniform
+    int dflags = 0;
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int tyk = tyg * T + k;
+        const bool more = (k + 1 < T) && ((tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
+        if (k + 1 < T) {
+            if (more) { note_flags(k + 1); lds_coords_box(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
+        }
+        if (k + 2 < T) load_flow(k + 2);
+        lds_write<NC, VALID>(lds, Bx[k], S);
+        lds_barrier();
+        f4 outv[4], ad[NC];
+        if (EARLY) { if (reuse) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; } else lds_load_addend<NC>(p, tx, tyk, n, hw, ad); }
+        if (k + 1 < T) {
+            if (more) lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[k + 1], S, sbb);   // the next tile's staging loads fly while this one is gathered and stored
+        }
+        lds_gather<NC, VALID, SUB, TS>(p, hw, sb, sm, Tc[k], Bx[k], smem, outv, sbb);
+        if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
+        lds_store<NC, VALID, ADD, DF, TD>(p, tx, tyk, n, hw, fmk[k], outv, ad, &dflags);
+        if (!more) break;
+        lds_barrier();
+    }
+    if (p.flow_flags) {
+        fflags = wave_or_flags(fflags);
+        if ((tid & 63) == 0) flag_or(&p.flow_flags[n], fflags);
+    }
     if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
 }
 
@@ -1966,6 +2058,14 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     if (NC == 2 && p.dst_flags) {                          // (host: only with a valid mask)
         if (add) hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, true, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         else hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+        return (int)hipGetLastError();
+    }
+    // (the fused composition -- ADD -- keeps the pair kernel: as a column its re-used flow registers spill, 1.03 instead of 0.92 ms)
+    if (kLdsT > 2 && !add && !p.flow_flags) {              // a plain warp (Flow.apply 't' of an image or a flow): columns of kLdsT tiles
+        WarpParams q = p;
+        const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
     }
 #define OFL_LAUNCH_L(V, A)                                                                                       \
