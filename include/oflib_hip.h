@@ -189,31 +189,35 @@ int ofl_splat_finalize_f32(const float* accum,
                            int32_t round_mode, void* stream);
 
 /*
- * Forward splat, single fused call (the fast path of the two passes above, same arguments):
- * a route kernel sorts every source pixel into the queue of the destination tile(s) it touches; a tile kernel then sums
- * each destination pixel's contributions in registers, per corner class in raster order of the source pixels and
- * ((c0 + c1) + c2) + c3 across the classes -- the order of the reference's four scatter_add_ passes and corner sum
- * (utils.py:1133-1143): results are BIT-IDENTICAL to the reference's (and from run to run), not just within a tolerance.
- * Normalise / masks / un-occlude fill happen in the same kernel; no float atomics, no accumulator in HBM.
+ * Forward splat, single fused call (the fast path of the two passes above, same arguments) -- an in-order GATHER:
+ * a bin kernel appends the id of every 16 x 4 source subtile to the list of each 32 x 16 destination tile its end points
+ * touch; a gather kernel (one block per destination tile) re-reads the listed source pixels, keeps those that land in
+ * the tile as LDS records per unit cell, puts every cell in raster order of its source pixels and sums each destination
+ * pixel's contributions in registers, per corner class in that order and ((c0 + c1) + c2) + c3 across the classes -- the
+ * order of the reference's four scatter_add_ passes and corner sum (utils.py:1133-1143): results are BIT-IDENTICAL to the
+ * reference's (and from run to run), not just within a tolerance.  Normalise / masks / un-occlude fill happen in the
+ * same kernel; no float atomics, no accumulator, no per-pixel records in HBM.
  * Needs 4 <= W < 32768, H < 32768 (any width: 16-byte accesses at 4-byte alignment; more than 3 channels are
  * processed in groups of 3), else it returns OFL_E_UNSUPPORTED and the caller
  * uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
- *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]  queue lengths, block table and the record queues
- *                  (fixed addresses: 1024 records of 24 bytes per destination tile + one spare block of 1024 per two
- *                  tiles, ~72 B/px; the batch is processed in equal passes so that it stays under ~4 GiB);
- *                  contents irrelevant on entry; afterwards workspace[0] = 1 if the launch fell back to the two-pass
- *                  path, workspace[1] = number of tiles that left the exact path, workspace[4] = blocks drawn
+ *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]: 8 statistics words | one flag per image | list
+ *                  lengths and the list of tiles that left the exact path | 128 list entries per destination tile
+ *                  (fixed addresses; ~1 B/px).  Contents irrelevant on entry; afterwards workspace[0] = 1 if some
+ *                  IMAGE took the two-pass path, workspace[1] = number of tiles that left the exact path,
+ *                  workspace[2] = number of such images
  *   data_b         optional [*,C,H,W] fp32 (C <= 2, else OFL_E_ARG): the data splatted is data - data_b (ONE fp32 subtraction per value, the
  *                  reference's `flow - self` in combine_with modes 1-2, flow_class.py:1763,1768), then x data_sign
  *   dst_flags      optional int32[N] (C == 2 only, else OFL_E_ARG; zeroed in-stream): the flag word (see
  *                  ofl_flow_flags_f32) of the OUTPUT read as a flow under its `valid` mask -- a by-product that spares
  *                  the caller the validation pass (utils.py:98, flow_class.py:1226-1244) over an intermediate flow
  *   accum_fallback fp32[ofl_splat_tiled_pass_images(n, h, w) * (1 + C + with_mask_chan) * H * W]  (one pass of the batch)
- *                  used (and zeroed in-stream) only when a queue overflows (> 9216 records for one tile, or the
- *                  spare blocks run out) or a 32 x 16 source tile spreads over > 48 destination tiles; the two-pass global-atomics path then runs inside the same call, decided on the device (no
- *                  host sync; tolerance instead of bit-exactness).  A heavy fold of the flow (> 64 source pixels
- *                  ending in one unit cell, or more records for one tile than four bands of its rows can hold) makes
- *                  only ITS tile fall back to (LDS) float atomics.
+ *                  used (and zeroed in-stream, per image) only for an image in which a destination tile is touched by
+ *                  more than 128 source subtiles or a subtile spreads over more than 256 destination tiles: the two-pass
+ *                  global-atomics path then runs for THAT image inside the same call, decided on the device (no host
+ *                  sync; tolerance instead of bit-exactness).  A heavy fold of the flow (> 64 source pixels ending in
+ *                  one unit cell, or more records for one tile than four bands of its rows can hold) makes only ITS
+ *                  tile fall back to (LDS) float atomics.  The limits are on lengths, never on timing: the choice of
+ *                  path, and with it every bit of the result, is the same in every run.
  */
 int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w);
 int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w);   /* images handled per pass (<= n) */
