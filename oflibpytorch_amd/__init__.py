@@ -6,7 +6,8 @@ Drop-in for the warp / compose hot path of oflibpytorch (`Flow.apply`, `Flow.com
 hand-written HIP kernels.  No CPU fallback: see `_native.NativeUnavailable`.
 """
 from .flow_class import Flow
-from .flow_operations import combine_flows, switch_flow_ref, invert_flow, valid_target, valid_source, batch_flows
+from .flow_operations import (combine_flows, switch_flow_ref, invert_flow, valid_target, valid_source, batch_flows,
+                              get_flow_padding)
 from .utils import (from_matrix, from_transforms, resize_flow, apply_flow, is_zero_flow, get_pure_pytorch,
                     set_pure_pytorch, unset_pure_pytorch, to_numpy, to_tensor, move_axis, apply_s_flow,
                     grid_from_unstructured_data, get_flow_endpoints, threshold_vectors, normalise_coords, track_pts,

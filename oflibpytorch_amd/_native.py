@@ -104,6 +104,7 @@ def set_splat_path(mode: int):
 
 collect_splat_stats = False   # tests / tools set this to read _last_splat_stats after a routed splat
 _last_splat_stats = None      # device int32[4] of the most recent routed splat: how exact was it
+_last_splat_ws = None
 
 
 def set_warp_shear(on: bool):
@@ -441,6 +442,9 @@ def _splat_fwd_raw(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0
         if collect_splat_stats:             # (a copy: a view would keep the whole workspace alive between calls)
             global _last_splat_stats
             _last_splat_stats = ws[:8].clone()   # [launch fell back to global atomics, tiles that left the exact path, -, -]
+            if collect_splat_stats == 2:         # tools/splat_list_stats.py: the whole workspace (list lengths)
+                global _last_splat_ws
+                _last_splat_ws = ws
     if rc == -4:   # not eligible (alignment / channels): the general two-pass path
         if d2 is not None:
             d = (data.to(dev, torch.float32) - data_b.to(dev, torch.float32)).expand(n, -1, -1, -1).contiguous()

@@ -110,6 +110,15 @@ struct WarpParams {
     int32_t fh, fw, foy, fox;
 };
 
+typedef const WarpParams __attribute__((address_space(4))) WarpParamsK;
+#define OFL_OPAQUE_S(ptr_) asm volatile("" : "+s"(ptr_))
+#ifndef OFL_WARP_KARG
+#define OFL_WARP_KARG 1
+#endif
+#ifndef OFL_WARP_COL_ADD
+#define OFL_WARP_COL_ADD 0
+#endif
+
 constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
 constexpr int kRows = 4;     // rows per thread (independent pixels in flight per lane)
 constexpr int kTileH = 4 * kRows;  // 4 wavefronts per 256-thread block
@@ -122,7 +131,8 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s) 
 }
 
 // XCD-aware 32-bit tile decode (no 64-bit integer division in the kernel prologue)
-__device__ __forceinline__ bool decode_tile(const WarpParams& p, int& tx, int& ty, int& n) {
+template <typename WP>
+__device__ __forceinline__ bool decode_tile(const WP& p, int& tx, int& ty, int& n) {
     const uint32_t b = blockIdx.x;
     const uint32_t tile = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
     if (tile >= (uint32_t)p.total_tiles) return false;
@@ -284,11 +294,14 @@ struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits, interior; 
 __device__ __forceinline__ int lds_shear(int c, int sq) { return __mul24(c, sq) >> 8; }
 
 // slope estimate from the flow at the two ends of the row between the block's two tiles (scalar loads: uniform addresses)
-__device__ __forceinline__ int lds_slope_row(const WarpParams& p, const float* __restrict__ fu, uint32_t hw, int tx, int row);
-__device__ __forceinline__ int lds_slope(const WarpParams& p, const float* __restrict__ fu, uint32_t hw, int tx, int ty2) {
+template <typename WP>
+__device__ __forceinline__ int lds_slope_row(const WP& p, const float* __restrict__ fu, uint32_t hw, int tx, int row);
+template <typename WP>
+__device__ __forceinline__ int lds_slope(const WP& p, const float* __restrict__ fu, uint32_t hw, int tx, int ty2) {
     return lds_slope_row(p, fu, hw, tx, ty2 * (2 * kLdsTH) + kLdsTH);
 }
-__device__ __forceinline__ int lds_slope_row(const WarpParams& p, const float* __restrict__ fu, uint32_t hw, int tx, int row) {
+template <typename WP>
+__device__ __forceinline__ int lds_slope_row(const WP& p, const float* __restrict__ fu, uint32_t hw, int tx, int row) {
     const int w = p.w, h = p.h;
     const int y = min(row, h - 1), xa = min(tx * (kLdsTWQ * 4), w - 1), xb = min(xa + kLdsTWQ * 4 - 1, w - 1);
     const float ul = fu[y * w + xa], ur = fu[y * w + xb], vl = fu[hw + y * w + xa], vr = fu[hw + y * w + xb];
@@ -300,7 +313,8 @@ __device__ __forceinline__ int lds_slope_row(const WarpParams& p, const float* _
 template <int NC> struct LdsStage { int slot[kLdsIters]; f4 q[kLdsIters][NC]; uint32_t mq[kLdsIters]; };
 
 // steps 1-2 for one tile
-__device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
+template <typename WP>
+__device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
                                                LdsCoords& T, LdsBox& B, int (*red)[4]) {
     constexpr int NW = kLdsNT / 64;
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
@@ -386,8 +400,8 @@ __device__ __forceinline__ void lds_coords_box(const WarpParams& p, int tx, int 
 }
 
 // step 3a: issue the staging loads of a tile into registers (nothing waits here)
-template <int NC, bool VALID, bool SUB = false, typename TS = float>
-__device__ __forceinline__ void lds_issue(const WarpParams& p, const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
+template <int NC, bool VALID, bool SUB = false, typename TS = float, typename WP = WarpParams>
+__device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                           uint32_t hw, const LdsBox& B, LdsStage<NC>& S, const float* __restrict__ sbb = nullptr) {
     const int tid = threadIdx.x;
     const uint32_t inv = inv20((uint32_t)B.cw);
@@ -445,8 +459,8 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
 }
 
 // step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
-template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float>
-__device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw,
+template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, typename WP = WarpParams>
+__device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                                                 const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                                 const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
                                                 const float* __restrict__ sbb = nullptr) {
@@ -522,8 +536,8 @@ __device__ __forceinline__ void lds_gather_impl(const WarpParams& p, uint32_t hw
     }
 }
 
-template <int NC, bool VALID, bool SUB = false, typename TS = float>
-__device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
+template <int NC, bool VALID, bool SUB = false, typename TS = float, typename WP = WarpParams>
+__device__ __forceinline__ void lds_gather(const WP& p, uint32_t hw,
                                            const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                            const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
                                            const float* __restrict__ sbb = nullptr) {
@@ -532,8 +546,8 @@ __device__ __forceinline__ void lds_gather(const WarpParams& p, uint32_t hw,
 }
 
 // the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
-template <int NC>
-__device__ __forceinline__ void lds_load_addend(const WarpParams& p, int tx, int ty, int n, uint32_t hw, f4 (&a)[NC]) {
+template <int NC, typename WP = WarpParams>
+__device__ __forceinline__ void lds_load_addend(const WP& p, int tx, int ty, int n, uint32_t hw, f4 (&a)[NC]) {
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const uint32_t pix = (uint32_t)(min(ty * kLdsTH + ly, p.h - 1) * p.w + min(tx * (kLdsTWQ * 4) + lx * 4, p.w - 4));
 #pragma unroll
@@ -541,8 +555,8 @@ __device__ __forceinline__ void lds_load_addend(const WarpParams& p, int tx, int
 }
 
 // step 4b: valid mask, epilogue (a_sign * addend + g_sign * G, rounding), 16-byte stores
-template <int NC, bool VALID, bool ADD, bool DF = false, typename TD = float>
-__device__ __forceinline__ void lds_store(const WarpParams& p, int tx, int ty, int n, uint32_t hw, uint32_t fmask4,
+template <int NC, bool VALID, bool ADD, bool DF = false, typename TD = float, typename WP = WarpParams>
+__device__ __forceinline__ void lds_store(const WP& p, int tx, int ty, int n, uint32_t hw, uint32_t fmask4,
                                           const f4 (&outv)[4], const f4 (&addend)[NC], int* dflags = nullptr) {
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const int w = p.w, h = p.h;
@@ -657,7 +671,17 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
 // its staged box) and the drain of its stores are paid once per BLOCK: a taller column of tiles amortises them over more
 // pixels with the same registers and the same LDS -- flow two tiles ahead, staging loads one tile ahead, stores behind.
 template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float>
-__global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p) {
+__global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p_by_value) {
+#if OFL_WARP_KARG
+    // parameters through the kernarg segment (see OFL_OPAQUE_S at the gather splat): the ~250 bytes of WarpParams are not
+    // held in SGPRs (and spilled to VGPR lanes) across the whole column, each phase s_loads what it needs
+    WarpParamsK* pp = (WarpParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*pp)
+#define OFL_WARP_PHASE() OFL_OPAQUE_S(pp)
+#else
+    const WarpParams& p = p_by_value;
+#define OFL_WARP_PHASE()
+#endif
     constexpr int NW = kLdsNT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int red[2][NW][4];
@@ -710,6 +734,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     int dflags = 0;
 #pragma unroll
     for (int k = 0; k < T; ++k) {
+        OFL_WARP_PHASE();
         const int tyk = tyg * T + k;
         const bool more = (k + 1 < T) && ((tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
         if (k + 1 < T) {
@@ -734,6 +759,10 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         if ((tid & 63) == 0) flag_or(&p.flow_flags[n], fflags);
     }
     if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
+#undef OFL_WARP_PHASE
+#if OFL_WARP_KARG
+#undef p
+#endif
 }
 
 // CT = compile-time channel count (0: run-time p.c)
@@ -1087,7 +1116,13 @@ constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // gather kernel: 2
 #define OFL_SP_Q 896    // (1024 leaves room for 3 blocks per CU only; 896: 39.7 KB per block, 4 blocks -- measured -4 % / -13 % on apply 's' / switch_ref)
 #endif
 constexpr int kSpQ = OFL_SP_Q;                               // records the gather kernel holds in LDS at a time
-constexpr int kSubW = 16, kSubH = 4;                         // source subtiles: 4 lanes x 4 pixels wide, 4 rows
+#ifndef OFL_SP_SUBH
+#define OFL_SP_SUBH 2
+#endif
+constexpr int kSubW = 16, kSubH = OFL_SP_SUBH;               // source subtiles: 4 lanes x 4 pixels wide, kSubH rows
+constexpr int kSubLanes = 4 * kSubH;                         // lanes per subtile (16: a DPP row; 8: half a row)
+constexpr int kRegH = 16;                                    // a bin block covers a 64 x 16 source region (its wave w: rows 4 w .. 4 w + 3)
+static_assert(kSubH == 2 || kSubH == 4, "subtile height");
 constexpr int kBinCap = 128;                                 // subtiles one destination tile can list
 constexpr int kBinSpread = 256;                              // destination tiles one subtile may touch
 constexpr int kSpLong = 64;   // longest cell list (source pixels whose end points share one unit cell) that is summed in raster order
@@ -1184,12 +1219,14 @@ __device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy,
     sp_finish_src(s, sx4, sy, inimg, a, b, wm4, q);
 }
 
-// min / max of two packed 16-bit fields over the 16 lanes of a DPP row (every lane of the row gets the result)
+// min / max of two packed 16-bit fields over the lanes of a subtile (16: a DPP row, 8: half a row; every lane gets the result)
 __device__ __forceinline__ int row_pk_min_dpp(int v) {
-    v = pk_min16(v, OFL_DPP(v, 0xB1)); v = pk_min16(v, OFL_DPP(v, 0x4E)); v = pk_min16(v, OFL_DPP(v, 0x141)); return pk_min16(v, OFL_DPP(v, 0x140));
+    v = pk_min16(v, OFL_DPP(v, 0xB1)); v = pk_min16(v, OFL_DPP(v, 0x4E)); v = pk_min16(v, OFL_DPP(v, 0x141));
+    return kSubLanes == 16 ? pk_min16(v, OFL_DPP(v, 0x140)) : v;          // (8 lanes: the half-row mirror completes it)
 }
 __device__ __forceinline__ int row_pk_max_dpp(int v) {
-    v = pk_max16(v, OFL_DPP(v, 0xB1)); v = pk_max16(v, OFL_DPP(v, 0x4E)); v = pk_max16(v, OFL_DPP(v, 0x141)); return pk_max16(v, OFL_DPP(v, 0x140));
+    v = pk_max16(v, OFL_DPP(v, 0xB1)); v = pk_max16(v, OFL_DPP(v, 0x4E)); v = pk_max16(v, OFL_DPP(v, 0x141));
+    return kSubLanes == 16 ? pk_max16(v, OFL_DPP(v, 0x140)) : v;
 }
 
 constexpr int kBinLocal = 64;   // destination tiles one 64 x 16 source region aggregates in LDS (more: straight to the global counters)
@@ -1205,7 +1242,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     const int sub = lane >> 4, r = (lane >> 2) & 3, c4 = lane & 3;       // subtile of the wave, row and 4-pixel group in it
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
-    const int sx4 = rx * (4 * kSubW) + sub * kSubW + c4 * 4, sy = ry * (4 * kSubH) + wave * kSubH + r;
+    const int sx4 = rx * (4 * kSubW) + sub * kSubW + c4 * 4, sy = ry * kRegH + wave * 4 + r;
     const bool inimg = (sx4 < w) && (sy < h);
     SpSrc q;
     sp_load_src<TF>(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
@@ -1225,17 +1262,18 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
             }
         }
     }
-    lo = row_pk_min_dpp(lo); hi = row_pk_max_dpp(hi);                    // over the subtile (16 lanes)
+    lo = row_pk_min_dpp(lo); hi = row_pk_max_dpp(hi);                    // over the subtile
     const int minx = (int)(short)(lo & 0xffff), miny = lo >> 16, maxx = (int)(short)(hi & 0xffff), maxy = hi >> 16;
     const bool any = maxx >= minx && maxy >= miny;                       // something of this subtile lands inside the image
     // destination tiles of the subtile (as packed 16-bit pairs, for the block-wide union)
     const int tlo = any ? (int)((uint32_t)(minx / kSpTW) | ((uint32_t)(miny / kSpTH) << 16)) : 0x7fff7fff;
     const int thi = any ? (int)((uint32_t)(maxx / kSpTW) | ((uint32_t)(maxy / kSpTH) << 16)) : (int)0xffffffffu;
     {
-        const int a = pk_min16(pk_min16(__builtin_amdgcn_readlane(tlo, 0), __builtin_amdgcn_readlane(tlo, 16)),
-                               pk_min16(__builtin_amdgcn_readlane(tlo, 32), __builtin_amdgcn_readlane(tlo, 48)));
-        const int b = pk_max16(pk_max16(__builtin_amdgcn_readlane(thi, 0), __builtin_amdgcn_readlane(thi, 16)),
-                               pk_max16(__builtin_amdgcn_readlane(thi, 32), __builtin_amdgcn_readlane(thi, 48)));
+        int a = __builtin_amdgcn_readlane(tlo, 0), b = __builtin_amdgcn_readlane(thi, 0);
+#pragma unroll
+        for (int l = kSubLanes; l < 64; l += kSubLanes) {
+            a = pk_min16(a, __builtin_amdgcn_readlane(tlo, l)); b = pk_max16(b, __builtin_amdgcn_readlane(thi, l));
+        }
         if (lane == 0) { red[wave][0] = a; red[wave][1] = b; }
     }
     __syncthreads();
@@ -1248,16 +1286,16 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     const bool local = bnt <= kBinLocal;                                 // block-uniform
     const int tx0 = minx / kSpTW, tx1 = maxx / kSpTW, ty0 = miny / kSpTH, ty1 = maxy / kSpTH;
     const int ntx = tx1 - tx0 + 1, cnt = any ? ntx * (ty1 - ty0 + 1) : 0;
-    const uint32_t subid = (uint32_t)((ry * 4 + wave) * p.subs_x + rx * 4 + sub);
+    const uint32_t subid = (uint32_t)(((ry * 4 + wave) * (4 / kSubH) + r / kSubH) * p.subs_x + rx * 4 + sub);
     if (cnt > kBinSpread) {                                              // a subtile torn over the whole frame: two-pass path
-        if ((lane & 15) == 0) atomicOr(&p.img_over[n], 1);
+        if ((lane & (kSubLanes - 1)) == 0) atomicOr(&p.img_over[n], 1);
     }
-    const int j0 = lane & 15;
-    // the common case: at most 16 destination tiles per subtile (one per lane), all inside the region's local grid -- ranks
+    const int j0 = lane & (kSubLanes - 1);
+    // the common case: at most kSubLanes destination tiles per subtile (one per lane), all inside the region's local grid -- ranks
     // from LDS atomics, then ONE global atomic per (source region, destination tile) instead of one per (subtile, tile):
     // device-scope atomics go all the way to memory and cost ~1 us each
     int lt = -1, rank = 0;
-    const bool fast = local && cnt <= 16;
+    const bool fast = local && cnt <= kSubLanes;
     if (fast && j0 < cnt) {
         const int jy = j0 / ntx;
         lt = (ty0 + jy - bty0) * bntx + (tx0 + (j0 - jy * ntx) - btx0);
@@ -1281,7 +1319,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
         }
     }
     if (!fast && cnt <= kBinSpread) {                                    // wide spreads: straight to the global counters
-        for (int j = j0; j < cnt; j += 16) {
+        for (int j = j0; j < cnt; j += kSubLanes) {
             const int jy = j / ntx;
             const int64_t d = (int64_t)n * p.tiles_img + (ty0 + jy) * p.tiles_x + tx0 + (j - jy * ntx);
             const int pos = atomicAdd(&p.cnt[d], 1);
@@ -1532,7 +1570,6 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
 // re-reads them 16 lanes at a time: 1 000 of the 1 300 VALU instructions a wave executed per tile were v_readlane /
 // v_writelane (rocprofv3 SQ_INSTS_VALU with and without the sort / sum phases: profiles/r2_splat_gather_sq_*.txt).
 typedef const GatherParams __attribute__((address_space(4))) GatherParamsK;
-#define OFL_OPAQUE_S(ptr_) asm volatile("" : "+s"(ptr_))
 
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const GatherParams p_by_value_unused) {
@@ -1559,7 +1596,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
-    constexpr int kHalf = kSpNT2 / 16, kStep = 2 * kHalf;             // subtiles per half step (one per DPP row of lanes) / per step
+    constexpr int kHalf = kSpNT2 / kSubLanes, kStep = 2 * kHalf;      // subtiles per half step (kSubLanes lanes each) / per step
     int tx, ty, n;
     if (!decode3(p.total, p.per_xcd, p.tiles_img, p.mi_m, p.mi_s, p.mx_m, p.mx_s, p.tiles_x, tx, ty, n)) return;
     if (p.img_over[n] != 0) return;                                   // this image takes the global-atomics path instead
@@ -1567,14 +1604,14 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     const uint32_t* __restrict__ lst = p.list + (int64_t)tile * kBinCap;
     // the first 32 entries of the list are fetched WITH its length (the list has a fixed address and kBinCap slots: entries
     // past the length are stale ids that are never used): one round trip for the list, one for the end points, one for the data
-    const uint32_t pre[2] = {lst[tid >> 4], lst[kHalf + (tid >> 4)]};
+    const uint32_t pre[2] = {lst[tid / kSubLanes], lst[kHalf + tid / kSubLanes]};
     const int nlist = min(p.cnt[tile], kBinCap);
     OFL_OPAQUE_S(pp);
     SpTile t;
     sp_tile_setup<TF>(s, tx, ty, n, t);
     const int dx0 = t.dx0, dy0 = t.dy0, ly = t.ly, lx2 = t.lx2;
     int dflags = 0;
-    const int sl = tid & 15, srow = sl >> 2, sc4 = sl & 3;
+    const int sl = tid & (kSubLanes - 1), srow = sl >> 2, sc4 = sl & 3;
     // ---- A: walk the tile's list, 32 subtiles per step (4 source pixels per lane and half step), in three waves of loads:
     // list -> flow + weight mask of both halves -> data of the 4-pixel groups that have a pixel in the tile.  The pixels
     // whose cell lies in the tile (cell rows r0 .. r1) become LDS records and join their cell; qcount ends up as the number
@@ -1635,9 +1672,11 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             SpSrc q[2];
             int sx4[2], sy[2];
             bool inb[2];
+            const bool two = base + kHalf < nlist;             // block-uniform: the second half step has entries
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = base + u * kHalf + (tid >> 4);
+                if (u == 1 && !two) { inb[1] = false; sx4[1] = sy[1] = 0; continue; }
+                const int e = base + u * kHalf + tid / kSubLanes;
                 const bool have = e < nlist;
                 const uint32_t sub = base == 0 ? pre[u] : (have ? lst[e] : 0u);
                 const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
@@ -1654,8 +1693,8 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
                 if (inb[u]) sp_load_data<NC, MCH, TF>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
             }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) process(q[u], sx4[u], sy[u], dat[u], mc4[u], r0, r1);
+            process(q[0], sx4[0], sy[0], dat[0], mc4[0], r0, r1);
+            if (two) process(q[1], sx4[1], sy[1], dat[1], mc4[1], r0, r1);
         }
     };
     using std::integral_constant;
@@ -1849,9 +1888,9 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const Gathe
         __syncthreads();
         for (int i = tid; i < (1 + NCH) * kPx; i += kSpNT2) acc[i] = 0.0f;
         __syncthreads();
-        const int sl = tid & 15, srow = sl >> 2, sc4 = sl & 3;
-        for (int base = 0; base < nlist; base += kSpNT2 / 16) {
-            const int e = base + (tid >> 4);
+        const int sl = tid & (kSubLanes - 1), srow = sl >> 2, sc4 = sl & 3;
+        for (int base = 0; base < nlist; base += kSpNT2 / kSubLanes) {
+            const int e = base + tid / kSubLanes;
             const bool have = e < nlist;
             const uint32_t sub = have ? lst[e] : 0u;
             const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
@@ -2061,6 +2100,13 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         return (int)hipGetLastError();
     }
     // (the fused composition -- ADD -- keeps the pair kernel: as a column its re-used flow registers spill, 1.03 instead of 0.92 ms)
+    if (OFL_WARP_COL_ADD && kLdsT > 2 && add && NC == 2 && !p.flow_flags) {
+        WarpParams q = p;
+        const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        return (int)hipGetLastError();
+    }
     if (kLdsT > 2 && !add && !p.flow_flags) {              // a plain warp (Flow.apply 't' of an image or a flow): columns of kLdsT tiles
         WarpParams q = p;
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
@@ -2481,7 +2527,7 @@ static int splat_tiled_impl(
     magic_u32(gp.tiles_img, gp.mi_m, gp.mi_s);
     gp.subs_x = (w + kSubW - 1) / kSubW;
     magic_u32((uint32_t)gp.subs_x, gp.sx_m, gp.sx_s);
-    gp.regs_x = (w + 4 * kSubW - 1) / (4 * kSubW); gp.regs_y = (h + 4 * kSubH - 1) / (4 * kSubH);
+    gp.regs_x = (w + 4 * kSubW - 1) / (4 * kSubW); gp.regs_y = (h + kRegH - 1) / kRegH;
     gp.regs_img = (uint32_t)(gp.regs_x * gp.regs_y);
     magic_u32((uint32_t)gp.regs_x, gp.rx_m, gp.rx_s);
     magic_u32(gp.regs_img, gp.ri_m, gp.ri_s);

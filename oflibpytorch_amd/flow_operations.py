@@ -51,6 +51,13 @@ def valid_source(flow, ref: str, consider_mask: bool = None) -> torch.Tensor:
     return area if len(flow.shape) > 3 else area.squeeze(0)
 
 
+def get_flow_padding(flow, ref: str) -> list:
+    """[top, bottom, left, right] per batch member (one list for 3-D input): Flow(flow, ref).get_padding()
+    (flow_operations.py:280-303)"""
+    p = Flow(flow, ref).get_padding()
+    return p if len(flow.shape) > 3 else p[0]
+
+
 def batch_flows(flows: Union[list, tuple]) -> FlowAlias:
     """Concatenate flow objects of equal H, W, ref and device along the batch axis (flow_operations.py:458-483)"""
     if not isinstance(flows, (list, tuple)):

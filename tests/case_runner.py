@@ -111,6 +111,10 @@ def run_case(case, golden, device):
         return {"out": o, "status": st}
     if op == 'Flow.get_padding':
         return {"_padding": _flow(i, "f", "m", a["ref"], d).get_padding(a["item"])}
+    if op == 'get_flow_padding':
+        v = T(i["flow_raw"], d)
+        arg = {'nchw': v, 'chw': v[0], 'hwc_np': v[1].permute(1, 2, 0).cpu().numpy()}[a["layout"]]
+        return {"_padding": ofl.get_flow_padding(arg, a["ref"])}
     if op.startswith('grad_'):
         return run_grad_case(case, golden, device)
     if op == 'kat_gfud':
@@ -210,7 +214,7 @@ def check_case(case, golden, got, exact_values=True, rtol=0.0, atol=0.0, max_mas
         s = float(vec.astype(np.float64).sum())
         assert abs(s - a["sum"]) <= 1e-6 * max(a["abs_sum"], 1.0), (s, a["sum"])
         return report
-    if op == 'Flow.get_padding':
+    if op in ('Flow.get_padding', 'get_flow_padding'):
         assert got["_padding"] == a["padding"], (got["_padding"], a["padding"])
         return report
     for k, e in exp.items():

@@ -624,6 +624,14 @@ def gen_next():
     tiny = Flow(torch.rand(1, 2, 7, 7, generator=torch.Generator().manual_seed(5)) * 1e-4)
     rec(g, 'get_padding_tiny', 'Flow.get_padding', {"ref": 't', "item": None, "padding": tiny.get_padding()},
         flow_inputs(tiny), {})
+    # the functional wrapper (flow_operations.py:280-303): 4-D -> list of lists, 3-D -> one list; H-W-2 numpy input
+    v = smooth_flow(2, h, w, 6.0, 322)
+    rec(g, 'get_flow_padding_4d_s', 'get_flow_padding', {"ref": 's', "layout": 'nchw', "padding": of.get_flow_padding(v, 's')},
+        {"flow_raw": v}, {})
+    rec(g, 'get_flow_padding_3d_t', 'get_flow_padding', {"ref": 't', "layout": 'chw', "padding": of.get_flow_padding(v[0], 't')},
+        {"flow_raw": v}, {})
+    rec(g, 'get_flow_padding_hw2_numpy_t', 'get_flow_padding',
+        {"ref": 't', "layout": 'hwc_np', "padding": of.get_flow_padding(v[1].permute(1, 2, 0).numpy(), 't')}, {"flow_raw": v}, {})
 
 
 # ------------------------------------------------------------------------------------------------
