@@ -1123,7 +1123,7 @@ constexpr int kSubW = 16, kSubH = OFL_SP_SUBH;               // source subtiles:
 constexpr int kSubLanes = 4 * kSubH;                         // lanes per subtile (16: a DPP row; 8: half a row)
 constexpr int kRegH = 16;                                    // a bin block covers a 64 x 16 source region (its wave w: rows 4 w .. 4 w + 3)
 static_assert(kSubH == 2 || kSubH == 4, "subtile height");
-constexpr int kBinCap = 128;                                 // subtiles one destination tile can list
+constexpr int kBinCap = 512 / kSubH;                         // subtiles one destination tile can list (fixed-address lists: 4 * kBinCap bytes per tile)
 constexpr int kBinSpread = 256;                              // destination tiles one subtile may touch
 constexpr int kSpLong = 64;   // longest cell list (source pixels whose end points share one unit cell) that is summed in raster order
 
@@ -1231,6 +1231,12 @@ __device__ __forceinline__ int row_pk_max_dpp(int v) {
 
 constexpr int kBinLocal = 64;   // destination tiles one 64 x 16 source region aggregates in LDS (more: straight to the global counters)
 
+// image n leaves the gather path (a list overflowed / a subtile is torn over the frame): its flag, and the statistics of
+// the call -- stats[0] some image took the two-pass path, stats[2] how many (the first thread to flag an image counts it)
+__device__ __forceinline__ void sp_flag_image(const GatherParams& p, int n) {
+    if (atomicOr(&p.img_over[n], 1) == 0) { atomicOr(&p.stats[0], 1); atomicAdd(&p.stats[2], 1); }
+}
+
 template <typename TF>
 __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     __shared__ int red[4][2];
@@ -1288,7 +1294,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     const int ntx = tx1 - tx0 + 1, cnt = any ? ntx * (ty1 - ty0 + 1) : 0;
     const uint32_t subid = (uint32_t)(((ry * 4 + wave) * (4 / kSubH) + r / kSubH) * p.subs_x + rx * 4 + sub);
     if (cnt > kBinSpread) {                                              // a subtile torn over the whole frame: two-pass path
-        if ((lane & (kSubLanes - 1)) == 0) atomicOr(&p.img_over[n], 1);
+        if ((lane & (kSubLanes - 1)) == 0) sp_flag_image(p, n);
     }
     const int j0 = lane & (kSubLanes - 1);
     // the common case: at most kSubLanes destination tiles per subtile (one per lane), all inside the region's local grid -- ranks
@@ -1308,7 +1314,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
             const int64_t d = (int64_t)n * p.tiles_img + (bty0 + ly_) * p.tiles_x + btx0 + (tid - ly_ * bntx);
             const int start = atomicAdd(&p.cnt[d], lcount[tid]);
             lbase[tid] = start;
-            if (start + lcount[tid] > kBinCap) atomicOr(&p.img_over[n], 1);
+            if (start + lcount[tid] > kBinCap) sp_flag_image(p, n);
         }
         __syncthreads();
         if (lt >= 0) {
@@ -1324,7 +1330,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
             const int64_t d = (int64_t)n * p.tiles_img + (ty0 + jy) * p.tiles_x + tx0 + (j - jy * ntx);
             const int pos = atomicAdd(&p.cnt[d], 1);
             if (pos < kBinCap) p.list[d * kBinCap + pos] = subid;
-            else atomicOr(&p.img_over[n], 1);
+            else sp_flag_image(p, n);
         }
     }
 }
@@ -1563,6 +1569,13 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
     }
     mc4 = nz_bytes(ma) & nz_bytes(mb);
 }
+
+#ifndef OFL_SP_FB_KERNEL
+#define OFL_SP_FB_KERNEL 0      // 1: fold tiles go to a list and a second kernel (the round-2 first cut); 0: redone in place
+#endif
+template <int NC, bool MCH, typename TF, typename TO, typename GP, typename SP>
+__device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float* acc, const uint32_t* __restrict__ lst, int nlist,
+                                                const SpTile& t, int n);
 
 // The gather kernel reads its ~400 bytes of parameters from the KERNARG SEGMENT through a pointer that is made opaque at
 // every phase boundary (OFL_OPAQUE_S): the compiler then fetches what a phase needs with scalar loads where it needs it.
@@ -1846,10 +1859,16 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
         __syncthreads();
     }
     if (over) {
-        // a fold (more records than four bands hold, or > 64 sources in one cell): this tile is redone with LDS float
-        // atomics by splat_tile_fallback_kernel (same stream, right after this kernel); whatever its first bands stored is
-        // overwritten there, and its flag word comes from there
+        // a fold (more records than four bands hold, or > 64 sources in one cell)
+#if OFL_SP_FB_KERNEL
         if (tid == 0) { p.fb_list[atomicAdd(&p.stats[3], 1)] = (int32_t)tile; atomicAdd(&p.stats[1], 1); }
+#else
+        // redone at once by this block with LDS float atomics (the records are dead: their LDS is the accumulator); whatever
+        // the first bands stored is overwritten, and the tile's flag word comes from here
+        if (tid == 0) atomicAdd(&p.stats[1], 1);
+        OFL_OPAQUE_S(pp);
+        sp_tile_atomics<NC, MCH, TF, TO>(p, s, reinterpret_cast<float*>(raw), lst, nlist, t, n);
+#endif
         return;
     }
     if (NC == 2 && s.dst_flags) {                             // (every thread of the block gets here)
@@ -1860,19 +1879,81 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
 #undef p
 }
 
-// The tiles the gather kernel could not sum in order (heavy folds of the flow): LDS float atomics over the tile's list
-// (plane 0 density, then the data channels; the mask channel accumulates the INVALID weight, so that an all-valid pixel is
-// exactly 1 in any order).  Tolerance instead of bit-exactness for these tiles; masks stay exact.  A persistent grid walks
-// the list of such tiles the gather kernel left (usually empty: the kernel ends at once).
+// A tile the gather kernel cannot sum in order (a heavy fold of the flow): LDS float atomics over the tile's list (plane 0
+// density, then the data channels; the mask channel accumulates the INVALID weight, so that an all-valid pixel is exactly 1
+// in any order).  Tolerance instead of bit-exactness for these tiles; masks stay exact.  `acc` = (1 + NCH) * 512 floats of
+// LDS no thread of the block still reads; every thread of the block calls this.
+template <int NC, bool MCH, typename TF, typename TO, typename GP, typename SP>
+__device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float* acc, const uint32_t* __restrict__ lst, int nlist,
+                                                const SpTile& t, int n) {
+    constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
+    __syncthreads();
+    for (int i = tid; i < (1 + NCH) * kPx; i += kSpNT2) acc[i] = 0.0f;
+    __syncthreads();
+    const int sl = tid & (kSubLanes - 1), srow = sl >> 2, sc4 = sl & 3;
+    for (int base = 0; base < nlist; base += kSpNT2 / kSubLanes) {
+        const int e = base + tid / kSubLanes;
+        const bool have = e < nlist;
+        const uint32_t sub = have ? lst[e] : 0u;
+        const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
+        const int sx4 = (int)subx * kSubW + sc4 * 4, sy = (int)suby * kSubH + srow;
+        const bool in = have && (sx4 < w) && (sy < h);
+        SpSrc q;
+        sp_load_src<TF>(s, n, sx4, sy, in, (uint32_t)(sy * w + sx4), hw, q);
+        f4 dat[NC];
+        uint32_t mc4 = 0x01010101u;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dat[c] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (q.on != 0u) sp_load_data<NC, MCH, TF>(s, n, sx4, sy, hw, dat, mc4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((q.on >> k) & 1u)) continue;
+            float wx[2], wy[2]; int ix[2], iy[2];
+            sp_corners(q.x[k], q.y[k], wmax, hmax, t.dx0, t.dy0, wx, wy, ix, iy);
+            const bool invalid = MCH ? (((mc4 >> (8 * k)) & 1u) == 0u) : false;
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx) {
+                    const float wgt = wy[ky] * wx[kx];
+                    const int xl = ix[kx], yl = iy[ky];
+                    if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
+                    const int d = yl * kSpTW + xl;
+                    atomicAdd(&acc[d], wgt);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) atomicAdd(&acc[(1 + c) * kPx + d], wgt * (s.data_sign * dat[c][k]));
+                    if (MCH && invalid) atomicAdd(&acc[(1 + NC) * kPx + d], wgt);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int dflags = 0;
+    float tot[2][1 + NCH];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int d = t.ly * kSpTW + max(t.lx2 + k, 0);
+#pragma unroll
+        for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
+        if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];      // density - invalid weight
+    }
+    sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg, dflags);
+    if (NC == 2 && s.dst_flags) {
+        dflags = wave_or_flags(dflags);
+        if (lane == 0) flag_or(&s.dst_flags[n], dflags);
+    }
+}
+
+// (OFL_SP_FB_KERNEL builds only: the gather kernel leaves its fold tiles on a list and this persistent grid redoes them)
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 __global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const GatherParams p) {
     constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0);
     __shared__ float acc[(1 + NCH) * kPx];
     const SplatParams& s = p.s;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = s.w, h = s.h;
-    const uint32_t hw = (uint32_t)(h * w);
-    const float wmax = (float)(w - 1), hmax = (float)(h - 1);
     const int count = p.stats[3];                                     // (of this launch; stats[1] counts the whole call)
     for (int item = blockIdx.x; item < count; item += gridDim.x) {
         const uint32_t tile = (uint32_t)p.fb_list[item];              // the tile the gather kernel gave up on
@@ -1881,65 +1962,9 @@ __global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const Gathe
         const uint32_t yy = fastdiv(rem, p.mx_m, p.mx_s);
         const int n = (int)nn, ty = (int)yy, tx = (int)(rem - yy * (uint32_t)p.tiles_x);
         const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
-        const uint32_t* __restrict__ lst = p.list + dtile * kBinCap;
-        const int nlist = min(p.cnt[dtile], kBinCap);
         SpTile t;
         sp_tile_setup<TF>(s, tx, ty, n, t);
-        __syncthreads();
-        for (int i = tid; i < (1 + NCH) * kPx; i += kSpNT2) acc[i] = 0.0f;
-        __syncthreads();
-        const int sl = tid & (kSubLanes - 1), srow = sl >> 2, sc4 = sl & 3;
-        for (int base = 0; base < nlist; base += kSpNT2 / kSubLanes) {
-            const int e = base + tid / kSubLanes;
-            const bool have = e < nlist;
-            const uint32_t sub = have ? lst[e] : 0u;
-            const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
-            const int sx4 = (int)subx * kSubW + sc4 * 4, sy = (int)suby * kSubH + srow;
-            const bool in = have && (sx4 < w) && (sy < h);
-            SpSrc q;
-            sp_load_src<TF>(s, n, sx4, sy, in, (uint32_t)(sy * w + sx4), hw, q);
-            f4 dat[NC];
-            uint32_t mc4 = 0x01010101u;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dat[c] = (f4){0.f, 0.f, 0.f, 0.f};
-            if (q.on != 0u) sp_load_data<NC, MCH, TF>(s, n, sx4, sy, hw, dat, mc4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!((q.on >> k) & 1u)) continue;
-                float wx[2], wy[2]; int ix[2], iy[2];
-                sp_corners(q.x[k], q.y[k], wmax, hmax, t.dx0, t.dy0, wx, wy, ix, iy);
-                const bool invalid = MCH ? (((mc4 >> (8 * k)) & 1u) == 0u) : false;
-#pragma unroll
-                for (int ky = 0; ky < 2; ++ky) {
-#pragma unroll
-                    for (int kx = 0; kx < 2; ++kx) {
-                        const float wgt = wy[ky] * wx[kx];
-                        const int xl = ix[kx], yl = iy[ky];
-                        if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
-                        const int d = yl * kSpTW + xl;
-                        atomicAdd(&acc[d], wgt);
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) atomicAdd(&acc[(1 + c) * kPx + d], wgt * (s.data_sign * dat[c][k]));
-                        if (MCH && invalid) atomicAdd(&acc[(1 + NC) * kPx + d], wgt);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        int dflags = 0;
-        float tot[2][1 + NCH];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int d = t.ly * kSpTW + max(t.lx2 + k, 0);
-#pragma unroll
-            for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
-            if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];      // density - invalid weight
-        }
-        sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg, dflags);
-        if (NC == 2 && s.dst_flags) {
-            dflags = wave_or_flags(dflags);
-            if (lane == 0) flag_or(&s.dst_flags[n], dflags);
-        }
+        sp_tile_atomics<NC, MCH, TF, TO>(p, s, acc, p.list + dtile * kBinCap, min(p.cnt[dtile], kBinCap), t, n);
     }
 }
 
@@ -1952,15 +1977,6 @@ __global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ pt
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
         reinterpret_cast<f4u*>(q)[i] = (f4){0.f, 0.f, 0.f, 0.f};
     if (blockIdx.x == 0 && threadIdx.x < (count_per_image & 3)) q[(n4 << 2) + threadIdx.x] = 0.0f;
-}
-
-// statistics of a launch: [0] some image took the two-pass path, [2] how many
-__global__ void splat_stats_kernel(const int32_t* __restrict__ img_over, int32_t n, int32_t* __restrict__ stats) {
-    int k = 0;
-    for (int i = threadIdx.x; i < n; i += 64) k += img_over[i] != 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o);
-    if (threadIdx.x == 0 && k) { atomicOr(&stats[0], 1); atomicAdd(&stats[2], k); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2172,7 +2188,9 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+#if OFL_SP_FB_KERNEL
     hipLaunchKernelGGL((splat_tile_fallback_kernel<NC, MCH, TF, TO>), dim3(512), dim3(kSpNT2), 0, st, gp);
+#endif
     return (int)hipGetLastError();
 }
 
@@ -2538,8 +2556,7 @@ static int splat_tiled_impl(
     gp.fb_list = gp.cnt + ((ctiles + 3) & ~(int64_t)3);
     gp.list = reinterpret_cast<uint32_t*>(gp.fb_list + ((ctiles + 3) & ~(int64_t)3));
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(gp.stats, 0, 8 * sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;                          // (the statistics words are zeroed with the first pass's list lengths)
     if (dst_flags) {
         e = hipMemsetAsync(dst_flags, 0, (size_t)n * sizeof(int32_t), st);
         if (e != hipSuccess) return (int)e;
@@ -2573,13 +2590,14 @@ static int splat_tiled_impl(
         gp.rtotal = (int64_t)gp.regs_img * nn;
         gp.rper_xcd = (gp.rtotal + kXcds - 1) / kXcds;
         // per-image fallback flags and list lengths of this pass
-        e = hipMemsetAsync(gp.img_over, 0, (size_t)(((chunk + 3) & ~(int64_t)3) + ctiles) * sizeof(int32_t), st);
+        const size_t zwords = (size_t)(((chunk + 3) & ~(int64_t)3) + ctiles);
+        e = n0 == 0 ? hipMemsetAsync(gp.stats, 0, (8 + zwords) * sizeof(int32_t), st)      // statistics | flags | lengths: contiguous
+                    : hipMemsetAsync(gp.img_over, 0, zwords * sizeof(int32_t), st);
         if (e != hipSuccess) return (int)e;
         if (half_in) hipLaunchKernelGGL(splat_bin_kernel<_Float16>, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
         else hipLaunchKernelGGL(splat_bin_kernel<float>, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
         rc = (int)hipGetLastError();
         if (rc) return rc;
-        hipLaunchKernelGGL(splat_stats_kernel, dim3(1), dim3(64), 0, st, gp.img_over, (int32_t)nn, gp.stats);
         // more than 3 channels: groups of 3 (a record holds 3 data channels); density and masks come out of the first group
         for (int32_t c0 = 0; c0 < c; c0 += 3) {
             SplatParams full = base;
@@ -2589,8 +2607,10 @@ static int splat_tiled_impl(
             if (c0 > 0) { full.with_mask_chan = 0; full.density = nullptr; full.warped = nullptr; full.valid = nullptr; full.mask_chan = nullptr; }
             const int32_t cg = full.c;
             gp.s = full;
+#if OFL_SP_FB_KERNEL
             e = hipMemsetAsync(gp.stats + 3, 0, sizeof(int32_t), st);      // tiles this launch hands to the fallback kernel
             if (e != hipSuccess) return (int)e;
+#endif
             const unsigned grid = (unsigned)(gp.per_xcd * kXcds);
             if (half_in) rc = launch_splat_gather_half(gp, grid, st, elem);
             else switch (cg) {
@@ -2604,7 +2624,7 @@ static int splat_tiled_impl(
             SplatParams fb = gp.s;
             fb.accum = accum_fallback;
             fb.run_if_set = gp.img_over;
-            fb.any_set = gp.stats;                            // stats[0]: some image of the pass is flagged (splat_stats_kernel)
+            fb.any_set = gp.stats;                            // stats[0]: some image (of this or an earlier pass) is flagged
             const int planes = 1 + cg + (fb.with_mask_chan ? 1 : 0);
             hipLaunchKernelGGL(zero_if_set_kernel, dim3(64, (unsigned)nn), dim3(256), 0, st, accum_fallback, (int64_t)planes * hw, gp.img_over);
             unsigned g2;

@@ -3,5 +3,5 @@
 sigma=$1; shift
 for lib in "$@"; do
   echo "== $(basename $lib .so)"
-  OFL_HIP_LIB="$PWD/$lib" python3 tools/bench_splat.py --sigma $sigma 2>/dev/null | tail -2 | cut -c1-90
+  OFL_HIP_LIB="$PWD/$lib" python3 tools/bench_splat.py --sigma $sigma 2>/dev/null | tail -2 | cut -c1-190
 done
