@@ -1135,9 +1135,8 @@ struct GatherParams {
     SplatParams s;
     int32_t* cnt;          // [n * tiles] subtiles listed for the tile
     uint32_t* list;        // [n * tiles][kBinCap] subtile ids (row-major over the image's subtile grid)
-    int32_t* stats;        // [0] some image took the two-pass path | [1] tiles that left the exact path | [2] images that did | [3] tiles of the current launch
+    int32_t* stats;        // [0] some image took the two-pass path | [1] tiles that left the exact path | [2] images that did (the rest: diagnostics of OFL_SP_DIAG builds)
     int32_t* img_over;     // [n] this image takes the two-pass path
-    int32_t* fb_list;      // [n * tiles] gather blocks whose tile left the exact path (stats[1] of them): redone by splat_tile_fallback_kernel
     int32_t tiles_x, tiles_y;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;
     int64_t total, per_xcd;
@@ -1379,6 +1378,22 @@ __device__ __forceinline__ void sp_use(const f4* rec4, uint32_t i, float (&a)[2]
     }
 }
 
+// A cell that phase S has already summed (more than two records): its class sums lie where its first three records were,
+// one f4 per channel (density, data ..., mask) holding the four corner classes in the order of a record's weights.
+template <int NCH, int DC, int KY>
+__device__ __forceinline__ void sp_use_presum(const f4* rec4, uint32_t ia, uint32_t ib, uint32_t ic, float (&a)[2][2][1 + NCH]) {
+#pragma unroll
+    for (int c = 0; c < 1 + NCH; ++c) {
+        const f4 pv = c < 2 ? rec4[2 * ia + c] : c < 4 ? rec4[2 * ib + (c - 2)] : rec4[2 * ic];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int kx = k - DC;
+            if (kx < 0 || kx > 1) continue;
+            a[k][kx][c] += pv[KY * 2 + kx];
+        }
+    }
+}
+
 // exchange with the neighbouring lane (lanes 2j <-> 2j + 1): the pair's partner owns the other half of a 4-pixel group
 __device__ __forceinline__ float swap1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); }
 __device__ __forceinline__ uint32_t swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }
@@ -1570,9 +1585,6 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
     mc4 = nz_bytes(ma) & nz_bytes(mb);
 }
 
-#ifndef OFL_SP_FB_KERNEL
-#define OFL_SP_FB_KERNEL 0      // 1: fold tiles go to a list and a second kernel (the round-2 first cut); 0: redone in place
-#endif
 template <int NC, bool MCH, typename TF, typename TO, typename GP, typename SP>
 __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float* acc, const uint32_t* __restrict__ lst, int nlist,
                                                 const SpTile& t, int n);
@@ -1589,7 +1601,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     GatherParamsK* pp = (GatherParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
     constexpr int NCH = NC + (MCH ? 1 : 0);
-    constexpr uint32_t kEnd = 0xffffu, kLongCell = 0xfffeu;
+    constexpr uint32_t kEnd = 0xffffu, kLongCell = 0xfffeu;     // (kLongCell in a cell's first slot: phase S summed it)
     // A CELL is a unit square of the destination grid: the records whose end point has floor(x, y) = (cx, cy).  The four
     // corner classes of a destination pixel (X, Y) are the cells (X - kx, Y - ky), so one list per cell serves them all:
     // (kSpTW + 1) x (kSpTH + 1) cells per tile, the first column / row being the cells left of / above the tile.
@@ -1599,6 +1611,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     // of a cell's 5th, 6th ... record (later: of its sorted list) | chain links
     __shared__ __attribute__((aligned(16))) unsigned char raw[kSpQ * 32 + kCellsP * 4 + kCellsP * 8 + kCellsP * 4 + kSpQ * 2];
     __shared__ int qcount;
+    // cells with more than two records (at most kSpQ / 3 of them), collected so that phase S works on them lane by lane
+    constexpr int kLongQ = (kSpQ / 3 + 7) & ~7;
+    __shared__ uint16_t lq[kLongQ];
+    __shared__ int lqn;
     f4* rec4 = reinterpret_cast<f4*>(raw);                            // rec4[2 * i] weights, rec4[2 * i + 1] data | key
     const uint32_t* rwords = reinterpret_cast<const uint32_t*>(raw);  // key of record i: rwords[8 * i + 7]
     uint32_t* ccnt = reinterpret_cast<uint32_t*>(raw + kSpQ * 32);    // [kCellsP]: records of the cell
@@ -1725,7 +1741,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                     ccnt[tid + i * kSpNT2] = 0u; ohead[tid + i * kSpNT2] = kEnd;
                     slots[tid + i * kSpNT2] = make_uint2(0xffffffffu, 0xffffffffu);
                 }
-            if (tid == 0) qcount = 0;
+            if (tid == 0) {
+                qcount = 0;
+                lqn = 0;
+            }
             __syncthreads();
             scan(r0, r1, 0);
             __syncthreads();                                   // records, cells and the count are in place
@@ -1746,52 +1765,85 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             // the sums start from +0); three or four are sorted by a network in registers; a longer list (a compression or
             // fold of the flow) becomes a chain sorted by insertion, walked by its readers.
             bool toolong = false;
+            // Cells with one or two records need nothing (a + b = b + a, sums start from +0).  The others -- a few per cent of
+            // the cells, scattered over the lanes -- are first COLLECTED, then handled one per lane: put in raster order (four:
+            // a network in registers; more: insertion sort of the chain) and summed there and then, per corner class, in that
+            // order; the four class sums of every channel overwrite the cell's first three records and its readers add them
+            // as if they were one record.  (Every reader sorting and walking such cells itself kept 60 lanes of a wave idle
+            // while 4 of them worked: -20 % VALU instructions on the bench flow.)
 #pragma unroll
             for (int r = 0; r < kCellRounds; ++r) {
                 const int c = tid + r * kSpNT2;
-                if (c < kCells) {
-                    const uint32_t cn = ccnt[c];
-                    if (cn > 4u) {
-                        // the four slots join the chain of the later records, then an insertion sort of the chain itself.  The
-                        // limit is on the LENGTH (the same in every run, unlike the order the atomics leave): beyond it the tile
-                        // takes the float-atomics fallback.
-                        if (cn > (uint32_t)kSpLong) {
-                            toolong = true;
-                        } else {
-                            const uint2 sl4 = slots[c];
-                            const uint32_t e4[4] = {sl4.x & 0xffffu, sl4.x >> 16, sl4.y & 0xffffu, sl4.y >> 16};
-                            uint32_t cur = ohead[c];
+                if (c < kCells && ccnt[c] > 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)c;
+            }
+            __syncthreads();
+            const int nlong = lqn;
+            for (int qi = tid; qi < nlong; qi += kSpNT2) {
+                const int c = lq[qi];
+                const uint32_t cn = ccnt[c];
+                if (cn > (uint32_t)kSpLong) { toolong = true; continue; }   // the limit is on the LENGTH: the same in every run
+                const uint2 sl4 = slots[c];
+                uint32_t e[4] = {sl4.x & 0xffffu, sl4.x >> 16, sl4.y & 0xffffu, sl4.y >> 16};
+                uint32_t head;
+                if (cn <= 4u) {
+                    uint32_t key[4];
 #pragma unroll
-                            for (int j4 = 0; j4 < 4; ++j4) { link[e4[j4]] = (uint16_t)cur; cur = e4[j4]; }
-                            uint32_t sorted = kEnd;
-                            while (cur != kEnd) {
-                                const uint32_t nxt = link[cur], k = rwords[8 * cur + 7];
-                                if (sorted == kEnd || rwords[8 * sorted + 7] > k) {
-                                    link[cur] = (uint16_t)sorted; sorted = cur;
-                                } else {
-                                    uint32_t q = sorted, qn = link[q];
-                                    while (qn != kEnd && rwords[8 * qn + 7] < k) { q = qn; qn = link[q]; }
-                                    link[cur] = (uint16_t)qn; link[q] = (uint16_t)cur;
-                                }
-                                cur = nxt;
-                            }
-                            ohead[c] = sorted;
-                            slots[c] = make_uint2(kLongCell | (kEnd << 16), 0xffffffffu);
-                        }
-                    } else if (cn > 2u) {
-                        const uint2 sl4 = slots[c];
-                        uint32_t e[4] = {sl4.x & 0xffffu, sl4.x >> 16, sl4.y & 0xffffu, sl4.y >> 16};
-                        uint32_t key[4];
-#pragma unroll
-                        for (int j4 = 0; j4 < 4; ++j4) key[j4] = e[j4] != kEnd ? rwords[8 * e[j4] + 7] : 0xffffffffu;
+                    for (int j4 = 0; j4 < 4; ++j4) key[j4] = e[j4] != kEnd ? rwords[8 * e[j4] + 7] : 0xffffffffu;
 #define OFL_CSWAP(a_, b_) { const bool sw = key[a_] > key[b_]; const uint32_t tk = sw ? key[b_] : key[a_], te = sw ? e[b_] : e[a_]; \
                             key[b_] = sw ? key[a_] : key[b_]; e[b_] = sw ? e[a_] : e[b_]; key[a_] = tk; e[a_] = te; }
-                        OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
+                    OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
 #undef OFL_CSWAP
-                        slots[c] = make_uint2(e[0] | (e[1] << 16), e[2] | (e[3] << 16));
+                    link[e[0]] = (uint16_t)e[1]; link[e[1]] = (uint16_t)e[2]; link[e[2]] = (uint16_t)e[3];   // (e[3] is kEnd for three records)
+                    if (e[3] != kEnd) link[e[3]] = (uint16_t)kEnd;
+                    head = e[0];
+                } else {
+                    uint32_t cur = ohead[c];
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) { link[e[j4]] = (uint16_t)cur; cur = e[j4]; }
+                    uint32_t sorted = kEnd;
+                    while (cur != kEnd) {
+                        const uint32_t nxt = link[cur], k = rwords[8 * cur + 7];
+                        if (sorted == kEnd || rwords[8 * sorted + 7] > k) {
+                            link[cur] = (uint16_t)sorted; sorted = cur;
+                        } else {
+                            uint32_t q = sorted, qn = link[q];
+                            while (qn != kEnd && rwords[8 * qn + 7] < k) { q = qn; qn = link[q]; }
+                            link[cur] = (uint16_t)qn; link[q] = (uint16_t)cur;
+                        }
+                        cur = nxt;
                     }
+                    head = sorted;
                 }
+                // the class sums, in list order: product rounded, then added (as sp_use does for the short cells)
+                f4 sum[1 + NCH];
+#pragma unroll
+                for (int ch = 0; ch < 1 + NCH; ++ch) sum[ch] = (f4){0.f, 0.f, 0.f, 0.f};
+                const uint32_t ia = head, ib = link[ia], ic = link[ib];
+                for (uint32_t i = head; i != kEnd; i = link[i]) {
+                    const f4 wv = rec4[2 * i], dv = rec4[2 * i + 1];
+                    sum[0] += wv;
+#pragma unroll
+                    for (int ch = 0; ch < NC; ++ch) sum[1 + ch] += wv * dv[ch];
+                    if (NCH > NC) sum[1 + NC] += wv * (float)(__float_as_uint(dv[3]) & 1u);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 1 + NCH; ++ch) {
+                    if (ch < 2) rec4[2 * ia + ch] = sum[ch];
+                    else if (ch < 4) rec4[2 * ib + (ch - 2)] = sum[ch];
+                    else rec4[2 * ic] = sum[ch];
+                }
+                slots[c] = make_uint2(kLongCell | (ia << 16), ib | (ic << 16));
             }
+#if OFL_SP_DIAG
+            {
+                int nl = 0, nc = 0, n2 = 0;
+                for (int r = 0; r < kCellRounds; ++r) { const int c = tid + r * kSpNT2; if (c < kCells) { nl += ccnt[c] > 2u; nc += ccnt[c] > 4u; n2 += ccnt[c] == 2u; } }
+                if (nl) atomicAdd(&p.stats[6], nl);
+                if (nc) atomicAdd(&p.stats[7], nc);
+                if (n2) atomicAdd(&p.stats[3], n2);
+                if (tid == 0) { atomicAdd(&p.stats[4], 1); if (nb > 1 && band == 0) atomicAdd(&p.stats[5], 1); }
+            }
+#endif
             over = __syncthreads_or((int)toolong) != 0;
             if (over) break;
             // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.
@@ -1822,15 +1874,9 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                     if (e0 == kEnd) return;
                     if (e0 != kLongCell) {
                         sp_use<NC, NCH, DC, KY>(rec4, e0, a);
-                        if (e1 != kEnd) {
-                            sp_use<NC, NCH, DC, KY>(rec4, e1, a);
-                            if (e2 != kEnd) {
-                                sp_use<NC, NCH, DC, KY>(rec4, e2, a);
-                                if (e3 != kEnd) sp_use<NC, NCH, DC, KY>(rec4, e3, a);
-                            }
-                        }
-                    } else {                                               // phase S left the chain in raster order
-                        for (uint32_t e = ohead[c]; e != kEnd; e = link[e]) sp_use<NC, NCH, DC, KY>(rec4, e, a);
+                        if (e1 != kEnd) sp_use<NC, NCH, DC, KY>(rec4, e1, a);
+                    } else {                                               // phase S left the cell's class sums
+                        sp_use_presum<NCH, DC, KY>(rec4, e1, e2, e3, a);
                     }
                 };
                 clear();                                                   // corner row 0: classes 0, 1
@@ -1860,15 +1906,11 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     }
     if (over) {
         // a fold (more records than four bands hold, or > 64 sources in one cell)
-#if OFL_SP_FB_KERNEL
-        if (tid == 0) { p.fb_list[atomicAdd(&p.stats[3], 1)] = (int32_t)tile; atomicAdd(&p.stats[1], 1); }
-#else
         // redone at once by this block with LDS float atomics (the records are dead: their LDS is the accumulator); whatever
         // the first bands stored is overwritten, and the tile's flag word comes from here
         if (tid == 0) atomicAdd(&p.stats[1], 1);
         OFL_OPAQUE_S(pp);
         sp_tile_atomics<NC, MCH, TF, TO>(p, s, reinterpret_cast<float*>(raw), lst, nlist, t, n);
-#endif
         return;
     }
     if (NC == 2 && s.dst_flags) {                             // (every thread of the block gets here)
@@ -1945,26 +1987,6 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
     if (NC == 2 && s.dst_flags) {
         dflags = wave_or_flags(dflags);
         if (lane == 0) flag_or(&s.dst_flags[n], dflags);
-    }
-}
-
-// (OFL_SP_FB_KERNEL builds only: the gather kernel leaves its fold tiles on a list and this persistent grid redoes them)
-template <int NC, bool MCH, typename TF = float, typename TO = float>
-__global__ __launch_bounds__(kSpNT2) void splat_tile_fallback_kernel(const GatherParams p) {
-    constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0);
-    __shared__ float acc[(1 + NCH) * kPx];
-    const SplatParams& s = p.s;
-    const int count = p.stats[3];                                     // (of this launch; stats[1] counts the whole call)
-    for (int item = blockIdx.x; item < count; item += gridDim.x) {
-        const uint32_t tile = (uint32_t)p.fb_list[item];              // the tile the gather kernel gave up on
-        const uint32_t nn = fastdiv(tile, p.mi_m, p.mi_s);
-        const uint32_t rem = tile - nn * p.tiles_img;
-        const uint32_t yy = fastdiv(rem, p.mx_m, p.mx_s);
-        const int n = (int)nn, ty = (int)yy, tx = (int)(rem - yy * (uint32_t)p.tiles_x);
-        const int64_t dtile = (int64_t)n * p.tiles_img + ty * p.tiles_x + tx;
-        SpTile t;
-        sp_tile_setup<TF>(s, tx, ty, n, t);
-        sp_tile_atomics<NC, MCH, TF, TO>(p, s, acc, p.list + dtile * kBinCap, min(p.cnt[dtile], kBinCap), t, n);
     }
 }
 
@@ -2188,9 +2210,6 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
-#if OFL_SP_FB_KERNEL
-    hipLaunchKernelGGL((splat_tile_fallback_kernel<NC, MCH, TF, TO>), dim3(512), dim3(kSpNT2), 0, st, gp);
-#endif
     return (int)hipGetLastError();
 }
 
@@ -2486,7 +2505,7 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 // workspace words of one pass of `images` frames: statistics (8) | per-image fallback flags | list lengths | lists
 static int64_t splat_pass_words(int64_t images, int32_t h, int32_t w) {
     const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
-    return 8 + ((images + 3) & ~(int64_t)3) + 2 * ((tiles + 3) & ~(int64_t)3) + (int64_t)kBinCap * tiles;
+    return 8 + ((images + 3) & ~(int64_t)3) + ((tiles + 3) & ~(int64_t)3) + (int64_t)kBinCap * tiles;
 }
 static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
     // one pass unless the caller bounds it (a testing aid) or the fallback accumulator of a pass would pass ~2^31 floats
@@ -2553,8 +2572,7 @@ static int splat_tiled_impl(
     gp.stats = workspace;
     gp.img_over = workspace + 8;
     gp.cnt = gp.img_over + ((chunk + 3) & ~(int64_t)3);
-    gp.fb_list = gp.cnt + ((ctiles + 3) & ~(int64_t)3);
-    gp.list = reinterpret_cast<uint32_t*>(gp.fb_list + ((ctiles + 3) & ~(int64_t)3));
+    gp.list = reinterpret_cast<uint32_t*>(gp.cnt + ((ctiles + 3) & ~(int64_t)3));
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;                          // (the statistics words are zeroed with the first pass's list lengths)
     if (dst_flags) {
@@ -2607,10 +2625,6 @@ static int splat_tiled_impl(
             if (c0 > 0) { full.with_mask_chan = 0; full.density = nullptr; full.warped = nullptr; full.valid = nullptr; full.mask_chan = nullptr; }
             const int32_t cg = full.c;
             gp.s = full;
-#if OFL_SP_FB_KERNEL
-            e = hipMemsetAsync(gp.stats + 3, 0, sizeof(int32_t), st);      // tiles this launch hands to the fallback kernel
-            if (e != hipSuccess) return (int)e;
-#endif
             const unsigned grid = (unsigned)(gp.per_xcd * kXcds);
             if (half_in) rc = launch_splat_gather_half(gp, grid, st, elem);
             else switch (cg) {
