@@ -300,7 +300,7 @@ class Flow(object):
         if not isinstance(item, int):
             raise TypeError("Error selecting from flow object: item needs to be an integer")
         try:
-            return Flow(self._vecs[item], self._ref, self.mask[item], self._device)
+            return self._subset(self._vecs[item], self.mask[item])
         except IndexError:
             raise IndexError("Error selecting from flow object: item {} out of bounds for flow with batch size {}"
                              .format(item, self.shape[0]))
@@ -309,7 +309,14 @@ class Flow(object):
         # index H, W (then N, 2) the way a tensor of shape H-W-N-2 would be indexed (flow_class.py:433-448)
         vecs = self._vecs.permute(2, 3, 0, 1).__getitem__(item).permute(2, 3, 0, 1)
         mask = self.mask.permute(1, 2, 0).__getitem__(item).permute(2, 0, 1)
-        return Flow(vecs, self._ref, mask, self._device)
+        return self._subset(vecs, mask)
+
+    def _subset(self, vecs: torch.Tensor, mask: torch.Tensor) -> FlowAlias:
+        """A slice of this (validated) flow as a flow object: the constructor's shape checks (flow_class.py:60-99) without its
+        finiteness reduction -- a subset of finite values is finite (no kernel launch, no host sync)."""
+        v = get_valid_vecs(vecs, error_string="Error setting flow vectors: ", _check_finite=False)
+        m = get_valid_mask(mask, desired_shape=(v.shape[0], v.shape[2], v.shape[3]), error_string="Error setting flow mask: ")
+        return Flow._wrap(v, self._ref, m, self._device)
 
     # ------------------------------------------------------------------------------------------
     # arithmetic (flow_class.py:450-692)

@@ -92,10 +92,7 @@ def get_valid_vecs(vecs: Any, desired_shape: Union[tuple, list] = None, error_st
         return vecs          # Flow.__init__ converts and validates in one fused pass once the mask is known
     vecs = vecs.float()
     if _check_finite:
-        if vecs.device.type == 'cpu' and not torch.cuda.is_available():
-            finite = bool(torch.isfinite(vecs).all())          # host-only validation (no HIP device at all)
-        else:
-            finite = not any(f & _native.FLAG_NONFINITE for f in _flags_to_host(_native.flow_flags(vecs)))
+        finite = not any(f & _native.FLAG_NONFINITE for f in _flags_to_host(_native.flow_flags(vecs)))   # (a HIP reduction: no host path)
         if not finite:
             raise ValueError(error_string + "Input contains NaN, Inf or -Inf values")
     if desired_shape is not None:
