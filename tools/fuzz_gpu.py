@@ -5,7 +5,9 @@
          shapes (any width >= 4, 1-7 channels), flow kinds (smooth, rough, huge, shear, zero), masks, signs, addends,
          rounding modes, batch broadcasts;
   splat: routed exact path == CPU oracle bit for bit on fold-free flows, == two-pass path within tolerance otherwise,
-         identical from run to run, masks always identical.
+         identical from run to run, masks always identical;
+  API  : Flow.apply(padding=...) through the kernels' flow window == through a padded copy of the flow; flows stored in
+         fp16 == their fp32 conversion (switch_ref, invert); track_pts == the oracle's sampler.  All bit for bit.
 """
 import argparse
 import os
@@ -39,6 +41,57 @@ def rand_flow(rng, g, n, h, w, dev):
     return kind, f.contiguous().to(dev)
 
 
+def extras(rng, g, flow, sm, fm, dev):
+    """Flow-level cross-checks of the round-2 paths: the padding WINDOW of the kernels == the padded copy of the flow; flows
+    stored in fp16 == their fp32 conversion; track_pts == the oracle's sampler.  All bit for bit."""
+    import oflibpytorch_amd as ofl
+    n, _, h, w = flow.shape
+    done = 0
+    ref = str(rng.choice(['s', 't']))
+    fl = ofl.Flow(flow, ref, fm)
+    # padded apply: target larger than the flow
+    pad = [int(v) for v in rng.integers(0, 9, 4)]
+    if sum(pad) > 0:
+        c = int(rng.integers(1, 4))
+        tgt = (torch.rand(n, c, h + pad[0] + pad[1], w + pad[2] + pad[3], generator=g) * 255).to(dev)
+        tm = (torch.rand(n, h + pad[0] + pad[1], w + pad[2] + pad[3], generator=g) > 0.2).to(dev)
+        cut = bool(rng.random() < 0.5)
+        _native._last_splat_stats = None
+        a, av = fl.apply(tgt, tm.clone(), return_valid_area=True, padding=pad, cut=cut)
+        flp = fl.pad(pad, mode='constant' if ref == 't' else 'replicate')
+        b, bv = flp.apply(tgt, tm.clone(), return_valid_area=True)
+        if cut:
+            b, bv = b[..., pad[0]:pad[0] + h, pad[2]:pad[2] + w], bv[..., pad[0]:pad[0] + h, pad[2]:pad[2] + w]
+        st = [0, 0] if _native._last_splat_stats is None else _native._last_splat_stats.cpu().tolist()
+        exact = st[0] == 0 and st[1] == 0                    # no tile / image on float atomics (their sums are unordered)
+        same = torch.equal(a, b) if exact else bool(torch.allclose(a, b, rtol=5e-5, atol=5e-5 * 255))
+        if not (same and torch.equal(av, bv)):
+            raise SystemExit("PADDING WINDOW MISMATCH ref %s shape %s pad %s cut %s stats %s" % (ref, tuple(flow.shape), pad, cut, st[:3]))
+        done += 1
+    # fp16 storage: the kernels read the halves directly
+    if w % 4 == 0 and float(flow.abs().max()) < 6e4:
+        hf = flow.half()
+        x = ofl.Flow(hf, ref, fm)
+        y = ofl.Flow(hf.float(), ref, fm)
+        for op in (lambda q: q.switch_ref(), lambda q: q.invert()):
+            _native._last_splat_stats = None
+            p, q = op(x), op(y)
+            st = [0, 0] if _native._last_splat_stats is None else _native._last_splat_stats.cpu().tolist()
+            exact = st[0] == 0 and st[1] == 0
+            same = torch.equal(p.vecs, q.vecs) if exact else bool(torch.allclose(p.vecs, q.vecs, rtol=5e-5, atol=5e-5 * 300))
+            if not (same and torch.equal(p.mask, q.mask)):
+                raise SystemExit("FP16 STORAGE MISMATCH ref %s shape %s stats %s" % (ref, tuple(flow.shape), st[:3]))
+        done += 1
+    # track_pts against the oracle's sampler
+    m = int(rng.integers(1, 40))
+    pts = torch.rand(n, m, 2, generator=g) * torch.tensor([h + 3.0, w + 3.0]) - 1.5
+    got = ofl.track_pts(flow, 's', pts.to(dev))
+    exp = oracle.track_pts(flow.cpu().numpy(), 's', pts.numpy())
+    if not np.array_equal(got.cpu().numpy(), np.asarray(exp, dtype=np.float32)):
+        raise SystemExit("TRACK_PTS MISMATCH shape %s" % (tuple(flow.shape),))
+    return done + 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -49,7 +102,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     g = torch.Generator().manual_seed(a.seed)
     t0 = time.time()
-    nw = ns = 0
+    nw = ns = nx = 0
     while time.time() - t0 < a.seconds:
         n, c = int(rng.integers(1, 4)), int(rng.integers(1, 8))
         h, w = (int(rng.integers(200, 1100)), int(rng.integers(300, 2000))) if a.big else (int(rng.integers(2, 180)), int(rng.integers(4, 300)))
@@ -128,7 +181,11 @@ def main():
             if "chan_mask_a" in skw:
                 assert np.array_equal(r1[1].cpu().numpy(), ref[:, c])
         ns += 1
-    print("fuzz ok: %d warp cases, %d splat cases in %.0f s" % (nw, ns, time.time() - t0))
+        # ---- the rows either side of the path (API level)
+        if kind in ("smooth", "rough", "shear", "const") and h >= 8 and w >= 8 and rng.random() < 0.35:
+            nx += extras(rng, g, flow, sm, fm, dev)
+    print("fuzz ok: %d warp cases, %d splat cases, %d API-level cases (padding window / fp16 storage / track_pts) in %.0f s"
+          % (nw, ns, nx, time.time() - t0))
 
 
 if __name__ == "__main__":
