@@ -190,7 +190,7 @@ int ofl_splat_finalize_f32(const float* accum,
 
 /*
  * Forward splat, single fused call (the fast path of the two passes above, same arguments) -- an in-order GATHER:
- * a bin kernel appends the id of every 16 x 4 source subtile to the list of each 32 x 16 destination tile its end points
+ * a bin kernel appends the id of every 16 x 2 source subtile to the list of each 32 x 16 destination tile its end points
  * touch; a gather kernel (one block per destination tile) re-reads the listed source pixels, keeps those that land in
  * the tile as LDS records per unit cell, puts every cell in raster order of its source pixels and sums each destination
  * pixel's contributions in registers, per corner class in that order and ((c0 + c1) + c2) + c3 across the classes -- the
@@ -201,8 +201,8 @@ int ofl_splat_finalize_f32(const float* accum,
  * processed in groups of 3), else it returns OFL_E_UNSUPPORTED and the caller
  * uses ofl_splat_fwd_f32 + ofl_splat_finalize_f32.
  *   workspace      int32[ofl_splat_tiled_workspace_ints(n, h, w)]: 8 statistics words | one flag per image | list
- *                  lengths and the list of tiles that left the exact path | 128 list entries per destination tile
- *                  (fixed addresses; ~1 B/px).  Contents irrelevant on entry; afterwards workspace[0] = 1 if some
+ *                  lengths | 256 list entries per destination tile
+ *                  (fixed addresses; ~2 B/px).  Contents irrelevant on entry; afterwards workspace[0] = 1 if some
  *                  IMAGE took the two-pass path, workspace[1] = number of tiles that left the exact path,
  *                  workspace[2] = number of such images
  *   data_b         optional [*,C,H,W] fp32 (C <= 2, else OFL_E_ARG): the data splatted is data - data_b (ONE fp32 subtraction per value, the
@@ -212,7 +212,7 @@ int ofl_splat_finalize_f32(const float* accum,
  *                  the caller the validation pass (utils.py:98, flow_class.py:1226-1244) over an intermediate flow
  *   accum_fallback fp32[ofl_splat_tiled_pass_images(n, h, w) * (1 + C + with_mask_chan) * H * W]  (one pass of the batch)
  *                  used (and zeroed in-stream, per image) only for an image in which a destination tile is touched by
- *                  more than 128 source subtiles or a subtile spreads over more than 256 destination tiles: the two-pass
+ *                  more than 256 source subtiles (16 x 2 pixels each) or a subtile spreads over more than 256 destination tiles: the two-pass
  *                  global-atomics path then runs for THAT image inside the same call, decided on the device (no host
  *                  sync; tolerance instead of bit-exactness).  A heavy fold of the flow (> 64 source pixels ending in
  *                  one unit cell, or more records for one tile than four bands of its rows can hold) makes only ITS
