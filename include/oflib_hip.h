@@ -379,6 +379,15 @@ int ofl_sample_pts_grad_f32(const float* flow, int64_t flow_bs, const float* pts
 int ofl_flow_extents_f32(const float* flow, int64_t flow_bs, const uint8_t* mask, int64_t mask_bs, float sign,
                          int32_t* workspace, float* extents, int32_t n, int32_t h, int32_t w, void* stream);
 
+/*
+ * The flag words of a batch (ofl_flow_flags_f32, or the by-product words of the warp / splat kernels), copied, followed by
+ * their OR over the batch as FIVE 0 / 1 integers, one per bit -- the form an all-reduce (MAX; NCCL / RCCL has no bitwise
+ * OR) over the ranks of a batch-sharded job needs, so that the reference's batch-global tests (isfinite().all(),
+ * utils.py:98; all(is_zero), utils.py:497, flow_class.py:1046, 1729, 1738) stay exact under sharding with one launch, one
+ * collective and one read-back per tensor.   words int32[N] -> out int32[N + 5]
+ */
+int ofl_flag_words_or_i32(const int32_t* words, int32_t n, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

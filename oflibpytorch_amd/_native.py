@@ -15,14 +15,14 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 20              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 21              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
 _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
-            "ofl_flow_extents_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
+            "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
             "ofl_warp_bwd_h_f32")
 _lib = None
 
@@ -80,6 +80,7 @@ def load_library(path: str = None):
     lib.ofl_sample_pts_f32.argtypes = [p, i64, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
+    lib.ofl_flag_words_or_i32.argtypes = [p, i32, p, p]
     lib.ofl_splat_tiled_f16.argtypes = [p, i64, f32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, i32, p, p, p, i64, p, i32, i32, i32, p]
     lib.ofl_warp_bwd_h_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, p, p, i32, i32, i32, p]
     lib.ofl_warp_bwd_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, p, i64, p, i64, p, p, i32, i32, i32, i32, i32, p]
@@ -556,6 +557,18 @@ def sample_pts_grad(flow, pts, grad_out, *, want_flow=True, want_pts=True):
             _check(lib.ofl_sample_pts_grad_f32(_ptr(f), fbs, _ptr(q), qbs, _ptr(g), _ptr(gf), _ptr(gp), n, m, h, w,
                                                _stream(dev)), "ofl_sample_pts_grad_f32")
     return gf, gp
+
+
+def flag_words_or(words: torch.Tensor) -> torch.Tensor:
+    """int32[N] flag words on a HIP device -> int32[N + 5] there: the words, then their OR over the batch as five 0 / 1
+    integers, one per bit (ofl_flag_words_or_i32) -- what `distributed.with_global_or` all-reduces."""
+    lib, dev = load_library(), words.device
+    n = int(words.numel())
+    with _on(dev):
+        src = words.to(torch.int32).contiguous()
+        out = torch.empty(n + 5, dtype=torch.int32, device=dev)
+        _check(lib.ofl_flag_words_or_i32(_ptr(src), n, _ptr(out), _stream(dev)), "ofl_flag_words_or_i32")
+    return out
 
 
 def flow_extents(vecs, mask, sign: float) -> torch.Tensor:

@@ -471,4 +471,20 @@ __attribute__((visibility("default"))) int ofl_flow_extents_f32(const float* flo
     return (int)hipGetLastError();
 }
 
+// the flag words of a batch followed by their OR, one int per bit (ofl_flag_words_or_i32): one wave
+__global__ void flag_words_or_kernel(const int32_t* __restrict__ words, int32_t n, int32_t* __restrict__ out) {
+    int f = 0;
+    for (int i = threadIdx.x; i < n; i += 64) { const int v = words[i]; out[i] = v; f |= v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) f |= __shfl_xor(f, o);
+    if (threadIdx.x < 5) out[n + threadIdx.x] = (f >> threadIdx.x) & 1;
+}
+
+__attribute__((visibility("default"))) int ofl_flag_words_or_i32(const int32_t* words, int32_t n, int32_t* out, void* stream) {
+    if (!words || !out) return OFL_E_NULL;
+    if (n < 1) return OFL_E_SHAPE;
+    hipLaunchKernelGGL(flag_words_or_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, n, out);
+    return (int)hipGetLastError();
+}
+
 }  // extern "C"

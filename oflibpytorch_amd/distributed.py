@@ -38,19 +38,32 @@ def reduce_flags(local_or: int, device) -> int:
     collective and one sync; the kernels' device-side words go through `with_global_or` instead."""
     if not is_enabled():
         return local_or
-    return int(with_global_or(torch.tensor([local_or], dtype=torch.int32, device=device))[-1].item())
+    host = with_global_or(torch.tensor([local_or], dtype=torch.int32, device=device)).cpu().tolist()
+    return split_global_or(host)[1]
 
 
 def with_global_or(words: torch.Tensor) -> torch.Tensor:
-    """int32[N] per-element flag words ON THE DEVICE (a kernel's by-product) -> int32[N + 1]: the same words followed by
-    their OR over the whole batch and over every rank.  Device ops and one tiny all-reduce only -- no host round trip
-    here; the caller reads the N + 1 words with a single sync."""
-    w = words.to(torch.int32)
-    shifts = torch.arange(5, dtype=torch.int32, device=w.device)
-    bits = ((w.reshape(-1, 1) >> shifts) & 1).amax(0) if w.numel() else torch.zeros(5, dtype=torch.int32, device=w.device)
+    """int32[N] per-element flag words ON THE DEVICE (a kernel's by-product) -> int32[N + 5]: the same words followed by
+    the five bits (0 / 1 each) of their OR over the whole batch and over every rank.  One launch (ofl_flag_words_or_i32)
+    and one tiny all-reduce (MAX: NCCL / RCCL has no bitwise OR) -- no host round trip here; the caller reads the N + 5
+    integers with a single sync and puts the word together with `split_global_or`."""
+    if words.device.type == 'cuda':
+        from . import _native
+        out = _native.flag_words_or(words)
+    else:                                   # host-resident words (the gloo tier of the tests)
+        w = words.to(torch.int32).reshape(-1)
+        shifts = torch.arange(5, dtype=torch.int32)
+        bits = ((w.reshape(-1, 1) >> shifts) & 1).amax(0) if w.numel() else torch.zeros(5, dtype=torch.int32)
+        out = torch.cat([w, bits.to(torch.int32)])
     if is_enabled():
-        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=_group)
-    return torch.cat([w.reshape(-1), (bits << shifts).sum().to(torch.int32).reshape(1)])
+        dist.all_reduce(out[-5:], op=dist.ReduceOp.MAX, group=_group)
+    return out
+
+
+def split_global_or(host: list) -> tuple:
+    """The host copy of `with_global_or`'s result -> (per-element words, their OR over batch and ranks)"""
+    n = len(host) - 5
+    return [int(v) for v in host[:n]], sum(int(host[n + k]) << k for k in range(5))
 
 
 def shard_bounds(n: int, rank: int = None, world: int = None) -> tuple:

@@ -153,8 +153,8 @@ class Flow(object):
             if distributed.is_enabled():
                 # batch sharding: the OR over every rank's shard is formed on the device (one small all-reduce) and read
                 # together with the local words -- one host sync per tensor version, as without sharding
-                host = _flags_to_host(distributed.with_global_or(dev_flags))
-                self._flag_cache = (key, host[:-1], (True, host[-1]))
+                words, glob = distributed.split_global_or(_flags_to_host(distributed.with_global_or(dev_flags)))
+                self._flag_cache = (key, words, (True, glob))
             else:
                 self._flag_cache = (key, _flags_to_host(dev_flags))
         return self._flag_cache[1]

@@ -47,6 +47,7 @@ def test_argument_validation_needs_no_gpu():
                                   1, 9, 4, 4, null) == -4
     assert lib.ofl_sample_pts_f32(one, 0, one, 0, one, 1, 0, 4, 4, null) == -2
     assert lib.ofl_flow_extents_f32(one, 0, null, 0, 0.5, one, one, 1, 4, 4, null) == -3
+    assert lib.ofl_flag_words_or_i32(null, 1, one, null) == -1 and lib.ofl_flag_words_or_i32(one, 0, one, null) == -2
     # flow_sign must be +-1, round mode 0..2
     assert lib.ofl_warp_bwd_f32(one, 0, 0.5, one, 0, null, 0, null, 0, null, 0, null, 0, 1.0, 1.0, one, null, null, null, null,
                                 1, 1, 4, 4, 0, null) == -3

@@ -81,9 +81,10 @@ def _worker(rank, world, port, q):
             a0, a1 = ofd.shard_bounds(total, rank, world)
             part = torch.arange(float(total))[a0:a1].reshape(-1, 1, 1) * torch.ones(1, 2, 3)
             assert ofd.all_gather_batch(part)[:, 0, 0].tolist() == [float(v) for v in range(total)]
-        # device-side words: the local words come back unchanged, followed by the OR over both ranks
+        # device-side words: the local words come back unchanged, followed by the bits of the OR over both ranks
         words = ofd.with_global_or(torch.tensor([1 << rank, 4], dtype=torch.int32))
-        assert words.tolist() == [1 << rank, 4, 0b111]
+        assert words.tolist() == [1 << rank, 4, 1, 1, 1, 0, 0]
+        assert ofd.split_global_or(words.tolist()) == ([1 << rank, 4], 0b111)
         ofd.disable_batch_sharding()
         assert not ofd.is_enabled()
         dist.barrier()

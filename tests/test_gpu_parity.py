@@ -772,3 +772,21 @@ def test_fp16_flow_outputs_are_an_option(dev):
     finally:
         ofl.set_half_flow_outputs(False)
     assert ofl.Flow(f16, 's', m).switch_ref()._half is None
+
+
+@pytest.mark.gpu
+def test_flag_words_or_for_the_sharded_reduce(dev):
+    """ofl_flag_words_or_i32: the words come back unchanged, followed by the bits of their OR (what
+    distributed.with_global_or all-reduces); N from 1 to beyond one wave."""
+    from oflibpytorch_amd import _native, distributed
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 2, 5, 64, 65, 300):
+        words = torch.randint(0, 32, (n,), generator=g, dtype=torch.int32)
+        if n > 2:
+            words &= 0b10110                                  # two bits never set
+        out = _native.flag_words_or(words.to(dev)).cpu().tolist()
+        expect = 0
+        for v in words.tolist():
+            expect |= v
+        assert out[:n] == words.tolist() and out[n:] == [(expect >> k) & 1 for k in range(5)]
+        assert distributed.split_global_or(distributed.with_global_or(words.to(dev)).cpu().tolist()) == (words.tolist(), expect)
