@@ -254,34 +254,30 @@ def flow_from_matrix(matrix: torch.Tensor, shape: list) -> torch.Tensor:
     return move_axis(pts - hom[..., 0:2], -1, 1)
 
 
-def _validated_matrix(matrix, error_string, device=None):
+def from_matrix(matrix, shape, ref: str = None, matrix_is_inverse: bool = None) -> torch.Tensor:
+    """Flow vectors N-2-H-W from a transformation matrix (utils.py:646-705): for 's' the matrix is applied directly, for 't'
+    its (pseudo-)inverse gives the backward flow (negated).  The batch size comes from the matrix (3-3 or N-3-3); the
+    shape is H-W or 1-H-W.  Checks in the reference's order: shape, matrix, ref, matrix_is_inverse."""
+    dims = get_valid_shape(shape)
+    if dims[0] != 1:
+        raise ValueError("Error creating flow from matrix: Given shape has batch dimension larger than 1")
     if not isinstance(matrix, (np.ndarray, torch.Tensor)):
-        raise TypeError(error_string + "Matrix needs to be a numpy array or a torch tensor")
+        raise TypeError("Error creating flow from matrix: Matrix needs to be a numpy array or a torch tensor")
     if isinstance(matrix, np.ndarray):
         matrix = torch.tensor(matrix)
-    if matrix.dim() == 2:
+    ndim = len(matrix.shape)
+    if ndim != 2 and ndim != 3:
+        raise ValueError("Error creating flow from matrix: Matrix has {} dimensions, should be 2 or 3".format(ndim))
+    if tuple(matrix.shape[-2:]) != (3, 3):
+        raise ValueError("Error creating flow from matrix: Matrix needs to be of shape (3, 3)")
+    if ndim == 2:
         matrix = matrix.unsqueeze(0)
-    if matrix.dim() != 3 or tuple(matrix.shape[1:]) != (3, 3):
-        raise ValueError(error_string + "Matrix needs to be of shape 3-3 or N-3-3")
-    return matrix.float()
-
-
-def from_matrix(matrix, shape, ref: str = None, matrix_is_inverse: bool = None) -> torch.Tensor:
-    """Flow vectors N-2-H-W from a transformation matrix (utils.py:646-726): for 's' the matrix is applied
-    directly, for 't' its inverse gives the backward flow (negated)."""
+    matrix = matrix.to(torch.float)
     ref = get_valid_ref(ref)
-    matrix = _validated_matrix(matrix, "Error creating flow from matrix: ")
-    dims = get_valid_shape(shape)
-    if dims[0] != matrix.shape[0]:
-        if dims[0] == 1:
-            dims = (matrix.shape[0],) + dims[1:]
-        elif matrix.shape[0] == 1:
-            matrix = matrix.expand(dims[0], -1, -1)
-        else:
-            raise ValueError("Error creating flow from matrix: Batch size of the matrix and shape do not match")
     matrix_is_inverse = False if matrix_is_inverse is None else matrix_is_inverse
     if not isinstance(matrix_is_inverse, bool):
         raise TypeError("Error creating flow from matrix: Matrix_is_inverse needs to be None or a Boolean")
+    dims = (matrix.shape[0],) + dims[1:]
     if ref == 's':
         if matrix_is_inverse:
             raise ValueError("Error creating flow from matrix: Matrix_is_inverse cannot be True when ref is 's'")
