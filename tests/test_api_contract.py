@@ -144,3 +144,28 @@ def test_misc_contract():
             Flow(torch.ones(2, 5, 7), 's').apply(torch.rand(5, 7))
     finally:
         ofl.set_pure_pytorch()
+
+
+def test_from_matrix_contract():
+    """utils.py:646-705 (checked in the reference's order: shape, matrix, ref, matrix_is_inverse); the batch size comes from
+    the matrix, a shape with a batch dimension other than 1 is refused."""
+    with pytest.raises(ValueError):
+        ofl.from_matrix(torch.eye(3), [2, 10, 10], 't')
+    with pytest.raises(TypeError):
+        ofl.from_matrix('test', [10, 10], 't')
+    with pytest.raises(ValueError):
+        ofl.from_matrix(np.eye(4), [10, 10], 't')
+    with pytest.raises(ValueError):
+        ofl.from_matrix(np.ones((1, 1, 3, 3)), [10, 10], 't')
+    with pytest.raises(TypeError):
+        ofl.from_matrix(torch.eye(3), [10, 10], matrix_is_inverse='test')
+    with pytest.raises(ValueError):
+        ofl.from_matrix(torch.eye(3), [10, 10], ref='s', matrix_is_inverse=True)
+    with pytest.raises(ValueError):
+        ofl.from_matrix(torch.eye(3), [10, 10], ref='x')
+    shift = torch.tensor([[1., 0, 10], [0, 1, 20], [0, 0, 1]])
+    v = ofl.from_matrix(torch.stack((shift, torch.eye(3))), [1, 6, 8], 's')
+    assert v.shape == (2, 2, 6, 8) and float(v[0, 0].min()) == 10.0 and float(v[0, 1].max()) == 20.0 and not v[1].any()
+    back = ofl.from_matrix(torch.linalg.inv(shift), (6, 8), 't', matrix_is_inverse=True)
+    assert torch.allclose(back, ofl.from_matrix(shift, (6, 8), 't'), atol=1e-5)
+    assert Flow.from_matrix(shift, (6, 8), 's').shape == (1, 6, 8)
