@@ -7,7 +7,8 @@
   splat: routed exact path == CPU oracle bit for bit on fold-free flows, == two-pass path within tolerance otherwise,
          identical from run to run, masks always identical;
   API  : Flow.apply(padding=...) through the kernels' flow window == through a padded copy of the flow; flows stored in
-         fp16 == their fp32 conversion (switch_ref, invert); track_pts == the oracle's sampler.  All bit for bit.
+         fp16 == their fp32 conversion (switch_ref, invert); track_pts == the oracle's sampler -- all bit for bit; gradients of
+         the warp and of the splat == torch's CPU autograd through the restated op sequence, within the stated tolerance.
 """
 import argparse
 import os
@@ -81,6 +82,35 @@ def extras(rng, g, flow, sm, fm, dev):
             same = torch.equal(p.vecs, q.vecs) if exact else bool(torch.allclose(p.vecs, q.vecs, rtol=5e-5, atol=5e-5 * 300))
             if not (same and torch.equal(p.mask, q.mask)):
                 raise SystemExit("FP16 STORAGE MISMATCH ref %s shape %s stats %s" % (ref, tuple(flow.shape), st[:3]))
+        done += 1
+    # gradients against torch's CPU autograd through the restated op sequence (tests/test_autograd.py)
+    if h * w <= 40000 and rng.random() < 0.5:
+        for sub in ('tests', os.path.join('tests', 'golden')):
+            if os.path.join(ROOT, sub) not in sys.path:
+                sys.path.insert(0, os.path.join(ROOT, sub))
+        import test_autograd as ta
+        c = int(rng.integers(1, 4))
+        img = torch.rand(1 if rng.random() < 0.3 else n, c, h, w, generator=g)
+        wts = torch.randn(n, c, h, w, generator=g)
+        fa, ia = flow.clone().requires_grad_(), img.to(dev).requires_grad_()
+        (ofl.apply_flow(fa, ia, 't') * wts.to(dev)).sum().backward()
+        fb, ib = flow.cpu().clone().requires_grad_(), img.clone().requires_grad_()
+        (ta._ref_apply_t(fb, ib) * wts).sum().backward()
+        ta._close(fa.grad.cpu(), fb.grad, "fuzz: warp grad wrt flow %s" % (tuple(flow.shape),), rtol=5e-4)
+        ta._close(ia.grad.cpu(), ib.grad, "fuzz: warp grad wrt target %s" % (tuple(flow.shape),), rtol=5e-4)
+        x = (flow[:, 0] + torch.arange(w, device=dev)[None, None, :]).contiguous()
+        y = (flow[:, 1] + torch.arange(h, device=dev)[None, :, None]).contiguous()
+        data = torch.rand(n, c, h, w, generator=g)
+        xa, ya, da = x.clone().requires_grad_(), y.clone().requires_grad_(), data.to(dev).requires_grad_()
+        od, oden = ofl.grid_from_unstructured_data(xa, ya, da, sm)
+        wn = torch.randn(n, h, w, generator=g)
+        ((od * wts.to(dev)).sum() + (oden * wn.to(dev)).sum()).backward()
+        xb, yb, db = x.cpu().clone().requires_grad_(), y.cpu().clone().requires_grad_(), data.clone().requires_grad_()
+        rd, rden = ta._ref_splat(xb, yb, db, sm.cpu())
+        ((rd * wts).sum() + (rden * wn).sum()).backward()
+        ta._close(da.grad.cpu(), db.grad, "fuzz: splat grad wrt data %s" % (tuple(flow.shape),), rtol=1e-3)
+        ta._close(xa.grad.cpu(), xb.grad, "fuzz: splat grad wrt x %s" % (tuple(flow.shape),), rtol=2e-3)
+        ta._close(ya.grad.cpu(), yb.grad, "fuzz: splat grad wrt y %s" % (tuple(flow.shape),), rtol=2e-3)
         done += 1
     # track_pts against the oracle's sampler
     m = int(rng.integers(1, 40))
