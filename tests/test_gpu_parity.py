@@ -662,6 +662,35 @@ def test_routed_splat_in_several_passes(rough, dev):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("pass_images", [0, 1])
+def test_only_the_flagged_image_leaves_the_exact_path(pass_images, dev):
+    """ADVICE r1 (overflow state must not leak between passes / images): image 0 of the batch overflows its lists and takes
+    the two-pass path; images 1 and 2 -- in the same pass or in later passes -- stay on the in-order path: bit-identical
+    to a call without image 0."""
+    from oflibpytorch_amd import _native
+    _native.collect_splat_stats = True
+    n, c, h, w = 3, 2, 160, 320
+    flow = _smooth(n, h, w, 2.0, 78, dev)
+    flow[0] *= 40
+    g = torch.Generator().manual_seed(13)
+    data = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    wm = (torch.rand(n, h, w, generator=g) > 0.15).to(dev)
+    kw = dict(want_density=True, want_warped=True)
+    alone = _native.splat_fwd(flow[1:].contiguous(), data[1:].contiguous(), weight_mask=wm[1:].contiguous(), **kw)
+    st = _native._last_splat_stats.cpu().tolist()
+    assert st[0] == 0 and st[1] == 0
+    _native.set_splat_pass_images(pass_images)
+    try:
+        mixed = _native.splat_fwd(flow, data, weight_mask=wm, **kw)
+    finally:
+        _native.set_splat_pass_images(0)
+    st = _native._last_splat_stats.cpu().tolist()
+    assert st[0] == 1 and st[2] == 1                           # exactly one image on the two-pass path
+    for a, b in zip(alone, mixed):
+        if a is not None:
+            assert torch.equal(a, b[1:])
+
+
 def test_tiled_splat_explicit_positions(dev):
     from oflibpytorch_amd import _native
     from oracle import oracle
