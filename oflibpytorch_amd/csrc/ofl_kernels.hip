@@ -187,8 +187,8 @@ __device__ __forceinline__ void st2(_Float16* p, f2 v) { *reinterpret_cast<h2u*>
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(_Float16* p, float v) { *p = (_Float16)v; }
 // write-once outputs of the staged warp: non-temporal (OFL_WARP_NT_STORE), so that they stream past the L2 lines the halos live
-// in.  (Also measured, all within +-1 %: non-temporal flow-mask loads, non-temporal loads in the splat's bin kernel,
-// non-temporal stores of the gather splat.)
+// in; the gather splat's 16-byte output stores use it too (+1 % on smooth flows).  (Also measured, within +-1 %:
+// non-temporal flow-mask loads, non-temporal loads in the splat's bin kernel.)
 template <typename T> __device__ __forceinline__ void st4o(T* p, f4 v) { st4(p, v); }
 #if OFL_WARP_NT_STORE
 template <> __device__ __forceinline__ void st4o<float>(float* p, f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f4u*>(p)); }
@@ -1525,7 +1525,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
             const f2 give = odd ? pa : pb, keep = odd ? pb : pa;
             const f2 got = {swap1(give[0]), swap1(give[1])};
             const f4 v = odd ? (f4){got[0], got[1], keep[0], keep[1]} : (f4){keep[0], keep[1], got[0], got[1]};
-            if (mine && (odd ? b_on : a_on)) { if (odd) st4(ptrb + pq, v); else st4(ptra + pq, v); }
+            if (mine && (odd ? b_on : a_on)) { if (odd) st4o(ptrb + pq, v); else st4o(ptra + pq, v); }
         };
         float* dpl = s.density ? s.density + (int64_t)n * hw : nullptr;
         float* mpl = (MCH && s.mask_chan) ? s.mask_chan + (int64_t)n * hw : nullptr;
