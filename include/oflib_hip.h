@@ -59,8 +59,9 @@ int ofl_version(void);
 /*   OFL_OPT_WARP_SHEAR: 1 = the LDS-staged warp kernel stages a y-sheared box (default), 0 = plain bounding box
  *   (speed only; the results are identical). */
 #define OFL_OPT_WARP_SHEAR 3
-/*   OFL_OPT_SPLAT_PASS_IMAGES: upper bound on the images ofl_splat_tiled_f32 handles per pass (0 = as many as keep the
- *   record queues under ~4 GiB; tests use small values to exercise the multi-pass code on small inputs). */
+/*   OFL_OPT_SPLAT_PASS_IMAGES: upper bound on the images ofl_splat_tiled_f32 handles per pass (0 = automatic: one pass
+ *   unless the fallback accumulator of a pass would pass 2^31 floats; tests use small values to exercise the multi-pass
+ *   code on small inputs). */
 #define OFL_OPT_SPLAT_PASS_IMAGES 4
 int ofl_set_option(int32_t key, int32_t value);
 

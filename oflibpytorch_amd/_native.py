@@ -103,8 +103,8 @@ def set_splat_path(mode: int):
     _splat_path = int(mode)
 
 
-collect_splat_stats = False   # tests / tools set this to read _last_splat_stats after a routed splat
-_last_splat_stats = None      # device int32[4] of the most recent routed splat: how exact was it
+collect_splat_stats = False   # tests / tools set this to read _last_splat_stats after a gather (in-order) splat
+_last_splat_stats = None      # device int32[4] of the most recent gather splat: how exact was it
 _last_splat_ws = None
 
 
@@ -114,7 +114,7 @@ def set_warp_shear(on: bool):
 
 
 def set_splat_pass_images(k: int):
-    """Routed splat: at most k images per pass (0 = automatic, ~4 GiB of queues); tests use it to force several passes."""
+    """Gather splat: at most k images per pass (0 = automatic); tests use it to force several passes."""
     _check(load_library().ofl_set_option(4, int(k)), "ofl_set_option")
 
 

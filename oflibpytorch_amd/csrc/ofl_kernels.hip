@@ -2145,7 +2145,7 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
-int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = as many as fit ~4 GiB of queues
+int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 
 template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {

@@ -55,7 +55,7 @@ def test_combine_mode3_full_frame_bit_exact(frames, dev):
 
 
 def test_apply_s_full_frame(frames, dev):
-    """Smooth flow: the routed splat is bit-exact at full size.  Bench flow (folds): masks bit-exact, values within the
+    """Smooth flow: the in-order (gather) splat is bit-exact at full size.  Bench flow (folds): masks bit-exact, values within the
     stated tolerance on the tiles that fell back to float atomics -- and bit-exact everywhere else."""
     import oflibpytorch_amd as ofl
     from oflibpytorch_amd import _native
@@ -94,7 +94,7 @@ def test_switch_ref_full_frame(frames, dev):
 
 def test_batch_of_64_repeats_its_two_frames(frames, dev):
     """B = 64 (the bench batch): 32 copies of two frames -> 32 copies of their results, bit for bit, for the backward warp,
-    the fused composition and the forward splat (several passes of the routed path)."""
+    the fused composition and the forward splat (several passes of the gather path)."""
     import oflibpytorch_amd as ofl
     t, _ = frames
     rep = lambda x: x.repeat((32,) + (1,) * (x.dim() - 1))
@@ -115,7 +115,7 @@ def test_batch_of_64_repeats_its_two_frames(frames, dev):
 def test_config5_4k_fp16_switch_ref_then_mode1(dev):
     """BASELINE.json configs[4]: 2160 x 3840 flows stored in fp16, ``switch_ref`` 's' -> 't', then ``combine_with`` mode 1
     in 't'.  The reference turns every flow into fp32 on entry (utils.py:95,118), so the oracle gets the same fp16 values
-    as exact fp32 numbers; both steps are bit-exact while the splat stays on its routed exact path."""
+    as exact fp32 numbers; both steps are bit-exact while the splat stays on its in-order path."""
     import bench
     import oflibpytorch_amd as ofl
     from oflibpytorch_amd import _native

@@ -4,7 +4,7 @@ C ABI) must reproduce what the reference produced.
 Bars (BASELINE.json north_star):
   * backward-gather ('t') family -- the kernel restates the reference's fp32 operation order, so values AND
     masks are compared BIT-EXACT;
-  * forward-splat ('s') family -- the routed kernel (C <= 3, W >= 4: every fixture but the 2 x 2 one) sums each destination pixel's
+  * forward-splat ('s') family -- the gather kernel (C <= 3, W >= 4: every fixture but the 2 x 2 one) sums each destination pixel's
     contributions in the reference's own order, so values AND masks are compared BIT-EXACT as well; the general two-pass
     path (float atomics; C > 3) is held to rtol 2e-5 / atol 2e-5 * max|expected| with masks bit for bit (tests below).
 """
@@ -67,7 +67,7 @@ def test_golden_case_gpu(cid, golden, dev):
         scale = max([float(np.abs(v).max()) for v in exp.values() if v.dtype.kind == 'f' and v.size] + [1.0])
         widths = {int(v.shape[-1]) for v in exp.values() if v.ndim >= 2}
         if min(widths) >= 4:
-            case_runner.check_case(case, golden, got, exact_values=True)      # routed exact path (C <= 3, W >= 4)
+            case_runner.check_case(case, golden, got, exact_values=True)      # in-order gather path (C <= 3, W >= 4)
         else:                                                                 # the 2 x 2 fixture: two-pass float atomics
             case_runner.check_case(case, golden, got, exact_values=False, rtol=2e-5, atol=2e-5 * scale, max_mask_flips=0)
     else:
@@ -485,7 +485,7 @@ def test_warp_output_flags_equal_a_flag_pass_over_the_output(shape, kind, dev):
 
 @pytest.mark.parametrize("kind", ["smooth", "zero", "tiny", "masked_out", "rough_two_pass", "general_path"])
 def test_splat_output_flags_equal_a_flag_pass_over_the_output(kind, dev):
-    """The routed splat returns the flag word of its OUTPUT (read as a flow under its valid mask) as a by-product; it
+    """The gather splat returns the flag word of its OUTPUT (read as a flow under its valid mask) as a by-product; it
     must equal what ofl_flow_flags_f32 computes from the stored tensors -- on the exact path, on the per-tile and
     launch-level fallbacks and on the general two-pass path."""
     from oflibpytorch_amd import _native
@@ -524,7 +524,7 @@ def test_splat_output_flags_equal_a_flag_pass_over_the_output(kind, dev):
 
 @pytest.mark.parametrize("kind", ["routed", "general_path", "two_pass_inside", "narrow"])
 def test_splat_of_a_difference_equals_the_materialised_difference(kind, dev):
-    """`data_b`: the splat of data - data_b formed inside the kernels (route kernel, un-occlude fill, two-pass fallback)
+    """`data_b`: the splat of data - data_b formed inside the kernels (gather kernel, un-occlude fill, two-pass fallback)
     is bit-identical to splatting the materialised difference -- combine_with mode 2 ('s') relies on it."""
     from oflibpytorch_amd import _native
     n, h, w = (2, 70, 132) if kind != "narrow" else (2, 20, 3)
@@ -636,7 +636,7 @@ def test_mode2_s_is_the_composed_expression(dev):
 
 @pytest.mark.parametrize("rough", [False, True])
 def test_routed_splat_in_several_passes(rough, dev):
-    """n = 5 images, at most 2 per pass: the passes re-use the queues; with a rough flow the launch-level two-pass fallback
+    """n = 5 images, at most 2 per pass: the passes re-use the lists; with a rough flow the per-image two-pass fallback
     runs per pass.  Same results as one pass / as the two-pass path."""
     from oflibpytorch_amd import _native
     _native.collect_splat_stats = True

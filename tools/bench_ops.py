@@ -75,7 +75,7 @@ def main():
     print("B=%d %dx%d fp32, %d iters" % (n, h, w, a.iters))
     if _native._last_splat_stats is not None:
         st = _native._last_splat_stats.cpu().tolist()
-        print("last routed splat: launch-level fallback %d, tiles on the LDS-atomics fallback %d" % (st[0], st[1]))
+        print("last gather splat: images on the two-pass path %d, fold tiles on LDS atomics %d" % (st[0], st[1]))
     for name, bpp, t in rows:
         print("%-28s %8.3f ms  %9.1f Mpix/s  %7.1f GB/s algorithmic (%d B/px)" % (name, t * 1e3, px / t / 1e6, bpp * px / t / 1e9, bpp))
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timing of the forward-splat family (apply 's', switch_ref) on B x 1080p for a given flow roughness, with the routed
+"""Timing of the forward-splat family (apply 's', switch_ref) on B x 1080p for a given flow roughness, with the gather
 path's exactness statistics.   python tools/bench_splat.py [--batch 16] [--sigma 8]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,7 +4,7 @@
   warp : LDS-staged kernel == generic direct-gather kernel, bit for bit (values, valid mask, flag words), over random
          shapes (any width >= 4, 1-7 channels), flow kinds (smooth, rough, huge, shear, zero), masks, signs, addends,
          rounding modes, batch broadcasts;
-  splat: routed exact path == CPU oracle bit for bit on fold-free flows, == two-pass path within tolerance otherwise,
+  splat: in-order gather path == CPU oracle bit for bit on fold-free flows, == two-pass path within tolerance otherwise,
          identical from run to run, masks always identical;
   API  : Flow.apply(padding=...) through the kernels' flow window == through a padded copy of the flow; flows stored in
          fp16 == their fp32 conversion (switch_ref, invert); track_pts == the oracle's sampler -- all bit for bit; gradients of
@@ -194,10 +194,10 @@ def main():
             if st[0] == 0 and st[1] == 0:
                 assert torch.equal(x, y), "splat not deterministic %s %s" % ((n, c, h, w), kind)
             if x.dtype == torch.bool:
-                assert torch.equal(x, z), "splat masks differ between routed and two-pass %s %s" % ((n, c, h, w), kind)
+                assert torch.equal(x, z), "splat masks differ between the gather path and two-pass %s %s" % ((n, c, h, w), kind)
             else:
                 np.testing.assert_allclose(x.cpu().numpy(), z.cpu().numpy(), rtol=5e-5, atol=5e-5 * scale,
-                                           err_msg="routed vs two-pass %s %s %s" % ((n, c, h, w), kind, st))
+                                           err_msg="gather path vs two-pass %s %s %s" % ((n, c, h, w), kind, st))
         if st[0] == 0 and st[1] == 0 and n * h * w < 40000:      # exact path everywhere: bit-identical to the oracle
             f = flow.cpu().numpy() * np.float32(skw["flow_sign"])
             d = data.cpu().numpy() * np.float32(skw["data_sign"])
