@@ -1102,31 +1102,35 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 // ------------------------------------------------------------------------------------------------
 // forward splat, GATHER formulation (ofl_splat_tiled_f32): the destination tile finds its own sources
 //
-//  bin kernel   : every 16 x 4 SOURCE subtile (16 lanes x 4 pixels: one DPP row) takes the bounding box of the destination
-//                 pixels its end points touch and appends its 4-byte id to the list of each DESTINATION tile the box
-//                 overlaps (2.0 lists per subtile on smooth flows; fixed capacity, one integer atomic per append).  Reads
-//                 the flow and the weight mask only (9 B/px), writes ~0.1 B/px.
+//  bin kernel   : every 16 x 2 SOURCE subtile (8 lanes x 4 pixels: half a DPP row) takes the bounding box of the
+//                 destination pixels its end points touch and appends its 4-byte id to the list of each DESTINATION tile
+//                 the box overlaps (fixed capacity; ranks from LDS atomics per 64 x 16 source region, one device-scope
+//                 atomic per (region, destination tile)).  Reads the flow and the weight mask only (9 B/px), writes
+//                 ~0.2 B/px.  A tile lists 28 - 32 subtiles on the bench flows.
 //  gather kernel: one block per 32 x 16 DESTINATION tile.
-//     A  walks its list, 16 subtiles per step: flow, mask and data of the listed source pixels straight from the operand
-//        tensors (16-byte row-coalesced loads, served by L2 for the ~2 tiles that share a subtile), end points in the
-//        reference's order (utils.py:1056-1057), the pixels whose unit cell lies in the tile's 33 x 17 cells become
-//        RECORDS IN LDS ONLY (x, y, raster key + mask-channel bit, data): ballot + popcount ranks, one LDS atomic per wave
-//        and step; every record is pushed on the list of its CELL (one LDS atomic exchange);
-//     S  every cell is put in raster order of its source pixels once: up to 4 records by a sorting network in registers
-//        (written as four 16-bit slots), 5 .. 64 by an insertion sort of the list itself;
-//     C  each thread sums its own 2 destination pixels in registers: its 3 x 2 cells, every record fetched once and
-//        added, in list order, to each corner-class sum it belongs to, then ((c0 + c1) + c2) + c3 -- exactly the order
+//     A  walks its list, 64 subtiles per step in two half steps of 32 (the second skipped when empty): flow, mask and data
+//        of the listed source pixels straight from the operand tensors (16-byte row-coalesced loads, served by L2 for the
+//        ~2 tiles that share a subtile), end points in the reference's order (utils.py:1056-1057); the pixels whose unit
+//        cell lies in the tile's 33 x 17 cells become RECORDS IN LDS ONLY (four corner weights, data, raster key +
+//        mask-channel bit): ballot + popcount ranks, one LDS atomic per wave and half step; every record joins its CELL
+//        (four 16-bit slots, later ones on a chain);
+//     S  cells with one or two records need no order (a + b = b + a); the others are collected and handled one per lane:
+//        put in raster order of their source pixels (up to 4: a sorting network in registers; 5 .. 64: an insertion sort
+//        of the chain) and SUMMED there and then, per corner class and channel -- the sums replace the cell's records;
+//     C  each thread sums its own 2 destination pixels in registers: its 3 x 2 cells, every record (or pre-summed entry)
+//        fetched once and added to each corner-class sum it belongs to, then ((c0 + c1) + c2) + c3 -- exactly the order
 //        of the reference's four scatter_add_ passes and its corner sum (utils.py:1133-1143), products rounded before
 //        they are added: BIT-IDENTICAL to the reference, and run to run; normalise, threshold, un-occlude, 16-byte stores
 //        (lane pairs exchange their halves through DPP), and, for flows, the output's flag word as a by-product.
-//     More records than the LDS holds (1024: a compression of the flow) are taken in 2 or 4 bands of destination rows,
+//     More records than the LDS holds (896: a compression of the flow) are taken in 2 or 4 bands of destination rows,
 //     each band walking the list again.
 //  No record ever reaches HBM (the routed version of round 1 wrote and re-read 27 B/px of them), no float atomics, no
-//  accumulator in HBM, no workspace beyond 516 bytes per destination tile.
+//  accumulator in HBM, no workspace beyond 1 KB per destination tile.
 //  Only a heavy fold of the flow (> 64 sources in one cell, or more records than four bands hold) makes THAT tile fall
-//  back to LDS float atomics over the same list (tolerance instead of bit-exactness for that tile).  An IMAGE whose lists
-//  overflow (> 128 subtiles for one destination tile: a 16-fold compression) or whose subtiles spread over > 256
-//  destination tiles takes the two-pass global-atomics path inside the same call, decided on the device, per image.
+//  back to LDS float atomics over the same list, at once and in the same block (tolerance instead of bit-exactness for
+//  that tile).  An IMAGE whose lists overflow (> 256 subtiles for one destination tile: a 16-fold compression) or whose
+//  subtiles spread over > 256 destination tiles takes the two-pass global-atomics path inside the same call, decided on
+//  the device, per image.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSpTW = 32, kSpTH = 16;                        // destination tiles
 constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // gather kernel: 2 destination pixels per thread
