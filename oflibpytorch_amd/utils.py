@@ -65,8 +65,27 @@ def _griddata_unavailable(what: str):
 # ------------------------------------------------------------------------------------------------
 # validators (utils.py:72-232): TypeError for wrong types, ValueError for wrong shapes / values
 # ------------------------------------------------------------------------------------------------
+_readback = {}
+
+
 def _flags_to_host(flags: torch.Tensor) -> list:
-    return [int(v) for v in flags.cpu().tolist()]
+    """The read-back every validation waits for (twice per bench step, with the GPU idle behind it): an asynchronous copy
+    into a small pinned buffer and a POLLED event instead of `flags.cpu()` -- a blocking synchronisation sleeps on an
+    interrupt, and its wake-up latency varies from a few microseconds to a few hundred with the host's power state."""
+    if flags.device.type != 'cuda' or flags.dtype != torch.int32:
+        return [int(v) for v in flags.cpu().tolist()]
+    n = int(flags.numel())
+    slot = _readback.get(flags.device)
+    if slot is None or slot[0].numel() < n:
+        slot = (torch.empty(max(n, 64), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        _readback[flags.device] = slot
+    buf, done = slot
+    with torch.cuda.device(flags.device):
+        buf[:n].copy_(flags.reshape(-1), non_blocking=True)
+        done.record()
+        while not done.query():
+            pass
+    return buf[:n].tolist()
 
 
 def get_valid_vecs(vecs: Any, desired_shape: Union[tuple, list] = None, error_string: str = None,
