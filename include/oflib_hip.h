@@ -257,6 +257,22 @@ int ofl_splat_tiled_win_f32(const float* flow, int64_t flow_bs, float flow_sign,
                             int32_t round_mode, void* stream);
 
 /*
+ * The weighted sums of a forward splat WITHOUT the division by the density:
+ *   dst[n,c,q] = sum over source pixels i and corners k that land on q of  w_ik * data_sign * data[n,c,i]
+ * with the end points and weights of ofl_splat_tiled_f32 (every pixel contributes: no weight mask, no occlusion rule).
+ * This is the transpose of the backward warp: with data = the upstream gradient and flow_sign = MINUS the warp's
+ * flow_sign it is the gradient of ofl_warp_bwd_f32 with respect to its source (ATen: the grad_input scatter of
+ * grid_sampler_2d_backward) -- one gather launch instead of twelve global float atomics per pixel (B=16 1080p C=3:
+ * 1.0 ms instead of 7.1 ms).  Same workspace, fallback accumulator ((1 + C) planes per image of a pass) and limits as
+ * ofl_splat_tiled_f32; OFL_E_UNSUPPORTED for shapes that one does not take (the caller then uses the atomics of
+ * ofl_warp_bwd_grad_f32).
+ */
+int ofl_splat_sum_f32(const float* flow, int64_t flow_bs, float flow_sign,
+                      const float* data, int64_t data_bs, float data_sign, float* dst,
+                      int32_t* workspace, int64_t workspace_ints, float* accum_fallback,
+                      int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
+/*
  * Per-batch-element flag word of a flow field (OR-ed into flags[n]; caller zeroes):
  *   bit 0 (1)  some component is NaN / +-Inf
  *   bit 1 (2)  some component != 0

@@ -15,14 +15,14 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 21              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 22              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
 _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_f32", "ofl_splat_finalize_f32", "ofl_splat_tiled_workspace_ints", "ofl_splat_tiled_pass_images",
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
-            "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
+            "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
             "ofl_warp_bwd_h_f32")
 _lib = None
 
@@ -81,6 +81,7 @@ def load_library(path: str = None):
     lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
     lib.ofl_flag_words_or_i32.argtypes = [p, i32, p, p]
+    lib.ofl_splat_sum_f32.argtypes = [p, i64, f32, p, i64, f32, p, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_splat_tiled_f16.argtypes = [p, i64, f32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, i32, p, p, p, i64, p, i32, i32, i32, p]
     lib.ofl_warp_bwd_h_f32.argtypes = [p, i64, f32, p, i64, p, i64, p, i64, p, i64, p, p, i32, i32, i32, p]
     lib.ofl_warp_bwd_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, p, i64, p, i64, p, p, i32, i32, i32, i32, i32, p]
@@ -478,11 +479,28 @@ def warp_bwd_grad(flow, src, grad_out, *, flow_sign=1.0, g_scale=1.0, want_src=T
         s, sbs = _planes(src.detach(), dev, torch.float32, n, "source")
         g = grad_out.detach().to(dev, torch.float32).contiguous()
         ns = 1 if sbs == 0 else n
-        gs = torch.zeros((ns, c, h, w), dtype=torch.float32, device=dev) if want_src else None
+        gs = None
+        if want_src:
+            # grad wrt the source = the un-normalised forward splat of the upstream gradient along the negated flow: the gather
+            # kernels instead of 4 * C global float atomics per pixel (ofl_splat_sum_f32; B=16 1080p C=3: 7.1 -> 1.0 ms)
+            ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
+            accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + min(c, 3), h, w), dtype=torch.float32, device=dev)
+            full = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+            rc = lib.ofl_splat_sum_f32(_ptr(f), fbs, -float(flow_sign), _ptr(g), c * h * w, float(g_scale), _ptr(full),
+                                       _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, _stream(dev))
+            if rc == 0:
+                gs = full.sum(0, keepdim=True) if (ns == 1 and n > 1) else full
+            elif rc != -4:
+                _check(rc, "ofl_splat_sum_f32")
+        atomics = want_src and gs is None                   # shapes the gather splat does not take (W < 4 ...)
+        if atomics:
+            gs = torch.zeros((ns, c, h, w), dtype=torch.float32, device=dev)
         gf = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev) if want_flow else None
-        _check(lib.ofl_warp_bwd_grad_f32(_ptr(f), fbs, float(flow_sign), _ptr(s), sbs, _ptr(g), float(g_scale), _ptr(gs),
-                                         0 if ns == 1 else c * h * w, _ptr(gf), n, c, h, w, _stream(dev)),
-               "ofl_warp_bwd_grad_f32")
+        if atomics or want_flow:
+            _check(lib.ofl_warp_bwd_grad_f32(_ptr(f), fbs, float(flow_sign), _ptr(s), sbs, _ptr(g), float(g_scale),
+                                             _ptr(gs) if atomics else None, 0 if ns == 1 else c * h * w, _ptr(gf), n, c, h, w,
+                                             _stream(dev)),
+                   "ofl_warp_bwd_grad_f32")
     return gs, gf
 
 

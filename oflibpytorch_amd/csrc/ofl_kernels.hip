@@ -924,6 +924,7 @@ struct SplatParams {
     const int32_t* run_if_set;   // optional device flags int32[n]: the atomics path runs for image i only when run_if_set[i] != 0
     const int32_t* any_set;      // (with run_if_set) one word: some image of the pass is flagged
     int32_t* dst_flags;          // optional int32[N] (2-channel data only): flag word of the OUTPUT read as a flow under `valid`
+    int32_t raw;                 // 1: the weighted sums themselves, not divided by the density (ofl_splat_sum_f32: the transpose of the backward warp)
 };
 
 // flow window (padded apply): offset of frame pixel (x, y) in a flow-geometry plane (clamped: replicate) and whether it is inside
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
         if (x >= w || y >= h) continue;
         const int64_t pix = (int64_t)y * w + x;
         const float den = acc[pix];
-        const float dcl = den < kDenMin ? kDenMin : den;  // clamp_min utils.py:1144
+        const float dcl = p.raw ? 1.0f : (den < kDenMin ? kDenMin : den);  // clamp_min utils.py:1144 (raw sums: x / 1 = x)
         const bool warped = den > 0.0f;                    // utils.py:1197
         bool fill = false;
         bool inside = true;
@@ -1486,7 +1487,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float den = tot[k][0];
-        const float dcl = den < kDenMin ? kDenMin : den;          // clamp_min utils.py:1144
+        const float dcl = s.raw ? 1.0f : (den < kDenMin ? kDenMin : den);          // clamp_min utils.py:1144 (raw sums: x / 1 = x)
         const bool warped = den > 0.0f;                            // utils.py:1197
         const bool fill = t.fill_ok[k] && !warped && mine;
         den2[k] = den;
@@ -2260,7 +2261,7 @@ int launch_splat_gather_half(const GatherParams& gp, unsigned grid, hipStream_t 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 21; }   // 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 22; }   // 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -2560,7 +2561,7 @@ static int splat_tiled_impl(
     const uint8_t* chan_mask_a, int64_t chan_mask_a_bs, const uint8_t* chan_mask_b, int64_t chan_mask_b_bs,
     int32_t with_mask_chan, int32_t occlude, float* dst, float* density, uint8_t* warped, uint8_t* valid,
     float* mask_chan, int32_t* dst_flags, int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n,
-    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream, int32_t fh, int32_t fw, int32_t foy, int32_t fox, int elem = 0) {
+    int32_t c, int32_t h, int32_t w, int32_t round_mode, void* stream, int32_t fh, int32_t fw, int32_t foy, int32_t fox, int elem = 0, int raw = 0) {
     const bool half_in = elem != 0;       // flow and data planes hold fp16 (2 channels, no window, no xs / ys, no data_b, no rounding)
     if (!data || !dst || !workspace || !accum_fallback) return OFL_E_NULL;
     if (half_in && (c != 2 || !flow || xs || ys || data_b || fw != 0 || round_mode != 0)) return OFL_E_UNSUPPORTED;
@@ -2586,6 +2587,7 @@ static int splat_tiled_impl(
     gp.s.data_b = data_b; gp.s.data_b_bs = data_b_bs;
     gp.s.round_mode = round_mode;
     gp.s.fh = fh; gp.s.fw = fw; gp.s.foy = foy; gp.s.fox = fox;
+    gp.s.raw = raw;
     gp.tiles_x = (w + kSpTW - 1) / kSpTW; gp.tiles_y = (h + kSpTH - 1) / kSpTH;
     gp.tiles_img = (uint32_t)(gp.tiles_x * gp.tiles_y);
     if ((int64_t)gp.tiles_img * n >= (1ll << 31)) return OFL_E_SHAPE;
@@ -2733,6 +2735,19 @@ __attribute__((visibility("default"))) int ofl_splat_tiled_win_f32(
                             weight_mask_bs, chan_mask_a, chan_mask_a_bs, chan_mask_b, chan_mask_b_bs, with_mask_chan, occlude, dst,
                             density, warped, valid, mask_chan, nullptr, workspace, workspace_ints, accum_fallback, n, c, h, w,
                             round_mode, stream, fh, fw, foy, fox);
+}
+
+// the weighted sums of a forward splat, NOT normalised: dst[n,c,q] = sum over source pixels i and corners k landing on q of
+// w_ik * data_sign * data[n,c,i] -- the transpose of the backward warp, i.e. the gradient of ofl_warp_bwd_f32 with respect to its
+// source when `data` is the upstream gradient and flow_sign the NEGATED sign of the warp (same kernels as ofl_splat_tiled_f32:
+// no float atomics outside fold tiles, deterministic there)
+__attribute__((visibility("default"))) int ofl_splat_sum_f32(
+    const float* flow, int64_t flow_bs, float flow_sign, const float* data, int64_t data_bs, float data_sign, float* dst,
+    int32_t* workspace, int64_t workspace_ints, float* accum_fallback, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+    if (!flow) return OFL_E_NULL;
+    return splat_tiled_impl(flow, flow_bs, flow_sign, nullptr, nullptr, 0, data, data_bs, data_sign, nullptr, 0, nullptr, 0, nullptr, 0,
+                            nullptr, 0, 0, 0, dst, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_ints,
+                            accum_fallback, n, c, h, w, 0, stream, 0, 0, 0, 0, 0, 1);
 }
 
 __attribute__((visibility("default"))) int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
