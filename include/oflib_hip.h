@@ -363,15 +363,17 @@ int ofl_warp_bwd_grad_f32(const float* flow, int64_t flow_bs, float flow_sign,
  * flow|xs,ys / data (the data actually splatted: data_sign * (data - data_b)) / weight_mask / occlude as in the forward
  * call; out [N,C,H,W] and density [N,H,W] are the forward results (out before any rounding); grad_out [N,C,H,W];
  * grad_density optional [N,H,W] (upstream gradient of the density output).  grad_data [N,C,H,W], grad_xy [N,2,H,W]
- * (x then y; for a flow operand grad_flow = flow_sign * grad_xy) -- either may be NULL.  C <= 8 per call, else
- * OFL_E_UNSUPPORTED (split the channels).
+ * (x then y; for a flow operand grad_flow = flow_sign * grad_xy) -- either may be NULL.  C <= 3 per call, else
+ * OFL_E_UNSUPPORTED (split the channels; grad_density with the first group only; the grad_xy of the groups add up).
+ * scratch: fp32[N * 4 * H * W] (a first pass leaves g_c / max(D, 1e-3) and the density term of every destination pixel in
+ * one 16-byte slot: the divisions are done once, and the gather loads one slot per corner instead of 2 C + 1 scalars).
  */
 int ofl_splat_grad_f32(const float* flow, int64_t flow_bs, float flow_sign,
                        const float* xs, const float* ys, int64_t xy_bs,
                        const float* data, int64_t data_bs,
                        const uint8_t* weight_mask, int64_t weight_mask_bs, int32_t occlude,
                        const float* out, const float* density,
-                       const float* grad_out, const float* grad_density,
+                       const float* grad_out, const float* grad_density, float* scratch,
                        float* grad_data, float* grad_xy,
                        int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 

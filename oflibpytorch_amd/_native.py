@@ -15,7 +15,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 22              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 23              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -76,7 +76,7 @@ def load_library(path: str = None):
     lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                         p, p, i64, p, i32, i32, i32, i32, i32, p]
     lib.ofl_warp_bwd_grad_f32.argtypes = [p, i64, f32, p, i64, p, f32, p, i64, p, i32, i32, i32, i32, p]
-    lib.ofl_splat_grad_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, p, i64, i32, p, p, p, p, p, p, i32, i32, i32, i32, p]
+    lib.ofl_splat_grad_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, p, i64, i32, p, p, p, p, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_sample_pts_f32.argtypes = [p, i64, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
@@ -526,8 +526,8 @@ def splat_grad(flow, data, out, density, grad_out, *, xs=None, ys=None, flow_sig
         gd = torch.empty((n, c, h, w), dtype=torch.float32, device=dev) if want_data else None
         gxy = None
         occ = 1 if (occlude and f is not None) else 0
-        for c0 in range(0, c, 8):                       # (the kernel keeps 8 channels of a pixel in registers)
-            c1 = min(c0 + 8, c)
+        for c0 in range(0, c, 3):                       # (3 channels + the density term: one 16-byte slot per destination pixel)
+            c1 = min(c0 + 3, c)
             part = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev) if want_xy else None
             dd = d[:, c0:c1]
             if c1 - c0 != c:
@@ -535,8 +535,9 @@ def splat_grad(flow, data, out, density, grad_out, *, xs=None, ys=None, flow_sig
             ddbs = 0 if dbs == 0 else dd.stride(0)
             oo, gg = (o, g) if c1 - c0 == c else (o[:, c0:c1].contiguous(), g[:, c0:c1].contiguous())
             gdd = None if gd is None else (gd if c1 - c0 == c else torch.empty((n, c1 - c0, h, w), dtype=torch.float32, device=dev))
+            scratch = torch.empty((n, h, w, 4), dtype=torch.float32, device=dev)
             _check(lib.ofl_splat_grad_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(dd), ddbs, _ptr(wm), wmbs,
-                                          occ, _ptr(oo), _ptr(den), _ptr(gg), _ptr(gden if c0 == 0 else None), _ptr(gdd),
+                                          occ, _ptr(oo), _ptr(den), _ptr(gg), _ptr(gden if c0 == 0 else None), _ptr(scratch), _ptr(gdd),
                                           _ptr(part), n, c1 - c0, h, w, _stream(dev)), "ofl_splat_grad_f32")
             if gd is not None and gdd is not gd:
                 gd[:, c0:c1] = gdd

@@ -133,6 +133,7 @@ struct SplatGradParams {
     const uint8_t* weight_mask; int64_t weight_mask_bs;
     int32_t occlude;
     const float* out; const float* density; const float* gout; const float* gden;   // gden: optional upstream gradient of the density output
+    float* prep;                       // [N, H * W] 16-byte slots (gA_0, gA_1, gA_2, density term) per DESTINATION pixel (splat_grad_prep_kernel)
     float* gdata; float* gxy;          // optional [N,C,H,W], [N,2,H,W]
     int32_t n, c, h, w;
 };
@@ -141,7 +142,44 @@ __device__ __forceinline__ bool is_zero_vec(float u, float v) {
     return (u < kZeroThr) && (u > -kZeroThr) && (v < kZeroThr) && (v > -kZeroThr);
 }
 
-constexpr int kMaxGradC = 8;   // channels handled per launch (the host loops over groups)
+constexpr int kMaxGradC = 3;   // channels handled per launch (the host loops over groups): with the density term they fill one 16-byte slot per destination pixel
+
+// Pass 1, per DESTINATION pixel (coalesced): gA_c = g_c / max(D, 1e-3) (0 where the pixel was un-occlude-filled: its gradient
+// never reached A, D) and the term every corner weight that lands here receives, gD = (D >= 1e-3 ? -sum_c g_c out_c / max(D,
+// 1e-3) : 0) + grad_density.  Each destination pixel is a corner of ~4 source pixels: its 2 C divisions are done once here
+// instead of four times in the gather below (B=16 1080p C=3: 1.7 -> 1.0 ms for the two passes).
+__global__ __launch_bounds__(256) void splat_grad_prep_kernel(const SplatGradParams p) {
+    const int n = blockIdx.y;
+    const int C = p.c;
+    const int64_t hw = (int64_t)p.h * p.w;
+    const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
+    const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
+    const float* __restrict__ ob = p.out + (int64_t)n * C * hw;
+    const float* __restrict__ den = p.density + (int64_t)n * hw;
+    const float* __restrict__ gb = p.gout + (int64_t)n * C * hw;
+    float4* __restrict__ pr = reinterpret_cast<float4*>(p.prep) + (int64_t)n * hw;
+    for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < hw; pos += (int64_t)gridDim.x * blockDim.x) {
+        const float d = den[pos];
+        bool filled = false;
+        if (!(d > 0.0f) && p.occlude && fu) {
+            const bool wmp = wmk ? (wmk[pos] != 0) : true;
+            filled = wmp && is_zero_vec(fu[pos], fu[hw + pos]);
+        }
+        const float dcl = d < kDenMin ? kDenMin : d;
+        float gD = 0.0f, gA[kMaxGradC] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < kMaxGradC; ++c) {
+            if (c < C) {
+                const float g = filled ? 0.0f : gb[(int64_t)c * hw + pos];
+                gA[c] = g / dcl;
+                gD -= g * ob[(int64_t)c * hw + pos] / dcl;
+            }
+        }
+        float term = d >= kDenMin ? gD : 0.0f;               // clamp_min passes the gradient where D >= 1e-3
+        if (p.gden) term += p.gden[(int64_t)n * hw + pos];
+        pr[pos] = make_float4(gA[0], gA[1], gA[2], term);
+    }
+}
 
 __global__ __launch_bounds__(256) void splat_grad_kernel(const SplatGradParams p) {
     const int n = blockIdx.y;
@@ -151,9 +189,9 @@ __global__ __launch_bounds__(256) void splat_grad_kernel(const SplatGradParams p
     const float* __restrict__ fu = p.flow ? p.flow + n * p.flow_bs : nullptr;
     const float* __restrict__ db = p.data + n * p.data_bs;
     const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
-    const float* __restrict__ ob = p.out + (int64_t)n * C * hw;
     const float* __restrict__ den = p.density + (int64_t)n * hw;
     const float* __restrict__ gb = p.gout + (int64_t)n * C * hw;
+    const float4* __restrict__ pr = reinterpret_cast<const float4*>(p.prep) + (int64_t)n * hw;
     for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < hw; pix += (int64_t)gridDim.x * blockDim.x) {
         const int y = (int)(pix / w), x = (int)(pix - (int64_t)y * w);
         float xv, yv;
@@ -190,28 +228,16 @@ __global__ __launch_bounds__(256) void splat_grad_kernel(const SplatGradParams p
 #pragma unroll
                 for (int kx = 0; kx < 2; ++kx) {
                     const int64_t pos = (int64_t)iys[ky] * w + ixs[kx];
-                    const float d = den[pos];
-                    bool filled = false;
-                    if (!(d > 0.0f) && p.occlude && fu) {
-                        // was this destination filled by the un-occlude rule?  then its gradient never reached A, D
-                        const bool wmp = wmk ? (wmk[pos] != 0) : true;
-                        filled = wmp && is_zero_vec(fu[pos], fu[hw + pos]);
-                    }
-                    const float dcl = d < kDenMin ? kDenMin : d;
-                    float gw = 0.0f, gD = 0.0f;
+                    float gw = 0.0f;
                     const float wgt = wy[ky] * wx[kx];
+                    const float4 slot = pr[pos];                              // pass 1's (g_c / max(D, 1e-3), density term) of that destination pixel: ONE load
+                    const float gAs[kMaxGradC] = {slot.x, slot.y, slot.z};
 #pragma unroll
                     for (int c = 0; c < kMaxGradC; ++c) {
-                        if (c < C) {
-                            const float g = filled ? 0.0f : gb[(int64_t)c * hw + pos];
-                            const float gA = g / dcl;
-                            gd[c] += wgt * gA;
-                            gw += dat[c] * gA;
-                            gD -= g * ob[(int64_t)c * hw + pos] / dcl;
-                        }
+                        gd[c] += wgt * gAs[c];                                // (channels beyond C are zero in the slot)
+                        gw += dat[c] * gAs[c];
                     }
-                    if (d >= kDenMin) gw += gD;          // clamp_min passes the gradient where D >= 1e-3
-                    if (p.gden) gw += p.gden[(int64_t)n * hw + pos];
+                    gw += slot.w;                                             // through the density, and the density output's own gradient
                     gwx[kx] += wy[ky] * gw;
                     gwy[ky] += wx[kx] * gw;
                 }
@@ -398,9 +424,9 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_grad_f32(
 __attribute__((visibility("default"))) int ofl_splat_grad_f32(
     const float* flow, int64_t flow_bs, float flow_sign, const float* xs, const float* ys, int64_t xy_bs,
     const float* data, int64_t data_bs, const uint8_t* weight_mask, int64_t weight_mask_bs, int32_t occlude,
-    const float* out, const float* density, const float* grad_out, const float* grad_density, float* grad_data,
-    float* grad_xy, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
-    if (!data || !out || !density || !grad_out) return OFL_E_NULL;
+    const float* out, const float* density, const float* grad_out, const float* grad_density, float* scratch,
+    float* grad_data, float* grad_xy, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+    if (!data || !out || !density || !grad_out || !scratch) return OFL_E_NULL;
     if (!flow && !(xs && ys)) return OFL_E_NULL;
     if (!grad_data && !grad_xy) return OFL_E_ARG;
     if (flow && !(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
@@ -412,7 +438,9 @@ __attribute__((visibility("default"))) int ofl_splat_grad_f32(
     p.flow = flow; p.flow_bs = flow_bs; p.flow_sign = flow_sign; p.xs = xs; p.ys = ys; p.xy_bs = xy_bs;
     p.data = data; p.data_bs = data_bs; p.weight_mask = weight_mask; p.weight_mask_bs = weight_mask_bs; p.occlude = occlude;
     p.out = out; p.density = density; p.gout = grad_out; p.gden = grad_density; p.gdata = grad_data; p.gxy = grad_xy;
+    p.prep = scratch;
     p.n = n; p.c = c; p.h = h; p.w = w;
+    hipLaunchKernelGGL(splat_grad_prep_kernel, dim3(blocks_for((int64_t)h * w, n), (unsigned)n), dim3(256), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(splat_grad_kernel, dim3(blocks_for((int64_t)h * w, n), (unsigned)n), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

@@ -43,8 +43,9 @@ def test_argument_validation_needs_no_gpu():
     # the new entry points: NULL / shape / argument checks
     assert lib.ofl_warp_bwd_grad_f32(null, 0, 1.0, null, 0, null, 1.0, null, 0, null, 1, 1, 4, 4, null) == -1
     assert lib.ofl_warp_bwd_grad_f32(one, 0, 1.0, one, 0, one, 1.0, null, 0, null, 1, 1, 4, 4, null) == -3
-    assert lib.ofl_splat_grad_f32(one, 0, 1.0, null, null, 0, one, 0, null, 0, 1, one, one, one, null, one, null,
-                                  1, 9, 4, 4, null) == -4
+    assert lib.ofl_splat_grad_f32(one, 0, 1.0, null, null, 0, one, 0, null, 0, 1, one, one, one, null, one, one, null,
+                                  1, 4, 4, 4, null) == -4
+    assert lib.ofl_splat_sum_f32(null, 0, 1.0, one, 0, 1.0, one, one, 8, one, 1, 1, 4, 4, null) == -1
     assert lib.ofl_sample_pts_f32(one, 0, one, 0, one, 1, 0, 4, 4, null) == -2
     assert lib.ofl_flow_extents_f32(one, 0, null, 0, 0.5, one, one, 1, 4, 4, null) == -3
     assert lib.ofl_flag_words_or_i32(null, 1, one, null) == -1 and lib.ofl_flag_words_or_i32(one, 0, one, null) == -2
