@@ -42,3 +42,19 @@ for ref in 'ts':
         t_f = timeit(lambda: ofl.apply_flow(f1, img, ref))
     t_b = timeit(both)
     print("apply_flow '%s' C=3: forward %.3f ms, forward + backward (grad wrt flow and image, incl. the torch mul / sum) %.3f ms" % (ref, t_f, t_b))
+
+
+# the flow-level operations: gradients wrt both flows
+for name, make in (("switch_ref s->t", lambda a, b: ofl.Flow(a, 's', m1).switch_ref().vecs),
+                   ("combine_with mode 3 't'", lambda a, b: ofl.Flow(a, 't', m1).combine_with(ofl.Flow(b, 't', m2), 3).vecs),
+                   ("combine_with mode 1 't'", lambda a, b: ofl.Flow(a, 't', m1).combine_with(ofl.Flow(b, 't', m2), 1).vecs)):
+    fa, fb = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+    wts = torch.randn_like(f1)
+
+    def both():
+        fa.grad = None; fb.grad = None
+        (make(fa, fb) * wts).sum().backward()
+    with torch.no_grad():
+        t_f = timeit(lambda: make(f1, f2))
+    t_b = timeit(both)
+    print("%-26s forward %.3f ms, forward + backward %.3f ms" % (name, t_f, t_b))
