@@ -186,3 +186,33 @@ def test_flow_api_under_inference_mode_gpu(dev):
     for p, q in zip(plain, got):
         assert torch.equal(p, q)
     assert torch.equal(pw, gw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 5, 90, 131, False), (3, 7, 64, 96, True), (1, 4, 33, 40, False)])
+def test_gradients_with_more_than_three_channels(shape, dev):
+    """More than 3 channels run as groups of 3 through the gather splat (grad wrt the warp's source: ofl_splat_sum_f32) and
+    through the two-pass splat backward (ofl_splat_grad_f32: the position gradients of the groups add up); odd widths."""
+    import oflibpytorch_amd as ofl
+    n, c, h, w, bcast = shape
+    g = torch.Generator().manual_seed(c)
+    f = _smooth(n, h, w, 5.0, 3 + c)
+    img = torch.rand(1 if bcast else n, c, h, w, generator=g)
+    wts = torch.randn(n, c, h, w, generator=g)
+    fa, ia = f.to(dev).requires_grad_(), img.to(dev).requires_grad_()
+    (ofl.apply_flow(fa, ia, 't') * wts.to(dev)).sum().backward()
+    fb, ib = f.clone().requires_grad_(), img.clone().requires_grad_()
+    (_ref_apply_t(fb, ib) * wts).sum().backward()
+    _close(fa.grad.cpu(), fb.grad, "grad wrt flow, C = %d" % c)
+    _close(ia.grad.cpu(), ib.grad, "grad wrt target, C = %d" % c)
+    full = img.expand(n, -1, -1, -1).contiguous()
+    fa2, da = f.to(dev).requires_grad_(), full.to(dev).requires_grad_()
+    x = fa2[:, 0] + torch.arange(w, device=dev)[None, None, :]
+    y = fa2[:, 1] + torch.arange(h, device=dev)[None, :, None]
+    (ofl.grid_from_unstructured_data(x, y, da)[0] * wts.to(dev)).sum().backward()
+    fb2, db = f.clone().requires_grad_(), full.clone().requires_grad_()
+    xb = fb2[:, 0] + torch.arange(w)[None, None, :]
+    yb = fb2[:, 1] + torch.arange(h)[None, :, None]
+    (_ref_splat(xb, yb, db, None)[0] * wts).sum().backward()
+    _close(da.grad.cpu(), db.grad, "splat: grad wrt data, C = %d" % c, rtol=1e-3)
+    _close(fa2.grad.cpu(), fb2.grad, "splat: grad wrt positions, C = %d" % c, rtol=2e-3)
