@@ -483,15 +483,9 @@ def warp_bwd_grad(flow, src, grad_out, *, flow_sign=1.0, g_scale=1.0, want_src=T
         if want_src:
             # grad wrt the source = the un-normalised forward splat of the upstream gradient along the negated flow: the gather
             # kernels instead of 4 * C global float atomics per pixel (ofl_splat_sum_f32; B=16 1080p C=3: 7.1 -> 1.0 ms)
-            ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
-            accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + min(c, 3), h, w), dtype=torch.float32, device=dev)
-            full = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
-            rc = lib.ofl_splat_sum_f32(_ptr(f), fbs, -float(flow_sign), _ptr(g), c * h * w, float(g_scale), _ptr(full),
-                                       _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, _stream(dev))
-            if rc == 0:
+            full = splat_sum(f if fbs != 0 or n == 1 else f.expand(n, -1, -1, -1), g, flow_sign=-float(flow_sign), data_sign=float(g_scale))
+            if full is not None:
                 gs = full.sum(0, keepdim=True) if (ns == 1 and n > 1) else full
-            elif rc != -4:
-                _check(rc, "ofl_splat_sum_f32")
         atomics = want_src and gs is None                   # shapes the gather splat does not take (W < 4 ...)
         if atomics:
             gs = torch.zeros((ns, c, h, w), dtype=torch.float32, device=dev)
@@ -502,6 +496,29 @@ def warp_bwd_grad(flow, src, grad_out, *, flow_sign=1.0, g_scale=1.0, want_src=T
                                              _stream(dev)),
                    "ofl_warp_bwd_grad_f32")
     return gs, gf
+
+
+def splat_sum(flow, data, *, flow_sign=1.0, data_sign=1.0):
+    """ofl_splat_sum_f32: the weighted sums of the forward splat of data [N,C,H,W] along flow_sign * flow [N|1,2,H,W], NOT divided
+    by the density (every pixel contributes) -- the transpose of the backward warp.  None for shapes the gather splat does not
+    take (W < 4)."""
+    lib, dev = load_library(), device(flow, data)
+    n, c, h, w = data.shape
+    with _on(dev):
+        f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
+        d = data.detach().to(dev, torch.float32).contiguous()
+        ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
+        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + min(c, 3), h, w), dtype=torch.float32, device=dev)
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+        rc = lib.ofl_splat_sum_f32(_ptr(f), fbs, float(flow_sign), _ptr(d), c * h * w, float(data_sign), _ptr(out),
+                                   _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, _stream(dev))
+        if rc == -4:
+            return None
+        _check(rc, "ofl_splat_sum_f32")
+        if collect_splat_stats:
+            global _last_splat_stats
+            _last_splat_stats = ws[:8].clone()
+    return out
 
 
 def splat_grad(flow, data, out, density, grad_out, *, xs=None, ys=None, flow_sign=1.0, weight_mask=None, occlude=True,

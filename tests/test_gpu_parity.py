@@ -819,3 +819,48 @@ def test_flag_words_or_for_the_sharded_reduce(dev):
             expect |= v
         assert out[:n] == words.tolist() and out[n:] == [(expect >> k) & 1 for k in range(5)]
         assert distributed.split_global_or(distributed.with_global_or(words.to(dev)).cpu().tolist()) == (words.tolist(), expect)
+
+
+def _splat_sum_reference(flow, data, flow_sign, data_sign):
+    """ofl_splat_sum_f32 restated with loops (small frames): per corner class, in raster order of the source pixels, then
+    ((c0 + c1) + c2) + c3 -- the order of utils.py:1133-1143 without the division of :1144."""
+    n, c, h, w = data.shape
+    out = np.zeros((n, c, h, w), np.float32)
+    f32 = np.float32
+    for b in range(n):
+        acc = np.zeros((4, c, h, w), np.float32)
+        for y in range(h):
+            for x in range(w):
+                xv = f32(f32(flow_sign) * flow[b, 0, y, x] + f32(x))
+                yv = f32(f32(flow_sign) * flow[b, 1, y, x] + f32(y))
+                x0, y0 = np.floor(xv), np.floor(yv)
+                for ky in range(2):
+                    for kx in range(2):
+                        xi, yi = int(x0) + kx, int(y0) + ky
+                        if not (0 <= xi < w and 0 <= yi < h):
+                            continue
+                        wx = f32(f32(x0 + 1) - xv) if kx == 0 else f32(xv - f32(x0))
+                        wy = f32(f32(y0 + 1) - yv) if ky == 0 else f32(yv - f32(y0))
+                        wgt = f32(wy * wx)
+                        for ch in range(c):
+                            acc[2 * ky + kx, ch, yi, xi] = f32(acc[2 * ky + kx, ch, yi, xi] + f32(wgt * f32(f32(data_sign) * data[b, ch, y, x])))
+        out[b] = ((acc[0] + acc[1]) + acc[2]) + acc[3]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 40, 56), (1, 5, 33, 45), (2, 2, 64, 72)])
+def test_splat_sum_is_the_unnormalised_splat_bit_for_bit(shape, dev):
+    """ofl_splat_sum_f32 (the gradient of the backward warp wrt its source) against its loop restatement: bit-exact on a
+    fold-free flow, both signs, more than three channels, odd widths."""
+    from oflibpytorch_amd import _native
+    _native.collect_splat_stats = True
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    flow = _smooth(n, h, w, 1.5, 91, dev)
+    data = (torch.rand(n, c, h, w, generator=g) * 10 - 3)
+    for fs, ds in ((1.0, 1.0), (-1.0, -1.0)):
+        got = _native.splat_sum(flow, data.to(dev), flow_sign=fs, data_sign=ds)
+        st = _native._last_splat_stats.cpu().tolist()
+        assert st[0] == 0 and st[1] == 0
+        assert np.array_equal(got.cpu().numpy(), _splat_sum_reference(flow.cpu().numpy(), data.numpy(), fs, ds))
