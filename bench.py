@@ -139,11 +139,79 @@ def cpu_baseline(h, w, seconds, threads):
     return out
 
 
+def _event_ms(fn, iters, warm=3):
+    """mean / median / min ms of `fn` over `iters` calls, HIP events on the launch stream"""
+    for _ in range(warm):
+        fn()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(iters)]
+    torch.cuda.synchronize()
+    for i in range(iters):
+        ev[i][0].record()
+        fn()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    t = sorted(e[0].elapsed_time(e[1]) for e in ev)
+    return sum(t) / iters, t[iters // 2], t[0]
+
+
+def secondary_lines(ofl, dev):
+    """The other single-GPU configurations of BASELINE.json, timed the same way (HIP events round the whole operation, inputs
+    resident, objects built inside the timed call where the config says so): ms, algorithmic B/px and the
+    fraction of the 8 TB/s HBM peak those bytes / that time come to."""
+    out = []
+
+    def line(name, px, bpp, stats, extra=None):
+        mean, median, lo = stats
+        d = {"config": name, "ms": round(mean, 4), "ms_median": round(median, 4), "ms_min": round(lo, 4),
+             "bytes_per_px": bpp, "Mpix_s": round(px / (mean * 1e-3) / 1e6, 1),
+             "achieved_GBs": round(bpp * px / (mean * 1e-3) / 1e9, 1), "frac": round(bpp * px / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if extra:
+            d.update(extra)
+        out.append(d)
+    h, w = 1080, 1920
+    # config 2: B = 1 1080p fp32 't' Flow.apply (one 2-Mpx launch: launch-latency bound, reported as it is)
+    f1, f2, img, m1, m2, tm = make_inputs(1, h, w, dev, seed=2)
+    fl = ofl.Flow(f2, 't', m2)
+    line("configs[1]: B=1 1080x1920 fp32 Flow.apply 't' (C=3, masks, valid area)", h * w, BYTES_APPLY,
+         _event_ms(lambda: fl.apply(img, target_mask=tm, return_valid_area=True), 200, 10))
+    # config 3: B = 16 1080p 's' forward-splat warp
+    from oflibpytorch_amd import _native
+    f1, f2, img, m1, m2, tm = make_inputs(16, h, w, dev, seed=3)
+    fs = ofl.Flow(f1, 's', m1)
+    _native.collect_splat_stats = True
+    st3 = _event_ms(lambda: fs.apply(img, target_mask=tm, return_valid_area=True), 50, 5)
+    stats = _native._last_splat_stats.cpu().tolist() if _native._last_splat_stats is not None else [0, 0, 0]
+    _native.collect_splat_stats = False
+    st3 = _event_ms(lambda: fs.apply(img, target_mask=tm, return_valid_area=True), 50, 2)
+    line("configs[2]: B=16 1080x1920 fp32 Flow.apply 's' (forward splat, C=3, masks, valid area; sigma 8)", 16 * h * w, 35, st3,
+         {"fold_tiles_on_lds_atomics": int(stats[1]), "images_on_two_pass_path": int(stats[2])})
+    fs2 = ofl.Flow(smooth_flow(16, h, w, 2.0, 1003, dev), 's', m1)
+    line("configs[2] on a smooth flow (sigma 2)", 16 * h * w, 35,
+         _event_ms(lambda: fs2.apply(img, target_mask=tm, return_valid_area=True), 50, 3))
+    line("switch_ref 's'->'t' B=16 1080x1920 fp32 (sigma 8)", 16 * h * w, 18, _event_ms(lambda: fs.switch_ref(), 50, 3))
+    del f1, f2, img, m1, m2, tm, fs, fs2, fl
+    # config 5: B = 16 (the per-GPU share of B = 128 on 8 GPUs) 2160x3840, flows STORED in fp16: switch_ref s->t, then mode 1
+    h, w = 2160, 3840
+    g1 = smooth_flow(16, h, w, 8.0, 1005, dev).half()
+    g2 = smooth_flow(16, h, w, 8.0, 5005, dev).half()
+    m = torch.ones(16, h, w, dtype=torch.bool, device=dev)
+
+    def cfg5():
+        return ofl.Flow(g1, 's', m).switch_ref().combine_with(ofl.Flow(g2, 't', m), 1)
+    line("configs[4] per GPU: B=16 2160x3840 fp16-stored flows, Flow() x2 + switch_ref 's'->'t' + combine_with mode 1", 16 * h * w, 25,
+         _event_ms(cfg5, 10, 2), {"note": "10 B/px switch_ref + 15 B/px mode 1 't' at fp16 storage; validation of both operands inside"})
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="timed blocks of EXACTLY --steps steps each (0: max(5, 500 / steps)); `value` is the median block")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (BASELINE configs 2, 3, 5)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=64, help="batch elements per GPU (weak) / in the whole job (strong)")
     ap.add_argument("--height", type=int, default=1080)
@@ -170,10 +238,12 @@ def main():
     _native.load_library()
 
     import torch.distributed as dist
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # under torch.distributed.run (also at N = 1)
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        ofd.enable_batch_sharding()          # batch-global early-exit flags over RCCL (one tiny all-reduce per new tensor)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" = RCCL over xGMI
+        ofd.enable_batch_sharding()          # batch-global early-exit flags over RCCL (one tiny all-reduce per new tensor; a no-op at N = 1)
 
     h, w = args.height, args.width
     if args.scaling == "strong":
@@ -183,66 +253,93 @@ def main():
         n, global_batch = args.batch, args.batch * world
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(nb, steps, warmup, seed):
-        """-> dict of per-step wall ms (validation-inclusive and cached) and HIP-event kernel ms of the two launches"""
+    def measure(nb, steps, warmup, seed, blocks):
+        """`blocks` timed blocks of EXACTLY `steps` steps each (barrier + synchronize on both sides of every block), validation
+        inclusive and on cached objects; then HIP events round every launch of max(steps, 100) more steps.
+        -> per-block seconds (both flavours) and the per-launch kernel times in ms"""
         f1, f2, img, m1, m2, tm = make_inputs(nb, h, w, dev, seed=seed)
 
         def step_streaming():
-            a, b = ofl.Flow(f1, 't', m1), ofl.Flow(f2, 't', m2)        # validation: one fused flag reduction + sync each
+            a, b = ofl.Flow(f1, 't', m1), ofl.Flow(f2, 't', m2)        # validation: one fused flag reduction + read-back each
             b.apply(img, target_mask=tm, return_valid_area=True)
             a.combine_with(b, 3)
         for _ in range(warmup):
             step_streaming()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):                                          # EXACTLY `steps` timed steps
-            step_streaming()
-        barrier()
-        el_stream = time.perf_counter() - t0
-        # the same step on pre-built objects (validation cached per tensor version), with HIP events round each launch
+        stream_s = []
+        for _ in range(blocks):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):                                      # EXACTLY `steps` timed steps per block
+                step_streaming()
+            barrier()
+            stream_s.append(time.perf_counter() - t0)
+        # the same step on pre-built objects (validation cached per tensor version)
         flow1, flow2 = ofl.Flow(f1, 't', m1), ofl.Flow(f2, 't', m2)
-        for _ in range(max(1, warmup)):
-            flow2.apply(img, target_mask=tm, return_valid_area=True)
-            flow1.combine_with(flow2, 3)
-        barrier()
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
-        t0 = time.perf_counter()
-        for k in range(steps):
-            ev[k][0].record()
-            flow2.apply(img, target_mask=tm, return_valid_area=True)
-            ev[k][1].record()
-            flow1.combine_with(flow2, 3)
-            ev[k][2].record()
-        barrier()
-        el_cached = time.perf_counter() - t0
-        return {"stream_s": el_stream, "cached_s": el_cached,
-                "apply_ms": sum(e[0].elapsed_time(e[1]) for e in ev) / steps,       # HIP events on the launch stream
-                "comb_ms": sum(e[1].elapsed_time(e[2]) for e in ev) / steps}
 
-    r = measure(n, args.steps, args.warmup, seed=rank)
-    elapsed, el_cached = r["stream_s"], r["cached_s"]
+        def step_cached():
+            flow2.apply(img, target_mask=tm, return_valid_area=True)
+            flow1.combine_with(flow2, 3)
+        for _ in range(max(1, warmup)):
+            step_cached()
+        cached_s = []
+        for _ in range(blocks):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_cached()
+            barrier()
+            cached_s.append(time.perf_counter() - t0)
+        # per-launch kernel times: HIP events on the launch stream (torch's current stream is the one the C ABI gets)
+        k = max(steps, 100)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(k)]
+        barrier()
+        for i in range(k):
+            ev[i][0].record()
+            flow2.apply(img, target_mask=tm, return_valid_area=True)
+            ev[i][1].record()
+            flow1.combine_with(flow2, 3)
+            ev[i][2].record()
+        barrier()
+        ta = sorted(e[0].elapsed_time(e[1]) for e in ev)
+        tc = sorted(e[1].elapsed_time(e[2]) for e in ev)
+        return {"stream_s": stream_s, "cached_s": cached_s, "launches": k,
+                "apply_ms": sum(ta) / k, "comb_ms": sum(tc) / k, "apply_ms_median": ta[k // 2], "comb_ms_median": tc[k // 2],
+                "apply_ms_min": ta[0], "comb_ms_min": tc[0]}
+
+    def med(v):
+        return sorted(v)[len(v) // 2]
+
+    blocks = args.blocks if args.blocks > 0 else max(5, -(-500 // args.steps))
+    r = measure(n, args.steps, args.warmup, rank, blocks)
     t_apply, t_comb = r["apply_ms"], r["comb_ms"]
-    if world > 1:
-        t = torch.tensor([elapsed, el_cached], dtype=torch.float64, device=dev)
+    stream_blocks, cached_blocks = r["stream_s"], r["cached_s"]
+    if world > 1:                                  # every block's time is the MAX over the ranks
+        t = torch.tensor([stream_blocks, cached_blocks], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, el_cached = float(t[0].item()), float(t[1].item())
+        stream_blocks, cached_blocks = [float(v) for v in t[0].tolist()], [float(v) for v in t[1].tolist()]
+    elapsed, el_cached = med(stream_blocks), med(cached_blocks)          # the median block is the reported one
 
     probe = None
     if world == 1 and not args.no_probe and (n, h, w) == (64, 1080, 1920):
         # BASELINE.json configs[3] on 8 GPUs leaves 8 elements per GPU: the same step at B = 8 on this GPU
-        k8 = max(args.steps, 50)
-        p8 = measure(8, k8, 5, seed=11)
-        ms8, msc8 = p8["stream_s"] / k8 * 1e3, p8["cached_s"] / k8 * 1e3
-        probe = {"batch": 8, "steps": k8, "ms_per_step": round(ms8, 4), "ms_per_step_cached": round(msc8, 4),
+        k8 = max(args.steps, 100)
+        p8 = measure(8, k8, 5, 11, 5)
+        ms8, msc8 = med(p8["stream_s"]) / k8 * 1e3, med(p8["cached_s"]) / k8 * 1e3
+        probe = {"batch": 8, "steps": k8, "blocks": 5, "ms_per_step": round(ms8, 4), "ms_per_step_cached": round(msc8, 4),
+                 "ms_per_step_min_max": [round(min(p8["stream_s"]) / k8 * 1e3, 4), round(max(p8["stream_s"]) / k8 * 1e3, 4)],
                  "kernel_ms_per_step": round(p8["apply_ms"] + p8["comb_ms"], 4),
                  "host_overhead_ms_per_step_cached": round(msc8 - (p8["apply_ms"] + p8["comb_ms"]), 4),
                  "implied_speedup_at_8_gpus": round((elapsed / args.steps * 1e3) / ms8, 2),
                  "implied_speedup_at_8_gpus_cached": round((el_cached / args.steps * 1e3) / msc8, 2),
-                 "note": "global B=64 over 8 GPUs = this step at B=8 per GPU; speed-up = t(B=64 on 1 GPU) / t(B=8)"}
+                 "note": "global B=64 over 8 GPUs = this step at B=8 per GPU; speed-up = t(B=64 on 1 GPU) / t(B=8), median blocks"}
+
+    secondary = None
+    if world == 1 and not args.no_secondary and rank == 0:
+        secondary = secondary_lines(ofl, dev)
 
     # measured device-copy ceiling (SURVEY.md 8d): a 1 GiB fp32 copy on the same stream, read + write bytes / time
     a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
@@ -258,17 +355,21 @@ def main():
     del a, b
 
     if rank == 0:
+        traffic_source = "--traffic-bytes" if args.traffic_bytes is not None else None
         if args.traffic_bytes is None and (n, h, w) == (64, 1080, 1920):
-            for name in ("r2_traffic.json", "r1_traffic.json"):          # PMC passes are separate runs (tools/profile_bench.sh)
+            for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # PMC passes are separate runs (tools/refresh_profiles_r3.sh)
                 tj = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tj):
                     with open(tj) as fh:
                         args.traffic_bytes = json.load(fh).get("traffic_bytes_per_launch")
+                    traffic_source = ("profiles/%s: an EARLIER rocprofv3 --pmc pass of this command (2 x FETCH_SIZE + WRITE_SIZE per "
+                                      "launch, MI355X_MICROARCH.md gfx950 correction), not measured in this run" % name)
                     break
         px = n * h * w
         gpx = global_batch * h * w
         ms_step = elapsed / args.steps * 1e3
         ach = BYTES_APPLY * px / (t_apply * 1e-3) / 1e9
+        per_step = sorted(b / args.steps * 1e3 for b in stream_blocks)
         out = {
             "metric": "Mpix/s warped+composed (Flow(...) x2 from raw tensors, Flow.apply 't' C=3 + valid area, then "
                       "Flow.combine_with mode=3 -- the methods combine_flows / apply_flow wrap -- 1080p fp32)",
@@ -282,27 +383,37 @@ def main():
                                    "target+flow masks, valid area) + combine_with(mode=3, 't', masks)" % (n, h, w),
                        "batch_per_gpu": n, "global_batch": global_batch, "height": h, "width": w,
                        "parallelism": "batch-sharded x%d (no data-path collective)" % world,
+                       "launcher": "torch.distributed (nccl)" if dist.is_initialized() else "single process",
                        "bytes_per_px": BYTES_APPLY + BYTES_COMBINE},
+            "timing": {"blocks": len(stream_blocks), "steps_per_block": args.steps, "reported": "median block",
+                       "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
+                       "ms_per_step_max": round(per_step[-1], 4),
+                       "value_min": round(gpx / (per_step[-1] * 1e-3) / 1e6, 1), "value_max": round(gpx / (per_step[0] * 1e-3) / 1e6, 1)},
             "roofline": {"bound": "hbm", "kernel": "warp_bwd_lds_column_kernel<4,3,valid> (Flow.apply 't')",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": args.traffic_bytes,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": BYTES_APPLY * px,
-                         "avg_launch_ms": round(t_apply, 4),
+                         "avg_launch_ms": round(t_apply, 4), "median_launch_ms": round(r["apply_ms_median"], 4),
+                         "min_launch_ms": round(r["apply_ms_min"], 4), "launches_timed": r["launches"],
                          "device_copy_GBs": round(copy_gbs, 1), "frac_of_device_copy": round(ach / copy_gbs, 4)},
             "kernels": {"apply_ms": round(t_apply, 4), "apply_GBs": round(ach, 1),
-                        "combine3_ms": round(t_comb, 4),
+                        "combine3_ms": round(t_comb, 4), "combine3_ms_median": round(r["comb_ms_median"], 4),
                         "combine3_GBs": round(BYTES_COMBINE * px / (t_comb * 1e-3) / 1e9, 1),
+                        "combine3_frac": round(BYTES_COMBINE * px / (t_comb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "validation_ms_per_step": round(ms_step - el_cached / args.steps * 1e3, 4)},
             "value_cached_flow_objects": round(gpx / (el_cached / args.steps) / 1e6, 1),
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if probe is not None:
             out["strong_scaling_probe"] = probe
         if not args.no_cpu_baseline and world == 1:          # (the CPU baseline is a single-node, N = 1 figure)
             # 64 OpenMP threads is where the oracle peaks on the 2 x 64-core host of the GPU box (tools/cpu_threads_probe.py)
             out["cpu_baseline"] = cpu_baseline(h, w, args.cpu_seconds, min(os.cpu_count() or 1, 64))
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

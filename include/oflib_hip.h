@@ -292,6 +292,26 @@ int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
                        int32_t* flags, int32_t n, int32_t h, int32_t w, void* stream);
 
 /*
+ * The same reduction with the read-back built in (the reference's constructor raises on non-finite vectors, utils.py:98, so
+ * `Flow(...)` has to WAIT for the words: this entry point makes that wait one kernel and one polled host word instead of a
+ * memset, the kernel, a copy and an event).
+ *   flow        [*,2,H,W] fp32, or fp16 when flow_is_f16 (then H*W % 4 == 0 and 8 / 4-byte aligned planes, else
+ *               OFL_E_UNSUPPORTED);
+ *   work        DEVICE int32[n + 1], all zero before the first call; the kernel leaves it all zero again (words + arrival
+ *               counter: one buffer can serve every later call on the same stream, ONE call in flight at a time);
+ *   host_words  HOST-VISIBLE int32[n + 1] (hipHostMalloc, coherent + mapped: ofl_host_words_alloc): the block that finishes last
+ *               stores the n flag words to host_words[1 .. n] and then, behind a system-scope release, `serial` to
+ *               host_words[0].  The caller polls host_words[0] == serial (a value it has not used before) and reads the words.
+ */
+int ofl_flow_flags_host(const void* flow, int32_t flow_is_f16, int64_t flow_bs,
+                        const uint8_t* mask, int64_t mask_bs, float thr,
+                        int32_t* work, int32_t* host_words, int32_t serial,
+                        int32_t n, int32_t h, int32_t w, void* stream);
+/* pinned, coherent, device-mapped host words for ofl_flow_flags_host (zeroed); *out is usable as host AND device pointer */
+int ofl_host_words_alloc(int64_t ints, void** out);
+int ofl_host_words_free(void* ptr);
+
+/*
  * fp16-STORED FLOWS (BASELINE config 5; SURVEY.md section 8b "fp16-I/O variants").  The reference up-casts every flow to
  * fp32 on entry (utils.py:95, 118) and computes in fp32; so do these entry points -- the up-conversion is exact and happens
  * in registers, the arithmetic is the fp32 arithmetic of the plain entry points, and the results are bit-identical to
@@ -397,6 +417,17 @@ int ofl_sample_pts_grad_f32(const float* flow, int64_t flow_bs, const float* pts
  */
 int ofl_flow_extents_f32(const float* flow, int64_t flow_bs, const uint8_t* mask, int64_t mask_bs, float sign,
                          int32_t* workspace, float* extents, int32_t n, int32_t h, int32_t w, void* stream);
+
+/*
+ * Flow field of a 3 x 3 transformation matrix (flow_from_matrix, utils.py:339-376; the O(HW) half of from_matrix :646-705 and
+ * from_transforms :729-807, whose 3 x 3 algebra stays on the host):
+ *   hom      = M [x, y, 1]^T    accumulated as ATen's CPU batched matmul does for 3 x 3 operands (acc = 0; acc += m_ik * v_k)
+ *   dst[n,0] = sign * (hom.x / hom.z - x),  dst[n,1] = sign * (hom.y / hom.z - y)
+ * matrices [*,3,3] fp32 DEVICE memory (matrix_bs = 9, or 0 to broadcast one matrix), sign = +1 ('s') / -1 (the reference's
+ * negation of its 't' branch, exact), dst [N,2,H,W] fp32.  Bit-identical to the reference's PyTorch-CPU result.
+ */
+int ofl_flow_from_matrix_f32(const float* matrices, int64_t matrix_bs, float sign, float* dst,
+                             int32_t n, int32_t h, int32_t w, void* stream);
 
 /*
  * The flag words of a batch (ofl_flow_flags_f32, or the by-product words of the warp / splat kernels), copied, followed by

@@ -9,13 +9,16 @@ HIP device -- callers move them where the reference would have put them.
 """
 import ctypes
 import os
+import threading
+import time
 
+import numpy as np
 import torch
 
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 23              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 24              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -23,7 +26,7 @@ _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
             "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
-            "ofl_warp_bwd_h_f32")
+            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32")
 _lib = None
 
 
@@ -87,6 +90,10 @@ def load_library(path: str = None):
     lib.ofl_warp_bwd_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, p, i64, p, i64, p, p, i32, i32, i32, i32, i32, p]
     lib.ofl_splat_tiled_win_f32.argtypes = [p, i64, f32, i32, i32, i32, i32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                             p, i64, p, i32, i32, i32, i32, i32, p]
+    lib.ofl_flow_flags_host.argtypes = [p, i32, i64, p, i64, f32, p, p, i32, i32, i32, i32, p]
+    lib.ofl_host_words_alloc.argtypes = [i64, ctypes.POINTER(ctypes.c_void_p)]
+    lib.ofl_host_words_free.argtypes = [p]
+    lib.ofl_flow_from_matrix_f32.argtypes = [p, i64, f32, p, i32, i32, i32, p]
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
     lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
@@ -204,6 +211,66 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
         _check(lib.ofl_flow_flags_f32(_ptr(v), vbs, _ptr(m), mbs, THRESHOLD, _ptr(flags), n, h, w, _stream(dev)),
                "ofl_flow_flags_f32")
     return flags
+
+
+# -- validation read-back: the reduction's last block writes the words to host-visible memory, the host polls one word --------
+_HOST_WORDS = 1 << 12        # flag words one call can hand over (larger batches take the copy + event route)
+_host_slots = {}             # device -> [lock, device work words, host address, numpy view of the host words, last serial]
+_host_slots_lock = threading.Lock()
+HOST_POLL_SECONDS = 20.0     # a reduction that has not reported after this long is a failed launch, not a slow one
+
+
+def _host_slot(lib, dev):
+    with _host_slots_lock:
+        slot = _host_slots.get(dev)
+        if slot is None:
+            addr = ctypes.c_void_p()
+            _check(lib.ofl_host_words_alloc(_HOST_WORDS + 1, ctypes.byref(addr)), "ofl_host_words_alloc")
+            view = np.ctypeslib.as_array((ctypes.c_int32 * (_HOST_WORDS + 1)).from_address(addr.value))
+            slot = [threading.Lock(), torch.zeros(_HOST_WORDS + 1, dtype=torch.int32, device=dev), addr, view, 0]
+            _host_slots[dev] = slot
+    return slot
+
+
+def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):
+    """Flag word per batch element as a list of host ints: `flow_flags` and its read-back in ONE launch
+    (ofl_flow_flags_host: no memset, no copy, no event; the host polls the word the kernel's last block writes).
+    None when this call cannot take that route (CPU-resident or fp64 vectors, more than 4096 batch elements, an fp16 layout
+    the vector kernel does not take): the caller then uses `flow_flags` + a copy."""
+    if vecs.device.type != 'cuda' or vecs.dtype not in (torch.float32, torch.float16):
+        return None
+    n, _, h, w = vecs.shape
+    if n > _HOST_WORDS:
+        return None
+    lib, dev = load_library(), device(vecs, mask)
+    half = vecs.dtype == torch.float16
+    with _on(dev):
+        v, vbs = _planes(vecs.detach(), dev, vecs.dtype, n, "flow")
+        if half and vbs == 0 and n != 1:
+            return None
+        m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+        slot = _host_slot(lib, dev)
+        with slot[0]:                      # one call in flight per device: the work words and the host words are shared
+            serial = slot[4] = (slot[4] % 0x7ffffff0) + 1
+            work, view = slot[1], slot[3]
+            rc = lib.ofl_flow_flags_host(_ptr(v), 1 if half else 0, vbs, _ptr(m), mbs, THRESHOLD, _ptr(work), slot[2], serial,
+                                         n, h, w, _stream(dev))
+            if rc == -4:
+                return None
+            _check(rc, "ofl_flow_flags_host")
+            spins, t0 = 0, None
+            while view[0] != serial:       # the GPU is busy with the reduction itself for most of this wait
+                spins += 1
+                if spins & 0xfff == 0:
+                    if t0 is None:
+                        t0 = time.perf_counter()
+                    elif time.perf_counter() - t0 > HOST_POLL_SECONDS:
+                        torch.cuda.synchronize(dev)          # surfaces a launch failure as the runtime's own error
+                        if view[0] == serial:
+                            break
+                        _host_slots.pop(dev, None)           # (the work words may be dirty: start afresh next time)
+                        raise RuntimeError("oflibpytorch_amd: the flag reduction did not report back")
+            return view[1:1 + n].tolist()
 
 
 def flow_from_half(vecs16: torch.Tensor, mask: torch.Tensor = None):
@@ -504,6 +571,8 @@ def splat_sum(flow, data, *, flow_sign=1.0, data_sign=1.0):
     take (W < 4)."""
     lib, dev = load_library(), device(flow, data)
     n, c, h, w = data.shape
+    if w < 4 or h * w >= (1 << 24) or h >= 32768 or w >= 32768:
+        return None              # frames the gather splat does not take (its own limit, utils.py:1118): the caller's atomics kernel does
     with _on(dev):
         f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
         d = data.detach().to(dev, torch.float32).contiguous()
@@ -512,7 +581,7 @@ def splat_sum(flow, data, *, flow_sign=1.0, data_sign=1.0):
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
         rc = lib.ofl_splat_sum_f32(_ptr(f), fbs, float(flow_sign), _ptr(d), c * h * w, float(data_sign), _ptr(out),
                                    _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, _stream(dev))
-        if rc == -4:
+        if rc in (-4, -2):       # not eligible / shape beyond the gather splat's limits
             return None
         _check(rc, "ofl_splat_sum_f32")
         if collect_splat_stats:
@@ -593,6 +662,20 @@ def sample_pts_grad(flow, pts, grad_out, *, want_flow=True, want_pts=True):
             _check(lib.ofl_sample_pts_grad_f32(_ptr(f), fbs, _ptr(q), qbs, _ptr(g), _ptr(gf), _ptr(gp), n, m, h, w,
                                                _stream(dev)), "ofl_sample_pts_grad_f32")
     return gf, gp
+
+
+def flow_from_matrix(matrix: torch.Tensor, n: int, h: int, w: int, sign: float = 1.0) -> torch.Tensor:
+    """ofl_flow_from_matrix_f32: the flow field [n,2,h,w] of 3 x 3 matrices [n|1,3,3] (utils.py:339-376), negated when sign = -1,
+    generated on the HIP device of the matrix (else torch's current device) -- write-only, 8 B/px."""
+    lib, dev = load_library(), device(matrix)
+    with _on(dev):
+        m = matrix.detach().to(dev, torch.float32).reshape(-1, 9).contiguous()
+        if m.shape[0] not in (1, n):
+            raise ValueError("oflibpytorch_amd: %d matrices cannot broadcast to a batch of %d" % (m.shape[0], n))
+        dst = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
+        _check(lib.ofl_flow_from_matrix_f32(_ptr(m), 0 if m.shape[0] == 1 else 9, float(sign), _ptr(dst), n, h, w, _stream(dev)),
+               "ofl_flow_from_matrix_f32")
+    return dst
 
 
 def flag_words_or(words: torch.Tensor) -> torch.Tensor:

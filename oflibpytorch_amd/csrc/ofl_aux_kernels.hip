@@ -500,6 +500,44 @@ __attribute__((visibility("default"))) int ofl_flow_extents_f32(const float* flo
 }
 
 // the flag words of a batch followed by their OR, one int per bit (ofl_flag_words_or_i32): one wave
+// ------------------------------------------------------------------------------------------------
+// flow of a homography (flow_from_matrix, utils.py:339-376): hom = M [x, y, 1]^T in the order of ATen's CPU batched
+// matmul for 3 x 3 operands (its plain loop: acc = 0; acc += m[i][k] * v[k], k = 0, 1, 2; every product rounded), then
+// hom.xy / hom.z (IEEE divide) minus (x, y); `sign` = -1 restates the reference's `-flow_from_matrix(...)` of its 't' branch
+// (utils.py:699-705, 804-807: an exact negation).  Write-only, 8 B/px: 4 pixels per thread, 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_from_matrix_kernel(const float* __restrict__ mats, int64_t mat_bs, float sign,
+                                                               float* __restrict__ dst, int32_t h, int32_t w) {
+    const int n = blockIdx.y;
+    const float* __restrict__ m = mats + n * mat_bs;
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    const int64_t hw = (int64_t)h * w;
+    float* __restrict__ du = dst + (int64_t)n * 2 * hw;
+    const int wq = (w + 3) >> 2;                                   // 4-pixel groups per row (the last one may be partial)
+    const int64_t groups = (int64_t)h * wq;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(g / wq), x0 = (int)(g - (int64_t)y * wq) * 4;
+        const float fy = (float)y;
+        float u[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float fx = (float)(x0 + k);
+            float hx = 0.0f + m00 * fx; hx = hx + m01 * fy; hx = hx + m02 * 1.0f;
+            float hy = 0.0f + m10 * fx; hy = hy + m11 * fy; hy = hy + m12 * 1.0f;
+            float hz = 0.0f + m20 * fx; hz = hz + m21 * fy; hz = hz + m22 * 1.0f;
+            u[k] = (hx / hz - fx) * sign;
+            v[k] = (hy / hz - fy) * sign;
+        }
+        const int64_t pix = (int64_t)y * w + x0;
+        if (x0 + 4 <= w && ((pix & 3) == 0) && ((hw & 3) == 0)) {
+            *reinterpret_cast<float4*>(du + pix) = make_float4(u[0], u[1], u[2], u[3]);
+            *reinterpret_cast<float4*>(du + hw + pix) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int k = 0; k < 4 && x0 + k < w; ++k) { du[pix + k] = u[k]; du[hw + pix + k] = v[k]; }
+        }
+    }
+}
+
 __global__ void flag_words_or_kernel(const int32_t* __restrict__ words, int32_t n, int32_t* __restrict__ out) {
     int f = 0;
     for (int i = threadIdx.x; i < n; i += 64) { const int v = words[i]; out[i] = v; f |= v; }
@@ -512,6 +550,18 @@ __attribute__((visibility("default"))) int ofl_flag_words_or_i32(const int32_t* 
     if (!words || !out) return OFL_E_NULL;
     if (n < 1) return OFL_E_SHAPE;
     hipLaunchKernelGGL(flag_words_or_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, words, n, out);
+    return (int)hipGetLastError();
+}
+
+__attribute__((visibility("default"))) int ofl_flow_from_matrix_f32(const float* matrices, int64_t matrix_bs, float sign, float* dst,
+                                                                    int32_t n, int32_t h, int32_t w, void* stream) {
+    if (!matrices || !dst) return OFL_E_NULL;
+    if (n < 1 || h < 1 || w < 1 || n > 65535 || (int64_t)h * w >= (1ll << 31)) return OFL_E_SHAPE;
+    if (!(sign == 1.0f || sign == -1.0f)) return OFL_E_ARG;
+    int64_t bx = ((int64_t)h * ((w + 3) / 4) + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(flow_from_matrix_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, matrices, matrix_bs, sign,
+                       dst, h, w);
     return (int)hipGetLastError();
 }
 

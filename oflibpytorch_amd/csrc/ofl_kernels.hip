@@ -2029,10 +2029,44 @@ __global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ pt
 // ------------------------------------------------------------------------------------------------
 // NT: non-temporal loads -- a batch larger than the last-level cache streams 13 % faster past it (B=64 1080p: 5.8 -> 6.65
 // TB/s); a small one (B=8: 150 MB) is better off cached
-template <bool VEC, bool NT = false>   // VEC: 4 pixels per thread and step (16-byte flow loads, one mask dword); needs hw % 4 == 0 and aligned planes
+// HOST (ofl_flow_flags_host): the words go straight to host-visible memory.  Every block, once its waves' atomics on the
+// device words are done, releases at agent scope and takes a ticket from an arrival counter; the block that draws the last
+// ticket reads the words back with memory-side atomics (exchange with 0: the device words and the counter are left zeroed
+// for the next call), stores them to the host buffer at system scope and, behind a system-scope release, the call's serial
+// number into word 0 -- the host polls that one word: no copy launch, no event, no memset (MI355X_MICROARCH.md,
+// Workgroup dispatch ... & inter-workgroup visibility: producer release -> counter -> last arriver; the last arriver reads
+// with returning atomics, which execute at the memory side, so no acquire of possibly stale L2 lines is involved).
+struct FlagsHost { int32_t* counter; int32_t* host; int32_t serial, total_blocks, n; };
+
+__device__ __forceinline__ void flags_publish(int32_t* __restrict__ flags, const FlagsHost& fh) {
+    __shared__ int last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's atomicOr (if any) has been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int prev = __hip_atomic_fetch_add(fh.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = prev == fh.total_blocks - 1;
+    }
+    __syncthreads();
+    if (!last) return;                                            // (block-uniform)
+    for (int i = threadIdx.x; i < fh.n; i += blockDim.x) {
+        const int v = __hip_atomic_exchange(&flags[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fh.host[1 + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 // system scope: the words are on their way before the serial number
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(fh.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fh.host[0], fh.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <bool VEC, bool NT = false, bool HOST = false>   // VEC: 4 pixels per thread and step (16-byte flow loads, one mask dword); needs hw % 4 == 0 and aligned planes
 __global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict__ flow, int64_t flow_bs,
                                                          const uint8_t* __restrict__ mask, int64_t mask_bs,
-                                                         int32_t* __restrict__ flags, int64_t hw) {
+                                                         int32_t* __restrict__ flags, int64_t hw, const FlagsHost fh) {
     const int n = blockIdx.y;
     const float* fu = flow + n * flow_bs;
     const uint8_t* mk = mask ? mask + n * mask_bs : nullptr;
@@ -2066,15 +2100,17 @@ __global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict
     }
     f = wave_or_flags(f);
     if ((threadIdx.x & 63) == 0) flag_or(&flags[n], f);
+    if (HOST) flags_publish(flags, fh);
 }
 
 // fp16-stored flows (BASELINE config 5): the reference's entry conversion `vecs.float()` (utils.py:95,118) and the flag
 // reduction in ONE pass -- 4 pixels per thread and step: 8-byte fp16 loads, 16-byte fp32 stores, one mask dword.
 // Needs hw % 4 == 0 and 8 / 16-byte aligned planes (else the binding converts with torch and calls ofl_flow_flags_f32).
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+template <bool HOST = false>
 __global__ __launch_bounds__(256) void flow_f16_kernel(const _Float16* __restrict__ src, int64_t src_bs,
                                                        const uint8_t* __restrict__ mask, int64_t mask_bs,
-                                                       float* __restrict__ dst, int32_t* __restrict__ flags, int64_t hw) {
+                                                       float* __restrict__ dst, int32_t* __restrict__ flags, int64_t hw, const FlagsHost fh) {
     const int n = blockIdx.y;
     const _Float16* su = src + n * src_bs;
     float* du = dst + (int64_t)n * 2 * hw;
@@ -2105,6 +2141,7 @@ __global__ __launch_bounds__(256) void flow_f16_kernel(const _Float16* __restric
     }
     f = wave_or_flags(f);
     if ((threadIdx.x & 63) == 0) flag_or(&flags[n], f);
+    if (HOST) flags_publish(flags, fh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2199,9 +2236,12 @@ int launch_warp_lds_u8(const WarpParams& p, unsigned grid, hipStream_t st) {
 
 inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
+// `fh`: optional hand-over of the words to host-visible memory by the last block (ofl_flow_flags_host)
 void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, int64_t mask_bs, int32_t* flags, int32_t n,
-                       int64_t hw, hipStream_t st) {
+                       int64_t hw, hipStream_t st, const FlagsHost* fhp = nullptr) {
     const bool vec = (hw % 4) == 0 && aligned_to(flow, 16) && (flow_bs % 4) == 0 && (!mask || (aligned_to(mask, 4) && (mask_bs % 4) == 0));
+    FlagsHost fh = {};
+    if (fhp) fh = *fhp;
     if (vec) {
         // about 512 blocks in all: every wave ends with a look at (and maybe an atomic on) its image's shared word, and
         // few long-running blocks stream better than many short ones (B=64 1080p: 3.1 -> 5.8 TB/s; B=16: 2.5 -> 5.4)
@@ -2209,14 +2249,21 @@ void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, 
         int64_t cap = 512 / n;
         cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
         if (bx > cap) bx = cap;
-        if (9 * hw * n >= ((int64_t)256 << 20))
-            hipLaunchKernelGGL((flow_flags_kernel<true, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw);
-        else
-            hipLaunchKernelGGL((flow_flags_kernel<true, false>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw);
+        fh.total_blocks = (int32_t)(bx * n);
+        const bool nt = 9 * hw * n >= ((int64_t)256 << 20);
+        if (fhp) {
+            if (nt) hipLaunchKernelGGL((flow_flags_kernel<true, true, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+            else hipLaunchKernelGGL((flow_flags_kernel<true, false, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+        } else {
+            if (nt) hipLaunchKernelGGL((flow_flags_kernel<true, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+            else hipLaunchKernelGGL((flow_flags_kernel<true, false>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+        }
     } else {
         int64_t bx = (hw + 255) / 256;
         if (bx > 512) bx = 512;
-        hipLaunchKernelGGL(flow_flags_kernel<false>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw);
+        fh.total_blocks = (int32_t)(bx * n);
+        if (fhp) hipLaunchKernelGGL((flow_flags_kernel<false, false, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+        else hipLaunchKernelGGL((flow_flags_kernel<false>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
     }
 }
 
@@ -2261,7 +2308,7 @@ int launch_splat_gather_half(const GatherParams& gp, unsigned grid, hipStream_t 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 23; }   // 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 24; }   // 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -2778,9 +2825,51 @@ __attribute__((visibility("default"))) int ofl_flow_from_f16(const void* src_f16
     int64_t bx = (hw / 4 + 1023) / 1024, cap = 512 / n;
     cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(flow_f16_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const _Float16*>(src_f16), src_bs, mask, mask_bs, dst, flags, hw);
+    hipLaunchKernelGGL(flow_f16_kernel<false>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const _Float16*>(src_f16), src_bs, mask, mask_bs, dst, flags, hw, FlagsHost{});
     return (int)hipGetLastError();
 }
+
+// the validation read-back without a copy launch or an event (flow_class.py / utils.py:98: the constructor must know whether
+// the vectors are finite before it returns): the reduction's last block writes the words to host-visible memory itself
+__attribute__((visibility("default"))) int ofl_flow_flags_host(const void* flow, int32_t flow_is_f16, int64_t flow_bs,
+                                                               const uint8_t* mask, int64_t mask_bs, float thr,
+                                                               int32_t* work, int32_t* host_words, int32_t serial,
+                                                               int32_t n, int32_t h, int32_t w, void* stream) {
+    if (!flow || !work || !host_words) return OFL_E_NULL;
+    int rc = check_dims(n, 2, h, w, false);
+    if (rc) return rc;
+    if (n > 65535) return OFL_E_SHAPE;
+    if (thr != kZeroThr) return OFL_E_ARG;
+    const int64_t hw = (int64_t)h * w;
+    FlagsHost fh = {};
+    fh.counter = work + n; fh.host = host_words; fh.serial = serial; fh.n = n;
+    hipStream_t st = (hipStream_t)stream;
+    if (!flow_is_f16) {
+        launch_flow_flags(static_cast<const float*>(flow), flow_bs, mask, mask_bs, work, n, hw, st, &fh);
+        return (int)hipGetLastError();
+    }
+    if ((hw % 4) != 0 || !aligned_to(flow, 8) || (flow_bs % 4) != 0 || (mask && (!aligned_to(mask, 4) || (mask_bs % 4) != 0)))
+        return OFL_E_UNSUPPORTED;
+    int64_t bx = (hw / 4 + 1023) / 1024, cap = 512 / n;
+    cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
+    if (bx > cap) bx = cap;
+    fh.total_blocks = (int32_t)(bx * n);
+    hipLaunchKernelGGL(flow_f16_kernel<true>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st,
+                       static_cast<const _Float16*>(flow), flow_bs, mask, mask_bs, (float*)nullptr, work, hw, fh);
+    return (int)hipGetLastError();
+}
+
+// host-visible (pinned, coherent, device-mapped) words for ofl_flow_flags_host
+__attribute__((visibility("default"))) int ofl_host_words_alloc(int64_t ints, void** out) {
+    if (!out || ints < 1) return OFL_E_ARG;
+    void* ptr = nullptr;
+    hipError_t e = hipHostMalloc(&ptr, (size_t)ints * sizeof(int32_t), hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) return (int)e;
+    for (int64_t i = 0; i < ints; ++i) static_cast<volatile int32_t*>(ptr)[i] = 0;
+    *out = ptr;
+    return OFL_OK;
+}
+__attribute__((visibility("default"))) int ofl_host_words_free(void* ptr) { return ptr ? (int)hipHostFree(ptr) : OFL_OK; }
 
 }  // extern "C"

@@ -14,6 +14,7 @@ import torch.distributed as dist
 
 _group = None
 _enabled = False
+_force_collectives = False   # tests only: run the collectives on a communicator of ONE rank too (tests/test_gpu_validation.py)
 
 
 def enable_batch_sharding(group=None):
@@ -30,7 +31,7 @@ def disable_batch_sharding():
 
 
 def is_enabled() -> bool:
-    return _enabled and dist.is_initialized() and dist.get_world_size(_group) > 1
+    return _enabled and dist.is_initialized() and (dist.get_world_size(_group) > 1 or _force_collectives)
 
 
 def reduce_flags(local_or: int, device) -> int:
@@ -76,7 +77,7 @@ def shard_bounds(n: int, rank: int = None, world: int = None) -> tuple:
 
 def broadcast_operand(t: torch.Tensor, src: int = 0) -> torch.Tensor:
     """Distribute a shared (batch-1) image / flow operand from rank `src` to every rank."""
-    if dist.is_initialized() and dist.get_world_size(_group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(_group) > 1 or _force_collectives):
         t = t.contiguous()
         dist.broadcast(t, src=src, group=_group)
     return t
@@ -86,7 +87,7 @@ def all_gather_batch(t: torch.Tensor) -> torch.Tensor:
     """Concatenate the ranks' shards along the batch axis on every rank (not part of the compute metric).  Shards may
     be ragged (`shard_bounds` hands out a shorter, possibly empty, tail): the batch sizes are exchanged first and every
     shard travels padded to the longest."""
-    if not (dist.is_initialized() and dist.get_world_size(_group) > 1):
+    if not (dist.is_initialized() and (dist.get_world_size(_group) > 1 or _force_collectives)):
         return t
     world = dist.get_world_size(_group)
     sizes = torch.zeros(world, dtype=torch.int64, device=t.device)

@@ -21,15 +21,31 @@ import torch.nn.functional as F
 from . import _native, distributed
 from .utils import (get_valid_vecs, get_valid_ref, get_valid_mask, get_valid_device, get_valid_padding,
                     get_valid_shape, get_pure_pytorch, move_axis, from_matrix, from_transforms, resize_flow,
-                    apply_flow, _flags_to_host, _griddata_unavailable, track_pts, get_half_flow_outputs)
+                    apply_flow, _flags_to_host, _host_flags, _griddata_unavailable, track_pts, get_half_flow_outputs)
 
 FlowAlias = 'Flow'
 _VALID_THR = 0.99999   # flow_class.py:922
 
 
-def _ver(t: torch.Tensor) -> int:
-    """Version counter of a tensor, -1 for inference tensors (which have none and raise on `_version`)."""
-    return -1 if t.is_inference() else t._version
+class _NeverEqual(object):
+    """Key component that matches nothing, not even itself: a flag word cached under it is never taken as current."""
+    __slots__ = ()
+
+    def __eq__(self, other):
+        return False
+
+    def __ne__(self, other):
+        return True
+
+    __hash__ = None
+
+
+def _ver(t: torch.Tensor):
+    """Version counter of a tensor.  Inference tensors have none (reading `_version` raises) yet CAN be edited in place inside
+    `torch.inference_mode()`: nothing tells an edited one from an untouched one, so their flag words are never cached
+    across calls (a FRESH key component that compares unequal to everything -- fresh because tuple comparison short-cuts on
+    identity)."""
+    return _NeverEqual() if t.is_inference() else t._version
 
 
 class Flow(object):
@@ -133,8 +149,9 @@ class Flow(object):
 
     def _key(self) -> tuple:
         """Cache key of the flag word: tensor versions (in-place edits invalidate it).  Tensors created under
-        torch.inference_mode() carry no version counter (reading `_version` raises); they cannot be modified in place
-        outside inference mode, so their identity stands in."""
+        torch.inference_mode() carry no version counter: their key never matches, i.e. every call that needs the flags of
+        such a flow runs the (cheap, fused) reduction again -- an in-place edit inside inference mode must not meet a
+        stale 'all zero' / 'finite' word."""
         return (_ver(self._fv), None if self._mask is None else (id(self._mask), _ver(self._mask)))
 
     def _flags_known(self) -> bool:
@@ -145,11 +162,16 @@ class Flow(object):
     def _flags(self) -> list:
         key = self._key()
         if self._flag_cache is None or self._flag_cache[0] != key:
+            dev_flags = None
             if self._pending_flags is not None and self._pending_flags[0] == key:
                 dev_flags = self._pending_flags[1]
-            else:
-                dev_flags = _native.flow_flags(self._fv, self._mask)
             self._pending_flags = None
+            if dev_flags is None and not distributed.is_enabled():
+                # a tensor nobody has looked at yet (the constructor's validation): reduction + read-back in one launch
+                self._flag_cache = (key, _host_flags(self._fv, self._mask))
+                return self._flag_cache[1]
+            if dev_flags is None:
+                dev_flags = _native.flow_flags(self._fv, self._mask)
             if distributed.is_enabled():
                 # batch sharding: the OR over every rank's shard is formed on the device (one small all-reduce) and read
                 # together with the local words -- one host sync per tensor version, as without sharding
@@ -185,8 +207,19 @@ class Flow(object):
 
     @property
     def vecs(self) -> torch.Tensor:
-        """Flow vectors N-2-H-W, fp32 (flow_class.py:68-80)"""
-        return self._vecs
+        """Flow vectors N-2-H-W, fp32 (flow_class.py:68-80).  As in the reference the tensor handed out IS the flow's
+        storage: an in-place edit of it edits the flow.  A flow kept in fp16 (`_half`) therefore gives up its fp16 planes
+        the moment its fp32 tensor is handed out -- from then on there is one store, the fp32 one, and the kernels read
+        that (the flag word carries over: the up-conversion is exact; a later in-place edit bumps the tensor's version and
+        invalidates it like any other)."""
+        v = self._vecs
+        if self._half is not None:
+            flags = self._flag_cache[1:] if self._flags_known() else None
+            pending = self._pending_flags[1] if (self._pending_flags is not None and self._pending_flags[0] == self._key()) else None
+            self._half = None
+            self._flag_cache = None if flags is None else (self._key(),) + tuple(flags)
+            self._pending_flags = None if pending is None else (self._key(), pending)
+        return v
 
     @vecs.setter
     def vecs(self, input_vecs):
@@ -269,14 +302,16 @@ class Flow(object):
     def from_matrix(cls, matrix, shape, ref: str = None, mask=None, device=None, matrix_is_inverse: bool = None) -> FlowAlias:
         """flow_class.py:260-292"""
         device = get_valid_device(device) if device is not None else None
-        return cls(from_matrix(matrix, shape, ref, matrix_is_inverse), ref, mask, device)
+        on = device if (device is not None and device.type == 'cuda') else None        # generate the field where it is wanted
+        return cls(from_matrix(matrix, shape, ref, matrix_is_inverse, _device=on), ref, mask, device)
 
     @classmethod
     def from_transforms(cls, transform_list: list, shape, ref: str = None, mask=None, device=None,
                         padding: list = None) -> FlowAlias:
         """flow_class.py:294-328"""
         device = get_valid_device(device) if device is not None else None
-        return cls(from_transforms(transform_list, shape, ref, padding), ref, mask, device)
+        on = device if (device is not None and device.type == 'cuda') else None
+        return cls(from_transforms(transform_list, shape, ref, padding, _device=on), ref, mask, device)
 
     # ------------------------------------------------------------------------------------------
     # copies, indexing (flow_class.py:376-448)
@@ -426,10 +461,15 @@ class Flow(object):
     # resize / pad (flow_class.py:694-753) -- thin PyTorch wrappers, not on the kernel path
     # ------------------------------------------------------------------------------------------
     def resize(self, scale) -> FlowAlias:
+        """flow_class.py:694-714: `F.interpolate(bilinear, align_corners=False)` of the vectors (scaled along) and of the mask
+        (then rounded), by ATen on the flow's own device, as in the reference.  (On a HIP device that is ATen's GPU kernel,
+        whose last-bit rounding differs from ATen's CPU kernel: values within 1e-5 of the CPU reference, see
+        tests/test_gpu_generators.py.)  The mask goes through the reference's own `.squeeze(0).squeeze(0)`, so -- exactly like
+        the reference -- a batch of more than one flow raises the mask's shape error."""
         resized = resize_flow(self._vecs, scale)
         sc = [scale, scale] if isinstance(scale, (float, int)) else scale
         m = F.interpolate(self.mask.float().unsqueeze(1), scale_factor=sc, mode='bilinear',
-                          align_corners=False).squeeze(1)
+                          align_corners=False).squeeze(0).squeeze(0)
         return Flow(resized, self._ref, torch.round(m), device=self._device)
 
     def pad(self, padding: list = None, mode: str = None) -> FlowAlias:

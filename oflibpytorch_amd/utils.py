@@ -6,6 +6,7 @@ Same names, argument meaning, defaults and error behaviour as ``oflibpytorch.uti
 generators are plain PyTorch host code.
 """
 import math
+import threading
 from typing import Any, Union
 
 import numpy as np
@@ -66,26 +67,44 @@ def _griddata_unavailable(what: str):
 # validators (utils.py:72-232): TypeError for wrong types, ValueError for wrong shapes / values
 # ------------------------------------------------------------------------------------------------
 _readback = {}
+_readback_lock = threading.Lock()
+_POLL_SPINS = 20000       # ~ a millisecond of polling before the blocking wait (a validation reduction takes 35 - 250 us)
 
 
 def _flags_to_host(flags: torch.Tensor) -> list:
-    """The read-back every validation waits for (twice per bench step, with the GPU idle behind it): an asynchronous copy
-    into a small pinned buffer and a POLLED event instead of `flags.cpu()` -- a blocking synchronisation sleeps on an
-    interrupt, and its wake-up latency varies from a few microseconds to a few hundred with the host's power state."""
+    """Read-back of DEVICE-resident flag words (a kernel's by-product): an asynchronous copy into a small pinned buffer and a
+    POLLED event instead of `flags.cpu()` -- a blocking synchronisation sleeps on an interrupt, and its wake-up latency varies
+    from a few microseconds to a few hundred with the host's power state.  The buffer and the event are per device and
+    shared, so the whole exchange runs under a lock (two threads validating flows on one device); the spin is bounded, then
+    the event is waited for the ordinary way.  (Validation of a NEW tensor does not come through here: `_host_flags`.)"""
     if flags.device.type != 'cuda' or flags.dtype != torch.int32:
         return [int(v) for v in flags.cpu().tolist()]
     n = int(flags.numel())
-    slot = _readback.get(flags.device)
-    if slot is None or slot[0].numel() < n:
-        slot = (torch.empty(max(n, 64), dtype=torch.int32).pin_memory(), torch.cuda.Event())
-        _readback[flags.device] = slot
-    buf, done = slot
-    with torch.cuda.device(flags.device):
-        buf[:n].copy_(flags.reshape(-1), non_blocking=True)
-        done.record()
-        while not done.query():
-            pass
-    return buf[:n].tolist()
+    with _readback_lock:
+        slot = _readback.get(flags.device)
+        if slot is None or slot[0].numel() < n:
+            slot = (torch.empty(max(n, 64), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+            _readback[flags.device] = slot
+        buf, done = slot
+        with torch.cuda.device(flags.device):
+            buf[:n].copy_(flags.reshape(-1), non_blocking=True)
+            done.record()
+            for _ in range(_POLL_SPINS):
+                if done.query():
+                    break
+            else:
+                done.synchronize()
+        return buf[:n].tolist()
+
+
+def _host_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> list:
+    """Flag words of a flow tensor as host ints -- the wait every validation ends in.  One launch whose last block writes the
+    words to host-visible memory (`_native.flow_flags_host`); shapes / devices that route does not take fall back to the
+    reduction + copy + polled event."""
+    host = _native.flow_flags_host(vecs, mask)
+    if host is None:
+        host = _flags_to_host(_native.flow_flags(vecs, mask))
+    return host
 
 
 def get_valid_vecs(vecs: Any, desired_shape: Union[tuple, list] = None, error_string: str = None,
@@ -111,7 +130,7 @@ def get_valid_vecs(vecs: Any, desired_shape: Union[tuple, list] = None, error_st
         return vecs          # Flow.__init__ converts and validates in one fused pass once the mask is known
     vecs = vecs.float()
     if _check_finite:
-        finite = not any(f & _native.FLAG_NONFINITE for f in _flags_to_host(_native.flow_flags(vecs)))   # (a HIP reduction: no host path)
+        finite = not any(f & _native.FLAG_NONFINITE for f in _host_flags(vecs))   # (a HIP reduction: no host path)
         if not finite:
             raise ValueError(error_string + "Input contains NaN, Inf or -Inf values")
     if desired_shape is not None:
@@ -219,7 +238,7 @@ def to_tensor(array: np.ndarray, switch_channels: str = None, device=None) -> to
 
 
 # ------------------------------------------------------------------------------------------------
-# flow generators (utils.py:339-442, 646-807) -- O(HW) one-off setup, host PyTorch
+# flow generators (utils.py:339-442, 646-807): the 3 x 3 algebra on the host, the O(HW) field on the HIP device
 # ------------------------------------------------------------------------------------------------
 def matrix_from_transform(transform: str, values: list) -> torch.Tensor:
     """3x3 matrix of one transform (utils.py:396-424): translation [dx, dy]; rotation [cx, cy, deg ccw];
@@ -261,19 +280,28 @@ def reverse_transform_values(transform_list: list) -> list:
     return out
 
 
-def flow_from_matrix(matrix: torch.Tensor, shape: list) -> torch.Tensor:
+def flow_from_matrix(matrix: torch.Tensor, shape: list, _sign: float = 1.0, _device=None) -> torch.Tensor:
     """'s'-reference flow of a homography: M [x, y, 1]^T dehomogenised, minus [x, y] (utils.py:339-376).
-    matrix N-3-3, shape [N, H, W] -> N-2-H-W"""
+    matrix N-3-3, shape [N, H, W] -> N-2-H-W on the matrix's device.  The O(HW) field is generated by `ofl_flow_from_matrix_f32`
+    on the HIP device (bit-identical to the reference's PyTorch-CPU result; `_sign` = -1: the exact negation of the reference's
+    't' branches).  A matrix that wants a gradient takes the torch expression (the reference's flow is differentiable wrt it).
+    `_device` (internal: Flow.from_matrix / from_transforms with a HIP `device`): leave the field there instead of taking it
+    to the matrix's device and back."""
     n, h, w = shape
-    dev = matrix.device
-    gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
-    hom = torch.stack((gx.float().to(dev), gy.float().to(dev), torch.ones((h, w), device=dev)), dim=-1)   # H-W-3
-    moved = torch.matmul(matrix.float().unsqueeze(1).unsqueeze(1), hom.unsqueeze(-1)).squeeze(-1)      # N-H-W-3
-    pts = moved[..., 0:2] / moved[..., 2:3]
-    return move_axis(pts - hom[..., 0:2], -1, 1)
+    dev = matrix.device if _device is None else _device
+    if _native._wants_grad(matrix):
+        gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+        hom = torch.stack((gx.float().to(dev), gy.float().to(dev), torch.ones((h, w), device=dev)), dim=-1)   # H-W-3
+        moved = torch.matmul(matrix.float().expand(n, -1, -1).unsqueeze(1).unsqueeze(1), hom.unsqueeze(-1)).squeeze(-1)   # N-H-W-3
+        pts = moved[..., 0:2] / moved[..., 2:3]
+        out = move_axis(pts - hom[..., 0:2], -1, 1)
+        return -out if _sign < 0 else out
+    if dev.type == 'cuda' and matrix.device != dev:
+        matrix = matrix.to(dev)                              # (9 floats per matrix: the field is generated where it is wanted)
+    return _native.flow_from_matrix(matrix, n, h, w, _sign).to(dev)
 
 
-def from_matrix(matrix, shape, ref: str = None, matrix_is_inverse: bool = None) -> torch.Tensor:
+def from_matrix(matrix, shape, ref: str = None, matrix_is_inverse: bool = None, _device=None) -> torch.Tensor:
     """Flow vectors N-2-H-W from a transformation matrix (utils.py:646-705): for 's' the matrix is applied directly, for 't'
     its (pseudo-)inverse gives the backward flow (negated).  The batch size comes from the matrix (3-3 or N-3-3); the
     shape is H-W or 1-H-W.  Checks in the reference's order: shape, matrix, ref, matrix_is_inverse."""
@@ -300,45 +328,52 @@ def from_matrix(matrix, shape, ref: str = None, matrix_is_inverse: bool = None) 
     if ref == 's':
         if matrix_is_inverse:
             raise ValueError("Error creating flow from matrix: Matrix_is_inverse cannot be True when ref is 's'")
-        return flow_from_matrix(matrix, list(dims))
+        return flow_from_matrix(matrix, list(dims), _device=_device)
     if not matrix_is_inverse:
         matrix = torch.pinverse(matrix)
-    return -flow_from_matrix(matrix, list(dims))
+    return flow_from_matrix(matrix, list(dims), _sign=-1.0, _device=_device)
 
 
-def from_transforms(transform_list: list, shape, ref: str = None, padding: list = None) -> torch.Tensor:
-    """Flow vectors N-2-H-W from a list of transforms (utils.py:729-807): 's' uses the forward matrix, 't' the
-    matrix of the reversed transforms (no numerical inverse), negated.  `padding` [top, bot, left, right] grows
-    the field and shifts rotation / scaling centres with it."""
+def from_transforms(transform_list: list, shape, ref: str = None, padding: list = None, _device=None) -> torch.Tensor:
+    """Flow vectors 1-2-H-W from a list of transforms (utils.py:707-807), checks in the reference's order and with its messages:
+    's' uses the matrix of the transforms, 't' the matrix of the reversed transforms in reverse order (no numerical inverse),
+    both through `from_matrix` -- so `shape` is H-W (or 1-H-W; without padding).  `padding` [top, bot, left, right] grows the
+    field and shifts rotation / scaling centres along (the reference computes the padded shape from shape[0], shape[1]:
+    it, and so this, means H-W there).  Unlike the reference, the caller's transform lists are not shifted in place."""
     ref = get_valid_ref(ref)
     if padding is not None:
-        padding = get_valid_padding(padding, "Error creating flow from transforms: ")
-        dims = get_valid_shape(shape)
-        shape = dims[:-2] + (dims[-2] + padding[0] + padding[1], dims[-1] + padding[2] + padding[3])
-        if isinstance(transform_list, list):
-            transform_list = [list(t) if isinstance(t, list) else t for t in transform_list]
-            for t in transform_list:
-                if isinstance(t, list) and len(t) == 4 and t[0] in ('rotation', 'scaling'):
-                    t[1] += padding[2]
-                    t[2] += padding[0]
+        padding = get_valid_padding(padding, "Error padding flow: ")
+        shape = [shape[0] + sum(padding[0:2]), shape[1] + sum(padding[2:4])]
     if not isinstance(transform_list, list):
         raise TypeError("Error creating flow from transforms: Transform_list needs to be a list")
+    if not all(isinstance(item, list) for item in transform_list):
+        raise TypeError("Error creating flow from transforms: Transform_list needs to be a list of lists")
+    if not all(len(item) > 1 for item in transform_list):
+        raise ValueError("Error creating flow from transforms: Invalid transforms passed")
+    transforms = []
     for t in transform_list:
-        if not isinstance(t, list):
-            raise TypeError("Error creating flow from transforms: Transform_list needs to be a list of lists")
-        if len(t) < 1 or t[0] not in ('translation', 'rotation', 'scaling'):
-            raise ValueError("Error creating flow from transforms: Transform needs to be 'translation', 'rotation' "
-                             "or 'scaling'")
-        if len(t) != (3 if t[0] == 'translation' else 4):
-            raise ValueError("Error creating flow from transforms: Wrong number of values for " + t[0])
-        if not all(isinstance(v, (int, float)) for v in t[1:]):
-            raise ValueError("Error creating flow from transforms: Transform values need to be numbers")
-    dims = get_valid_shape(shape)
+        t = list(t)
+        if t[0] == 'translation':
+            if not len(t) == 3:
+                raise ValueError("Error creating flow from transforms: Not enough transform values passed for "
+                                 "'translation' - expected 2, got {}".format(len(t) - 1))
+        elif t[0] in ('rotation', 'scaling'):
+            if not len(t) == 4:
+                raise ValueError("Error creating flow from transforms: Not enough transform values passed for "
+                                 "'{}' - expected 3, got {}".format(t[0], len(t) - 1))
+            if padding is not None:
+                t[1] += padding[2]
+                t[2] += padding[0]
+        else:
+            raise ValueError("Error creating flow from transforms: Transform '{}' not recognised".format(t[0]))
+        if not all(isinstance(item, (float, int)) for item in t[1:]):
+            raise ValueError("Error creating flow from transforms: "
+                             "Transform values for '{}' need to be integers or floats".format(t[0]))
+        transforms.append(t)
     if ref == 's':
-        m = matrix_from_transforms(transform_list)
-        return flow_from_matrix(m.unsqueeze(0).expand(dims[0], -1, -1), list(dims))
-    m = matrix_from_transforms(list(reversed(reverse_transform_values(transform_list))))
-    return -flow_from_matrix(m.unsqueeze(0).expand(dims[0], -1, -1), list(dims))
+        return from_matrix(matrix_from_transforms(transforms), shape, ref, matrix_is_inverse=False, _device=_device)
+    matrix = matrix_from_transforms(list(reversed(reverse_transform_values(transforms))))
+    return from_matrix(matrix, shape, ref, matrix_is_inverse=True, _device=_device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -367,7 +402,7 @@ def apply_flow(flow, target: torch.Tensor, ref: str, mask=None) -> torch.Tensor:
     zero-flow occlusion rule.  Returns a tensor of the target's shape and dtype on the flow's device."""
     ref = get_valid_ref(ref)
     flow = get_valid_vecs(flow, error_string="Error applying flow to a target: ", _check_finite=False)
-    flags = _flags_to_host(_native.flow_flags(flow))
+    flags = _host_flags(flow)
     if any(f & _native.FLAG_NONFINITE for f in flags):                          # utils.py:98
         raise ValueError("Error applying flow to a target: Input contains NaN, Inf or -Inf values")
     if not any(f & _native.FLAG_NZ_THR for f in flags):                         # utils.py:497-498
@@ -442,8 +477,7 @@ def is_zero_flow(flow, thresholded: bool = None) -> torch.Tensor:
     thresholded = True if thresholded is None else thresholded
     if not isinstance(thresholded, bool):
         raise TypeError("Error checking whether flow is zero: Thresholded needs to be a boolean")
-    flags = _native.flow_flags(flow)
-    host = _flags_to_host(flags)
+    host = _host_flags(flow)
     if any(f & _native.FLAG_NONFINITE for f in host):
         raise ValueError("Error checking whether flow is zero: Input contains NaN, Inf or -Inf values")
     bit = _native.FLAG_NZ_THR if thresholded else _native.FLAG_NZ
@@ -457,7 +491,7 @@ def track_pts(flow, ref: str, pts: torch.Tensor, int_out: bool = None) -> torch.
     't' (PURE_PYTORCH): the flow is first splatted to its own start points -- `grid_from_unstructured_data` at
     `get_flow_endpoints(-flow, 's')`, :993-996 -- one forward-splat launch with the end points formed in-kernel."""
     flow = get_valid_vecs(flow, error_string="Error tracking points: ", _check_finite=False)
-    flags = _flags_to_host(_native.flow_flags(flow))
+    flags = _host_flags(flow)
     if any(f & _native.FLAG_NONFINITE for f in flags):                          # utils.py:98
         raise ValueError("Error tracking points: Input contains NaN, Inf or -Inf values")
     ref = get_valid_ref(ref)

@@ -58,6 +58,8 @@ def lib():
         L.orc_flow_flags_f32.argtypes = [fp, u8, ctypes.c_float, ctypes.POINTER(i32), i32, i32, i32]
         L.orc_sample_pts_f32.argtypes = [fp, i64, fp, i64, fp, i32, i32, i32, i32]
         L.orc_sample_pts_f32.restype = None
+        L.orc_flow_from_matrix_f32.argtypes = [fp, i64, ctypes.c_float, fp, i32, i32, i32]
+        L.orc_flow_from_matrix_f32.restype = None
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
         for name in ("orc_warp_bwd_f32", "orc_normalise_coords_f32", "orc_flow_endpoints_f32",
@@ -219,6 +221,15 @@ def flow_extents(flow, mask, sign):
         mk = np.ones((h, w), bool) if mask is None else np.asarray(mask[b], bool)
         if mk.any():
             out[b] = [py[b][mk].min(), py[b][mk].max(), px[b][mk].min(), px[b][mk].max(), 1.0]
+    return out
+
+
+def flow_from_matrix(matrix, n, h, w, sign=1.0):
+    """utils.py:339-376 (flow_from_matrix); sign = -1: the negated result of the 't' branches (utils.py:699-705, 804-807).
+    matrix [n|1, 3, 3] -> [n, 2, h, w]."""
+    m = _f32(np.asarray(matrix, np.float32).reshape(-1, 9))
+    out = np.empty((n, 2, h, w), np.float32)
+    lib().orc_flow_from_matrix_f32(_fp(m), 0 if m.shape[0] == 1 else 9, float(sign), _fp(out), n, h, w)
     return out
 
 

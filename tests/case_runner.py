@@ -115,6 +115,41 @@ def run_case(case, golden, device):
         v = T(i["flow_raw"], d)
         arg = {'nchw': v, 'chw': v[0], 'hwc_np': v[1].permute(1, 2, 0).cpu().numpy()}[a["layout"]]
         return {"_padding": ofl.get_flow_padding(arg, a["ref"])}
+    if op in ('from_matrix', 'Flow.from_matrix'):
+        mat = i["matrix"] if a.get("numpy") else T(i["matrix"], d)
+        if op == 'from_matrix':
+            return {"out": ofl.from_matrix(mat, a["shape"], a["ref"], a["matrix_is_inverse"])}
+        fl = Flow.from_matrix(mat, tuple(a["shape"]), a["ref"], T(i["m"], d), matrix_is_inverse=a["matrix_is_inverse"])
+        return {"vecs": fl.vecs, "mask": fl.mask}
+    if op in ('from_transforms', 'Flow.from_transforms'):
+        tl = [list(t) for t in a["transforms"]]
+        if op == 'from_transforms':
+            out = ofl.from_transforms(tl, a["shape"], a["ref"], a["padding"])
+            return {"out": out.to(d) if d.type == 'cuda' else out, "_device": str(out.device)}
+        fl = Flow.from_transforms(tl, tuple(a["shape"]), a["ref"], T(i["m"], d), device=d if d.type == 'cuda' else None, padding=a["padding"])
+        return {"vecs": fl.vecs, "mask": fl.mask}
+    if op == 'resize_flow':
+        f = T(i["flow"], d)
+        arg = f[0] if a.get("squeeze") else (f[1].permute(1, 2, 0).contiguous().cpu().numpy() if a.get("hwc_np") else f)
+        sc = tuple(a["scale"]) if a.get("tuple") else a["scale"]
+        return {"out": ofl.resize_flow(arg, sc)}
+    if op in ('Flow.resize', 'Flow.pad', 'Flow.unpad', 'Flow.pad_unpad'):
+        fl = _flow(i, "f", "m", a["ref"], d)
+        if op == 'Flow.resize':
+            if a.get("raises"):
+                try:
+                    fl.resize(a["scale"])
+                except (ValueError, TypeError) as exc:
+                    return {"_raised": type(exc).__name__}
+                return {"_raised": None}
+            out = fl.resize(a["scale"])
+        elif op == 'Flow.pad':
+            out = fl.pad(a["padding"], a["mode"])
+        elif op == 'Flow.unpad':
+            out = fl.unpad(a["padding"])
+        else:
+            out = fl.pad(a["padding"]).unpad(a["padding"])
+        return {"vecs": out.vecs, "mask": out.mask, "_ref": out.ref}
     if op.startswith('grad_'):
         return run_grad_case(case, golden, device)
     if op == 'kat_gfud':
@@ -213,6 +248,9 @@ def check_case(case, golden, got, exact_values=True, rtol=0.0, atol=0.0, max_mas
         _cmp(codec.subsample(vec, 4), exp["sub4"], exact_values, rtol, atol, "vec")
         s = float(vec.astype(np.float64).sum())
         assert abs(s - a["sum"]) <= 1e-6 * max(a["abs_sum"], 1.0), (s, a["sum"])
+        return report
+    if "raises" in a and a["raises"]:
+        assert got["_raised"] == a["raises"], (got["_raised"], a["raises"])
         return report
     if op in ('Flow.get_padding', 'get_flow_padding'):
         assert got["_padding"] == a["padding"], (got["_padding"], a["padding"])

@@ -718,21 +718,109 @@ def gen_grads():
             {"g_flow": fv.grad, "g_pts": pv.grad, "out": out.detach()})
 
 
+# ------------------------------------------------------------------------------------------------
+# group: gen  (the callers either side of the path: from_matrix / from_transforms utils.py:646-807,
+#   resize_flow :878-916, Flow.from_matrix / from_transforms / resize / pad / unpad flow_class.py:238-328, 694-753)
+# ------------------------------------------------------------------------------------------------
+def gen_generators():
+    g = 'gen'
+    h, w = 30, 44
+    rot = ofu.matrix_from_transforms([['rotation', 12, 9, -25], ['scaling', 20, 14, 1.3]])
+    persp = rot.clone()
+    persp[2, 0], persp[2, 1] = 4e-4, -7e-4                       # a true homography: the divide matters
+    batch = torch.stack([rot, persp, torch.eye(3)])
+    for name, mat, ref, inv in (('rot_s', rot, 's', None), ('rot_t', rot, 't', None), ('persp_s', persp, 's', None),
+                                ('persp_t', persp, 't', False), ('persp_t_isinv', persp, 't', True),
+                                ('batch_s', batch, 's', None), ('batch_t', batch, 't', None)):
+        out = ofu.from_matrix(mat, [h, w], ref, inv)
+        rec(g, 'from_matrix_' + name, 'from_matrix', {"shape": [h, w], "ref": ref, "matrix_is_inverse": inv}, {"matrix": mat},
+            {"out": out})
+    out = ofu.from_matrix(persp.numpy(), (1, h, w), 't')            # numpy matrix, 1-H-W shape
+    rec(g, 'from_matrix_numpy_1hw', 'from_matrix', {"shape": [1, h, w], "ref": 't', "matrix_is_inverse": None, "numpy": True},
+        {"matrix": persp}, {"out": out})
+    big = ofu.from_matrix(persp, [150, 260], 's')                    # coordinates beyond 2^7: more mantissa bits in play
+    rec(g, 'from_matrix_persp_150x260', 'from_matrix', {"shape": [150, 260], "ref": 's', "matrix_is_inverse": None},
+        {"matrix": persp}, {"out": big})
+    tlists = {'rot': [['rotation', 10, 20, -30]], 'tr': [['translation', 10, -20]], 'sc': [['scaling', 5, 7, 0.7]],
+              'chain': [['translation', -3, 4.5], ['rotation', 20, 10, 33], ['scaling', 15, 12, 1.25]]}
+    for name, tl in tlists.items():
+        for ref in 'st':
+            out = ofu.from_transforms([list(t) for t in tl], [h, w], ref)
+            rec(g, 'from_transforms_%s_%s' % (name, ref), 'from_transforms', {"transforms": tl, "shape": [h, w], "ref": ref, "padding": None},
+                {}, {"out": out})
+    for ref in 'st':
+        out = ofu.from_transforms([list(t) for t in tlists['chain']], [2, h, w], ref, padding=[3, 5, 4, 2])
+        rec(g, 'from_transforms_chain_padded_batched_' + ref, 'from_transforms',
+            {"transforms": tlists['chain'], "shape": [2, h, w], "ref": ref, "padding": [3, 5, 4, 2]}, {}, {"out": out})
+    mk = hole_mask(1, h, w, 51)
+    fl = Flow.from_matrix(persp, (h, w), 't', mk)
+    rec(g, 'Flow_from_matrix_t_mask', 'Flow.from_matrix', {"shape": [h, w], "ref": 't', "matrix_is_inverse": None},
+        {"matrix": persp, "m": mk}, {"vecs": fl.vecs, "mask": fl.mask})
+    fl = Flow.from_transforms([list(t) for t in tlists['chain']], (h, w), 's', mk, padding=None)
+    rec(g, 'Flow_from_transforms_s_mask', 'Flow.from_transforms', {"transforms": tlists['chain'], "shape": [h, w], "ref": 's', "padding": None},
+        {"m": mk}, {"vecs": fl.vecs, "mask": fl.mask})
+    pm = hole_mask(1, h + 8, w + 6, 52)
+    fl = Flow.from_transforms([list(t) for t in tlists['rot']], (h, w), 't', pm, padding=[3, 5, 4, 2])
+    rec(g, 'Flow_from_transforms_t_padded', 'Flow.from_transforms', {"transforms": tlists['rot'], "shape": [h, w], "ref": 't', "padding": [3, 5, 4, 2]},
+        {"m": pm}, {"vecs": fl.vecs, "mask": fl.mask})
+    # resize_flow / Flow.resize (F.interpolate bilinear, align_corners=False; vectors scaled along)
+    f = smooth_flow(2, h, w, 4.0, 501)
+    for name, sc in (('half', 0.5), ('x2', 2), ('aniso', [1.5, 0.7]), ('tuple', (0.8, 1.25))):
+        out = ofu.resize_flow(f, sc)
+        rec(g, 'resize_flow_' + name, 'resize_flow', {"scale": list(sc) if isinstance(sc, (list, tuple)) else sc, "tuple": isinstance(sc, tuple)},
+            {"flow": f}, {"out": out})
+    out = ofu.resize_flow(f[0], 1.5)
+    rec(g, 'resize_flow_3d', 'resize_flow', {"scale": 1.5, "squeeze": True}, {"flow": f}, {"out": out})
+    out = ofu.resize_flow(f[1].permute(1, 2, 0).contiguous().numpy(), [0.6, 1.4])
+    rec(g, 'resize_flow_hw2_numpy', 'resize_flow', {"scale": [0.6, 1.4], "hwc_np": True}, {"flow": f}, {"out": out})
+    m = hole_mask(1, h, w, 53)
+    for ref in 'st':
+        for name, sc in (('half', 0.5), ('aniso', [1.5, 0.7])):
+            out = Flow(f[:1], ref, m).resize(sc)
+            rec(g, 'Flow_resize_%s_%s' % (name, ref), 'Flow.resize', {"ref": ref, "scale": sc}, {"f": f[:1], "m": m},
+                {"vecs": out.vecs, "mask": out.mask})
+    try:                                                          # a batch: the reference's mask `.squeeze(0).squeeze(0)` leaves 4 dimensions
+        Flow(f, 's', hole_mask(2, h, w, 54)).resize(0.5)
+        raised = None
+    except (ValueError, TypeError) as exc:
+        raised = type(exc).__name__
+    rec(g, 'Flow_resize_batched', 'Flow.resize', {"ref": 's', "scale": 0.5, "raises": raised}, {"f": f, "m": hole_mask(2, h, w, 54)}, {})
+    # Flow.pad / unpad
+    m2 = hole_mask(2, h, w, 55)
+    for ref in 'st':
+        for mode in (None, 'constant', 'reflect', 'replicate'):
+            out = Flow(f, ref, m2).pad([3, 5, 4, 2], mode)
+            rec(g, 'Flow_pad_%s_%s' % (mode, ref), 'Flow.pad', {"ref": ref, "padding": [3, 5, 4, 2], "mode": mode}, {"f": f, "m": m2},
+                {"vecs": out.vecs, "mask": out.mask})
+        out = Flow(f, ref, m2).unpad([3, 5, 4, 2])
+        rec(g, 'Flow_unpad_' + ref, 'Flow.unpad', {"ref": ref, "padding": [3, 5, 4, 2]}, {"f": f, "m": m2}, {"vecs": out.vecs, "mask": out.mask})
+    out = Flow(f, 't', m2).pad([2, 0, 0, 7]).unpad([2, 0, 0, 7])
+    rec(g, 'Flow_pad_unpad_roundtrip', 'Flow.pad_unpad', {"ref": 't', "padding": [2, 0, 0, 7]}, {"f": f, "m": m2},
+        {"vecs": out.vecs, "mask": out.mask})
+
+
 def main():
+    """`gen_golden.py` regenerates everything; `gen_golden.py --groups gen ...` only the named groups (the other groups' npz
+    files and manifest entries stay as they are, byte for byte)."""
     of.set_pure_pytorch()
-    gen_prims()
-    gen_flow_apply()
-    gen_flow_ops()
-    gen_kats()
-    gen_next()
-    gen_grads()
+    gens = {'prims': gen_prims, 'flow_apply': gen_flow_apply, 'flow_ops': gen_flow_ops, 'kats': gen_kats, 'next': gen_next,
+            'grads': gen_grads, 'gen': gen_generators}
+    only = sys.argv[sys.argv.index('--groups') + 1:] if '--groups' in sys.argv else list(gens)
+    for name in only:
+        gens[name]()
     for grp, store in GROUPS.items():
         path = os.path.join(HERE, grp + '.npz')
         np.savez_compressed(path, **store)
         print(grp, len(store), 'arrays', os.path.getsize(path) // 1024, 'KiB')
-    with open(os.path.join(HERE, 'manifest.json'), 'w') as fh:
-        json.dump({"reference": "oflibpytorch 2.1.1", "torch": torch.__version__, "cases": MANIFEST}, fh, indent=1)
-    print(len(MANIFEST), 'cases')
+    mpath = os.path.join(HERE, 'manifest.json')
+    cases = MANIFEST
+    if set(only) != set(gens) and os.path.exists(mpath):
+        with open(mpath) as fh:
+            old = json.load(fh)["cases"]
+        cases = [c for c in old if c["group"] not in GROUPS] + MANIFEST
+    with open(mpath, 'w') as fh:
+        json.dump({"reference": "oflibpytorch 2.1.1", "torch": torch.__version__, "cases": cases}, fh, indent=1)
+    print(len(cases), 'cases')
 
 
 if __name__ == '__main__':

@@ -46,6 +46,10 @@ def _no_grad(*tensors):
         raise NotImplementedError("oracle-backed primitives (CPU test tier) are forward-only")
 
 
+def flow_from_matrix(matrix, n, h, w, sign=1.0):
+    return torch.tensor(oracle.flow_from_matrix(_np(matrix, np.float32), n, h, w, sign))
+
+
 def flow_flags(vecs, mask=None):
     m = None if mask is None else _np(mask)
     return torch.tensor(oracle.flow_flags(_np(vecs, np.float32), m), dtype=torch.int32)

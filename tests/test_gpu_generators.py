@@ -1,0 +1,76 @@
+"""GPU tier, SURVEY.md 8(f) rank 4 -- the callers either side of the path: `from_matrix` / `from_transforms` (utils.py:646-807),
+`resize_flow` (:878-916), `Flow.from_matrix` / `from_transforms` / `resize` / `pad` / `unpad` (flow_class.py:238-328, 694-753) on the
+HIP device against the fixtures the imported reference produced (tests/golden/gen.npz, group `gen`).
+
+Bars:
+  * generated fields (`ofl_flow_from_matrix_f32`), pad, unpad: BIT-EXACT (the kernel restates the accumulation order of ATen's CPU
+    batched matmul; pad / unpad move values);
+  * resize: the reference calls `F.interpolate` on the flow's device (utils.py:912) -- on a HIP device that is ATen's GPU kernel,
+    whose interpolation weights round differently from ATen's CPU kernel in the last bits: |got - expected| <= 1e-5 * max|expected|
+    (fp32 tolerance, stated here); the resized MASK (a rounded interpolation of 0 / 1 values) bit for bit.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_ids
+import case_runner
+
+pytestmark = pytest.mark.gpu
+
+GEN = golden_ids(group='gen')
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu tier needs a HIP device"
+    from oflibpytorch_amd import _native
+    _native.load_library()
+    return torch.device('cuda', 0)
+
+
+@pytest.mark.parametrize("cid", GEN)
+def test_generator_case_gpu(cid, golden, dev):
+    case = golden.cases[cid]
+    got = case_runner.run_case(case, golden, dev)
+    if case["op"] in ('resize_flow', 'Flow.resize') and not case["args"].get("raises"):
+        _, exp = golden.arrays(case)
+        scale = max([float(np.abs(v).max()) for v in exp.values() if v.dtype.kind == 'f' and v.size] + [1.0])
+        case_runner.check_case(case, golden, got, exact_values=False, rtol=0.0, atol=1e-5 * scale, max_mask_flips=0)
+    else:
+        case_runner.check_case(case, golden, got, exact_values=True)
+    for k, v in got.items():                                   # results live where the reference would put them
+        if isinstance(v, torch.Tensor) and k in ("vecs", "mask"):
+            assert v.device.type == 'cuda'
+
+
+def test_from_matrix_full_size_against_the_oracle(dev):
+    """1080p and 4K homographies, both references, a batch of matrices: bit for bit the oracle's restatement (pinned by the
+    fixtures above) -- and generated on the device the Flow is wanted on."""
+    import oflibpytorch_amd as ofl
+    from oracle import oracle
+    m = ofl.utils.matrix_from_transforms([['rotation', 960, 540, -30], ['scaling', 400, 300, 0.9]])
+    p = m.clone()
+    p[2, 0], p[2, 1] = 1.5e-5, -2e-5
+    for (h, w) in ((1080, 1920), (2160, 3840), (37, 1001)):
+        for ref in 'st':
+            got = ofl.from_matrix(p.to(dev), (h, w), ref, matrix_is_inverse=True if ref == 't' else None)
+            assert got.device.type == 'cuda'
+            exp = oracle.flow_from_matrix(p.numpy()[None], 1, h, w, 1.0 if ref == 's' else -1.0)
+            assert np.array_equal(got.cpu().numpy(), exp)
+    mats = torch.stack([m, p, torch.eye(3)])
+    got = ofl.from_matrix(mats.to(dev), (300, 400), 's')
+    assert np.array_equal(got.cpu().numpy(), oracle.flow_from_matrix(mats.numpy(), 3, 300, 400))
+    fl = ofl.Flow.from_transforms([['rotation', 200, 150, -30]], (300, 400), 't', device=dev)
+    assert fl.vecs.device.type == 'cuda'
+    fc = ofl.from_transforms([['rotation', 200, 150, -30]], (300, 400), 't')          # CPU matrix in -> CPU tensor out, same values
+    assert fc.device.type == 'cpu' and torch.equal(fc, fl.vecs.cpu())
+
+
+def test_from_matrix_keeps_the_graph_of_a_matrix_that_wants_a_gradient(dev):
+    import oflibpytorch_amd as ofl
+    m = torch.eye(3, device=dev).clone().requires_grad_()
+    out = ofl.from_matrix(m, (20, 30), 's')
+    assert out.grad_fn is not None
+    out.sum().backward()
+    assert m.grad is not None and bool(torch.isfinite(m.grad).all())

@@ -17,7 +17,7 @@ import case_runner
 
 pytestmark = pytest.mark.gpu
 
-ALL = [c for c in golden_ids() if not c.endswith("cfg1_inputs")]
+ALL = [c for c in golden_ids() if not c.endswith("cfg1_inputs") and not c.startswith("gen.")]   # (group gen: tests/test_gpu_generators.py)
 
 
 def uses_splat(case):
