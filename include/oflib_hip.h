@@ -297,12 +297,15 @@ int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
  * memset, the kernel, a copy and an event).
  *   flow        [*,2,H,W] fp32, or fp16 when flow_is_f16 (then H*W % 4 == 0 and 8 / 4-byte aligned planes, else
  *               OFL_E_UNSUPPORTED);
- *   work        DEVICE int32[n + 1], all zero before the first call; the kernel leaves it all zero again (words + arrival
- *               counter: one buffer can serve every later call on the same stream, ONE call in flight at a time);
- *   host_words  HOST-VISIBLE int32[n + 1] (hipHostMalloc, coherent + mapped: ofl_host_words_alloc): the block that finishes last
- *               stores the n flag words to host_words[1 .. n] and then, behind a system-scope release, `serial` to
- *               host_words[0].  The caller polls host_words[0] == serial (a value it has not used before) and reads the words.
+ *   work        DEVICE int32[n + OFL_FLAGS_HOST_WORK_EXTRA], all zero before the first call; the kernel leaves it all zero again
+ *               (flag words + arrival counters: one buffer can serve every later call on the same stream, ONE call in flight
+ *               at a time);
+ *   host_words  HOST-VISIBLE int32[2 * n], 8-byte aligned (hipHostMalloc, coherent + mapped: ofl_host_words_alloc): the block
+ *               that finishes last stores, for every batch element i, the pair {host_words[2 i] = serial, host_words[2 i + 1] =
+ *               flag word} with ONE 8-byte store.  The caller polls until every host_words[2 i] == serial (a value it has not
+ *               used before) and reads the words beside them.
  */
+#define OFL_FLAGS_HOST_WORK_EXTRA 33
 int ofl_flow_flags_host(const void* flow, int32_t flow_is_f16, int64_t flow_bs,
                         const uint8_t* mask, int64_t mask_bs, float thr,
                         int32_t* work, int32_t* host_words, int32_t serial,

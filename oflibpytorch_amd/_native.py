@@ -18,7 +18,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 24              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 25              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -213,64 +213,82 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
     return flags
 
 
-# -- validation read-back: the reduction's last block writes the words to host-visible memory, the host polls one word --------
+# -- validation read-back: the reduction's last block writes the words to host-visible memory, the host polls them ---------------
 _HOST_WORDS = 1 << 12        # flag words one call can hand over (larger batches take the copy + event route)
-_host_slots = {}             # device -> [lock, device work words, host address, numpy view of the host words, last serial]
+_WORK_EXTRA = 33             # OFL_FLAGS_HOST_WORK_EXTRA
+_host_slots = {}             # device index -> [lock, device work words, host address, int32 view of the host {serial, word} pairs, last serial]
 _host_slots_lock = threading.Lock()
 HOST_POLL_SECONDS = 20.0     # a reduction that has not reported after this long is a failed launch, not a slow one
 
 
 def _host_slot(lib, dev):
     with _host_slots_lock:
-        slot = _host_slots.get(dev)
+        slot = _host_slots.get(dev.index)
         if slot is None:
             addr = ctypes.c_void_p()
-            _check(lib.ofl_host_words_alloc(_HOST_WORDS + 1, ctypes.byref(addr)), "ofl_host_words_alloc")
-            view = np.ctypeslib.as_array((ctypes.c_int32 * (_HOST_WORDS + 1)).from_address(addr.value))
-            slot = [threading.Lock(), torch.zeros(_HOST_WORDS + 1, dtype=torch.int32, device=dev), addr, view, 0]
-            _host_slots[dev] = slot
+            with torch.cuda.device(dev):
+                _check(lib.ofl_host_words_alloc(2 * _HOST_WORDS, ctypes.byref(addr)), "ofl_host_words_alloc")
+                work = torch.zeros(_HOST_WORDS + _WORK_EXTRA, dtype=torch.int32, device=dev)
+            view = np.ctypeslib.as_array((ctypes.c_int32 * (2 * _HOST_WORDS)).from_address(addr.value))
+            slot = [threading.Lock(), work, addr, view, 0]
+            _host_slots[dev.index] = slot
     return slot
 
 
 def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):
     """Flag word per batch element as a list of host ints: `flow_flags` and its read-back in ONE launch
-    (ofl_flow_flags_host: no memset, no copy, no event; the host polls the word the kernel's last block writes).
-    None when this call cannot take that route (CPU-resident or fp64 vectors, more than 4096 batch elements, an fp16 layout
-    the vector kernel does not take): the caller then uses `flow_flags` + a copy."""
+    (ofl_flow_flags_host: no memset, no copy, no event; the host polls the {serial, word} pairs the kernel's last block
+    writes).  None when this call cannot take that route (CPU-resident or fp64 vectors, more than 4096 batch elements, an
+    fp16 layout the vector kernel does not take): the caller then uses `flow_flags` + a copy.
+    This is the wait every `Flow(...)` ends in, so the common case (contiguous operands already on the device) skips the
+    general staging code."""
     if vecs.device.type != 'cuda' or vecs.dtype not in (torch.float32, torch.float16):
         return None
     n, _, h, w = vecs.shape
     if n > _HOST_WORDS:
         return None
-    lib, dev = load_library(), device(vecs, mask)
+    lib, dev = load_library(), vecs.device
     half = vecs.dtype == torch.float16
-    with _on(dev):
-        v, vbs = _planes(vecs.detach(), dev, vecs.dtype, n, "flow")
-        if half and vbs == 0 and n != 1:
-            return None
-        m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
-        slot = _host_slot(lib, dev)
+    switch = torch.cuda.current_device() != dev.index
+    ctx = torch.cuda.device(dev) if switch else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        if vecs.is_contiguous() and (mask is None or (mask.dtype == torch.bool and mask.device == dev and mask.shape[0] == n
+                                                      and mask.is_contiguous())):
+            v, vbs, m, mbs = vecs, 2 * h * w, mask, h * w
+        else:
+            v, vbs = _planes(vecs.detach(), dev, vecs.dtype, n, "flow")
+            if half and vbs == 0 and n != 1:
+                return None
+            m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+        slot = _host_slots.get(dev.index) or _host_slot(lib, dev)
+        stream = torch._C._cuda_getCurrentRawStream(dev.index)
         with slot[0]:                      # one call in flight per device: the work words and the host words are shared
             serial = slot[4] = (slot[4] % 0x7ffffff0) + 1
-            work, view = slot[1], slot[3]
-            rc = lib.ofl_flow_flags_host(_ptr(v), 1 if half else 0, vbs, _ptr(m), mbs, THRESHOLD, _ptr(work), slot[2], serial,
-                                         n, h, w, _stream(dev))
+            view = slot[3]
+            rc = lib.ofl_flow_flags_host(v.data_ptr(), 1 if half else 0, vbs, 0 if m is None else m.data_ptr(), mbs, THRESHOLD,
+                                         slot[1].data_ptr(), slot[2], serial, n, h, w, stream)
             if rc == -4:
                 return None
             _check(rc, "ofl_flow_flags_host")
+            tags = view[0:2 * n:2]
             spins, t0 = 0, None
-            while view[0] != serial:       # the GPU is busy with the reduction itself for most of this wait
-                spins += 1
+            while not (view[2 * n - 2] == serial and (n == 1 or bool((tags == serial).all()))):
+                spins += 1                 # (the GPU is busy with the reduction itself for most of this wait)
                 if spins & 0xfff == 0:
                     if t0 is None:
                         t0 = time.perf_counter()
                     elif time.perf_counter() - t0 > HOST_POLL_SECONDS:
                         torch.cuda.synchronize(dev)          # surfaces a launch failure as the runtime's own error
-                        if view[0] == serial:
+                        if bool((tags == serial).all()):
                             break
-                        _host_slots.pop(dev, None)           # (the work words may be dirty: start afresh next time)
+                        _host_slots.pop(dev.index, None)     # (the work words may be dirty: start afresh next time)
                         raise RuntimeError("oflibpytorch_amd: the flag reduction did not report back")
-            return view[1:1 + n].tolist()
+            return view[1:2 * n:2].tolist()
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
 
 
 def flow_from_half(vecs16: torch.Tensor, mask: torch.Tensor = None):

@@ -1368,6 +1368,9 @@ __device__ __forceinline__ void sp_corners(float xv, float yv, float wmax, float
     ix[0] = (int)x0s - dx0; ix[1] = (int)x1s - dx0; iy[0] = (int)y0s - dy0; iy[1] = (int)y1s - dy0;
 }
 
+#ifndef OFL_SP_FASTDIV
+#define OFL_SP_FASTDIV 1   // sp_finalize: the division's core sequence without range scaling / fix-up for in-range operands (same bits)
+#endif
 #ifndef OFL_SP_MINB
 #define OFL_SP_MINB 4   // blocks per CU the gather kernel's register budget is sized for (what its 39.7 KB of LDS allow)
 #endif
@@ -1484,17 +1487,71 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
     const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
     f2 den2, out[NC], mch2;
     uint32_t warped2 = 0, valid2 = 0;
+    // The 2 * (NC + MCH) quotients of a thread share two denominators, and their operands sit in the middle of the exponent range:
+    // the denominator is a density clamped to >= 1e-3 and at most the number of pixels of a frame (< 2^24).  There the
+    // correctly rounded division the compiler emits (v_div_scale x 2, v_rcp, 4 fma, mul, v_div_fmas, v_div_fixup: 11 VALU)
+    // reduces to its core -- y = rcp refined once, q = a y, two residual corrections -- with scaling and fix-up the identity:
+    // 3 VALU per denominator + 5 per numerator, the same bits (OFL_SP_FASTDIV=0 builds take `/`; compared bit for bit by the
+    // parity tests).  Numerators outside [2^-100, 2^80] (a NaN, an infinity, sums of denormal-sized data: the hardware
+    // sequence rescales those) send the wave through `/`.
+    float quot[2][NC + (MCH ? 1 : 0)];
+    {
+        float dcl[2], nb[2], y[2];
+        bool odd_range = false;
+        bool mch_trivial = true;             // the mask channel equals the density (every contributor valid) or 0: no division
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float den = tot[k][0];
+            dcl[k] = s.raw ? 1.0f : (den < kDenMin ? kDenMin : den);      // clamp_min utils.py:1144 (raw sums: x / 1 = x)
+            float r0 = __builtin_amdgcn_rcpf(dcl[k]);
+            const float e = __builtin_fmaf(-dcl[k], r0, 1.0f);
+            y[k] = __builtin_fmaf(e, r0, r0);
+            nb[k] = -dcl[k];
+            float amax = 0.0f;
+            int emin = 0;
+#pragma unroll
+            for (int c = 0; c < NC + (MCH ? 1 : 0); ++c) {
+                const float a = tot[k][1 + c];
+                amax = fmaxf(amax, fabsf(a));
+                emin = min(emin, __builtin_amdgcn_frexp_expf(a));           // (0 for a zero)
+                odd_range |= !(fabsf(a) <= 0x1p80f);                        // also a NaN
+            }
+            odd_range |= emin < -100 || !(amax <= 0x1p80f);
+            if (MCH) mch_trivial &= (tot[k][1 + NC] == 0.0f) || (tot[k][1 + NC] == den && den >= kDenMin);
+        }
+        const bool fast = OFL_SP_FASTDIV && !__builtin_expect(__any(odd_range), 0);     // wave-uniform
+        const bool skip_m = MCH && OFL_SP_FASTDIV && __all(mch_trivial);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int c = 0; c < NC + (MCH ? 1 : 0); ++c) {
+                const float a = tot[k][1 + c];
+                float q;
+                if (MCH && c == NC && skip_m) {
+                    q = a == 0.0f ? 0.0f : 1.0f;                                // den / den, den >= 1e-3
+                } else if (fast) {
+                    q = a * y[k];
+                    float r = __builtin_fmaf(nb[k], q, a);
+                    q = __builtin_fmaf(r, y[k], q);
+                    r = __builtin_fmaf(nb[k], q, a);
+                    q = __builtin_fmaf(r, y[k], q);
+                } else {
+                    q = a / dcl[k];
+                }
+                quot[k][c] = q;
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float den = tot[k][0];
-        const float dcl = s.raw ? 1.0f : (den < kDenMin ? kDenMin : den);          // clamp_min utils.py:1144 (raw sums: x / 1 = x)
         const bool warped = den > 0.0f;                            // utils.py:1197
         const bool fill = t.fill_ok[k] && !warped && mine;
         den2[k] = den;
         warped2 |= (uint32_t)warped << (8 * k);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            out[c][k] = stored_as<TO>(apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)) : tot[k][1 + c] / dcl, s.round_mode));
+            out[c][k] = stored_as<TO>(apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)) : quot[k][c], s.round_mode));
         if (MCH) {
             float mv;
             if (fill) {
@@ -1507,7 +1564,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
                 }
                 mv = (a && b) ? 1.0f : 0.0f;
             } else {
-                mv = tot[k][1 + NC] / dcl;
+                mv = quot[k][NC + (MCH ? 1 : 0) - 1];
             }
             mch2[k] = mv;
             valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
@@ -2029,38 +2086,41 @@ __global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ pt
 // ------------------------------------------------------------------------------------------------
 // NT: non-temporal loads -- a batch larger than the last-level cache streams 13 % faster past it (B=64 1080p: 5.8 -> 6.65
 // TB/s); a small one (B=8: 150 MB) is better off cached
-// HOST (ofl_flow_flags_host): the words go straight to host-visible memory.  Every block, once its waves' atomics on the
-// device words are done, releases at agent scope and takes a ticket from an arrival counter; the block that draws the last
-// ticket reads the words back with memory-side atomics (exchange with 0: the device words and the counter are left zeroed
-// for the next call), stores them to the host buffer at system scope and, behind a system-scope release, the call's serial
-// number into word 0 -- the host polls that one word: no copy launch, no event, no memset (MI355X_MICROARCH.md,
-// Workgroup dispatch ... & inter-workgroup visibility: producer release -> counter -> last arriver; the last arriver reads
-// with returning atomics, which execute at the memory side, so no acquire of possibly stale L2 lines is involved).
-struct FlagsHost { int32_t* counter; int32_t* host; int32_t serial, total_blocks, n; };
+// HOST (ofl_flow_flags_host): the words go straight to host-visible memory.  Every wave waits for its own atomicOr on the
+// device words (agent-scope atomics execute at the memory side, beyond the per-XCD L2s: once `vmcnt` has drained they are
+// performed for every XCD); the block then takes a ticket from one of kFlagShards arrival counters (its linear id modulo
+// kFlagShards: ~500 equal blocks end together, and returning atomics on ONE word serialise at ~12 ns each), the last arriver
+// of a shard takes a ticket from the top counter, and the block that draws the last top ticket reads the words back with
+// returning atomics (exchange with 0: words and counters are left zeroed for the next call) and stores each of them to the
+// host buffer as ONE 8-byte {serial number, word} pair with a system-scope (write-through) store -- the host polls the
+// pairs: no copy launch, no event, no memset, no ordering between stores.  Only atomics and write-through stores carry
+// the payload, so no L2 write-back (`buffer_wbl2`, a release fence) is involved -- one such fence per block cost 30 us per
+// launch (MI355X_MICROARCH.md, Workgroup dispatch ... & inter-workgroup visibility: atomics on both sides; 8-byte granules).
+constexpr int kFlagShards = 32;
+struct FlagsHost { int32_t* counters; unsigned long long* host; int32_t serial, total_blocks, n; };   // counters: [kFlagShards] + [1] top
 
 __device__ __forceinline__ void flags_publish(int32_t* __restrict__ flags, const FlagsHost& fh) {
     __shared__ int last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's atomicOr (if any) has been performed
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int prev = __hip_atomic_fetch_add(fh.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = prev == fh.total_blocks - 1;
+        const int id = (int)(blockIdx.y * gridDim.x + blockIdx.x), shard = id % kFlagShards;
+        const int in_shard = (fh.total_blocks - shard + kFlagShards - 1) / kFlagShards;          // blocks whose id = shard (mod kFlagShards)
+        const int shards = fh.total_blocks < kFlagShards ? fh.total_blocks : kFlagShards;        // (non-empty ones)
+        int l = 0;
+        if (__hip_atomic_fetch_add(fh.counters + shard, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(fh.counters + shard, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l = __hip_atomic_fetch_add(fh.counters + kFlagShards, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+        }
+        last = l;
     }
     __syncthreads();
     if (!last) return;                                            // (block-uniform)
     for (int i = threadIdx.x; i < fh.n; i += blockDim.x) {
-        const int v = __hip_atomic_exchange(&flags[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&fh.host[1 + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t v = (uint32_t)__hip_atomic_exchange(&flags[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&fh.host[i], ((unsigned long long)v << 32) | (uint32_t)fh.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 // system scope: the words are on their way before the serial number
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(fh.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&fh.host[0], fh.serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (threadIdx.x == 0) __hip_atomic_store(fh.counters + kFlagShards, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool VEC, bool NT = false, bool HOST = false>   // VEC: 4 pixels per thread and step (16-byte flow loads, one mask dword); needs hw % 4 == 0 and aligned planes
@@ -2308,7 +2368,7 @@ int launch_splat_gather_half(const GatherParams& gp, unsigned grid, hipStream_t 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 24; }   // 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 25; }   // 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
@@ -2842,8 +2902,9 @@ __attribute__((visibility("default"))) int ofl_flow_flags_host(const void* flow,
     if (n > 65535) return OFL_E_SHAPE;
     if (thr != kZeroThr) return OFL_E_ARG;
     const int64_t hw = (int64_t)h * w;
+    if ((reinterpret_cast<uintptr_t>(host_words) & 7) != 0) return OFL_E_ARG;
     FlagsHost fh = {};
-    fh.counter = work + n; fh.host = host_words; fh.serial = serial; fh.n = n;
+    fh.counters = work + n; fh.host = reinterpret_cast<unsigned long long*>(host_words); fh.serial = serial; fh.n = n;
     hipStream_t st = (hipStream_t)stream;
     if (!flow_is_f16) {
         launch_flow_flags(static_cast<const float*>(flow), flow_bs, mask, mask_bs, work, n, hw, st, &fh);

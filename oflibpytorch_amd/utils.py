@@ -330,7 +330,12 @@ def from_matrix(matrix, shape, ref: str = None, matrix_is_inverse: bool = None, 
             raise ValueError("Error creating flow from matrix: Matrix_is_inverse cannot be True when ref is 's'")
         return flow_from_matrix(matrix, list(dims), _device=_device)
     if not matrix_is_inverse:
-        matrix = torch.pinverse(matrix)
+        # the 3 x 3 pseudo-inverse is formed by the HOST's LAPACK path whatever device the matrix lives on (unless it wants a
+        # gradient): nine numbers, and the same bits as the reference's PyTorch-CPU result (a GPU SVD rounds differently)
+        if matrix.device.type != 'cpu' and not _native._wants_grad(matrix):
+            matrix = torch.pinverse(matrix.cpu()).to(matrix.device)
+        else:
+            matrix = torch.pinverse(matrix)
     return flow_from_matrix(matrix, list(dims), _sign=-1.0, _device=_device)
 
 
