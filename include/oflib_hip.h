@@ -63,6 +63,11 @@ int ofl_version(void);
  *   unless the fallback accumulator of a pass would pass 2^31 floats; tests use small values to exercise the multi-pass
  *   code on small inputs). */
 #define OFL_OPT_SPLAT_PASS_IMAGES 4
+/*   OFL_OPT_SPLAT_FALLBACK_SLOTS: images the two-pass fallback accumulator of ofl_splat_tiled_f32 holds (0 = automatic: the
+ *   pass, capped at 1 GiB); tests use 1 to exercise the rounds.
+ *   All options are PROCESS-GLOBAL, unsynchronised testing / benchmarking aids: set them before any concurrent use of the
+ *   library, never from two threads; production code leaves them alone. */
+#define OFL_OPT_SPLAT_FALLBACK_SLOTS 5
 int ofl_set_option(int32_t key, int32_t value);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,
@@ -222,6 +227,9 @@ int ofl_splat_finalize_f32(const float* accum,
  */
 int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w);
 int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w);   /* images handled per pass (<= n) */
+/* images `accum_fallback` must hold, for `planes` = 1 + min(C, 3) + (with_mask_chan ? 1 : 0) planes per image: the pass, capped
+ * at 1 GiB (>= 1) -- accum_fallback is fp32 [that many, planes, H, W] */
+int64_t ofl_splat_tiled_fallback_images(int32_t n, int32_t planes, int32_t h, int32_t w);
 int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
                         const float* xs, const float* ys, int64_t xy_bs,
                         const float* data, int64_t data_bs, float data_sign,

@@ -18,7 +18,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 25              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 26              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -26,7 +26,7 @@ _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
             "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
-            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32")
+            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images")
 _lib = None
 
 
@@ -76,6 +76,7 @@ def load_library(path: str = None):
     lib.ofl_flow_flags_f32.argtypes = [p, i64, p, i64, f32, p, i32, i32, i32, p]
     lib.ofl_splat_tiled_workspace_ints.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_pass_images.argtypes = [i32, i32, i32]
+    lib.ofl_splat_tiled_fallback_images.argtypes = [i32, i32, i32, i32]
     lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                         p, p, i64, p, i32, i32, i32, i32, i32, p]
     lib.ofl_warp_bwd_grad_f32.argtypes = [p, i64, f32, p, i64, p, f32, p, i64, p, i32, i32, i32, i32, p]
@@ -98,6 +99,7 @@ def load_library(path: str = None):
         getattr(lib, name).restype = ctypes.c_int
     lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
     lib.ofl_splat_tiled_pass_images.restype = ctypes.c_int64
+    lib.ofl_splat_tiled_fallback_images.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -135,12 +137,18 @@ def exported_symbols():
     return _SYMBOLS
 
 
+_hip_seen = False
+
+
 def device(*operands) -> torch.device:
     """The HIP device the kernels run on: the device of the first operand that already lives on one (the flow comes
     first in every primitive), else torch's current device."""
-    if not torch.cuda.is_available():
-        raise NativeUnavailable("oflibpytorch_amd: no HIP device visible -- this package has no CPU fallback "
-                                "(its compute path is libofl_hip.so on MI355X)")
+    global _hip_seen
+    if not _hip_seen:
+        if not torch.cuda.is_available():
+            raise NativeUnavailable("oflibpytorch_amd: no HIP device visible -- this package has no CPU fallback "
+                                    "(its compute path is libofl_hip.so on MI355X)")
+        _hip_seen = True
     for t in operands:
         if isinstance(t, torch.Tensor) and t.device.type == 'cuda':
             return t.device
@@ -151,9 +159,24 @@ def _wants_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
+class _Here(object):
+    """No-op launch context: the operands already live on torch's current device (the common case -- entering
+    `torch.cuda.device` costs several microseconds per call, which a small batch pays with the GPU idle)."""
+    __slots__ = ()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE = _Here()
+
+
 def _on(dev):
     """Launch context: kernels go to the current stream OF THE OPERANDS' DEVICE, whatever torch's current device is."""
-    return torch.cuda.device(dev)
+    return _HERE if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
 
 
 def _check(rc: int, what: str):
@@ -162,12 +185,14 @@ def _check(rc: int, what: str):
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index))
 
 
 def _planes(t: torch.Tensor, dev, dtype, n: int, what: str):
     """Stage tensor [Nb, (C,) H, W] for a kernel: on `dev`, `dtype`, planes contiguous; returns
     (tensor to keep alive, batch stride in elements -- 0 broadcasts one batch element)."""
+    if t.device == dev and t.dtype == dtype and t.shape[0] == n and t.is_contiguous():
+        return t, (0 if n == 1 else t.stride(0))           # (the common case, kept short: host time is exposed at small batch)
     if t.device != dev:
         t = t.to(dev)
     if t.dtype != dtype:
@@ -407,7 +432,7 @@ def _splat_fwd_half(flow, data, *, out_half=False, xs=None, ys=None, flow_sign=1
         valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
         dflags = torch.empty((n,), dtype=torch.int32, device=dev) if want_dst_flags else None
         ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
-        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        accum = _fallback_accum(lib, n, c, mch, h, w, dev)
         rc = lib.ofl_splat_tiled_f16(_ptr(f), fbs, float(flow_sign), _ptr(d), dbs, float(data_sign), _ptr(wm), wmbs, _ptr(ca), cabs,
                                      _ptr(cb), cbbs, mch, 1 if occlude else 0, _ptr(dst), 1 if out_half else 0, _ptr(valid),
                                      _ptr(dflags), _ptr(ws), ws.numel(), _ptr(accum), n, h, w, _stream(dev))
@@ -420,6 +445,18 @@ def _splat_fwd_half(flow, data, *, out_half=False, xs=None, ys=None, flow_sign=1
     if want_dst_flags:
         return dst, valid, None, None, dflags
     return dst, valid, None, None
+
+
+def _fallback_accum(lib, n, c, mch, h, w, dev):
+    """The two-pass fallback accumulator a gather-splat call must bring (touched only when the bin kernel flags an image): the
+    pass, capped at 1 GiB by the library -- flagged images beyond that are served in rounds."""
+    planes = 1 + min(c, 3) + mch
+    return torch.empty((int(lib.ofl_splat_tiled_fallback_images(n, planes, h, w)), planes, h, w), dtype=torch.float32, device=dev)
+
+
+def set_splat_fallback_slots(k: int):
+    """Gather splat: the fallback accumulator holds k images (0 = automatic); tests use 1 to force several rounds."""
+    _check(load_library().ofl_set_option(5, int(k)), "ofl_set_option")
 
 
 def _warp_bwd_raw(flow, src, *, flow_sign=1.0, src_mask=None, flow_mask=None, want_valid=False, addend=None,
@@ -519,7 +556,7 @@ def _splat_fwd_raw(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0
     if _splat_path != 1 and w >= 4:
         # fused tiled path: LDS accumulation per destination tile; `accum` is only touched if the flow is too rough
         ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
-        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        accum = _fallback_accum(lib, n, c, mch, h, w, dev)
         rc = lib.ofl_splat_tiled_f32(_ptr(f), fbs, float(flow_sign), _ptr(x), _ptr(y), xbs, _ptr(d), dbs,
                                      float(data_sign), _ptr(d2), d2bs, _ptr(wm), wmbs, _ptr(ca), cabs, _ptr(cb), cbbs, mch, occ,
                                      _ptr(dst), _ptr(density), _ptr(warped), _ptr(valid), _ptr(mchan), _ptr(dflags),
@@ -595,7 +632,7 @@ def splat_sum(flow, data, *, flow_sign=1.0, data_sign=1.0):
         f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
         d = data.detach().to(dev, torch.float32).contiguous()
         ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
-        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + min(c, 3), h, w), dtype=torch.float32, device=dev)
+        accum = _fallback_accum(lib, n, c, 0, h, w, dev)
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
         rc = lib.ofl_splat_sum_f32(_ptr(f), fbs, float(flow_sign), _ptr(d), c * h * w, float(data_sign), _ptr(out),
                                    _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, _stream(dev))
@@ -692,7 +729,7 @@ def flow_from_matrix(matrix: torch.Tensor, n: int, h: int, w: int, sign: float =
             raise ValueError("oflibpytorch_amd: %d matrices cannot broadcast to a batch of %d" % (m.shape[0], n))
         dst = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
         _check(lib.ofl_flow_from_matrix_f32(_ptr(m), 0 if m.shape[0] == 1 else 9, float(sign), _ptr(dst), n, h, w, _stream(dev)),
-               "ofl_flow_from_matrix_f32")
+               "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images")
     return dst
 
 
@@ -768,7 +805,7 @@ def splat_fwd_win(flow, data, window, *, weight_mask=None, chan_mask_a=None, cha
         dst = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
         valid = torch.empty((n, h, w), dtype=torch.bool, device=dev) if want_valid else None
         ws = torch.empty(int(lib.ofl_splat_tiled_workspace_ints(n, h, w)), dtype=torch.int32, device=dev)
-        accum = torch.empty((int(lib.ofl_splat_tiled_pass_images(n, h, w)), 1 + c + mch, h, w), dtype=torch.float32, device=dev)
+        accum = _fallback_accum(lib, n, c, mch, h, w, dev)
         rc = lib.ofl_splat_tiled_win_f32(_ptr(f), fbs, 1.0, fh, fw, int(window[0]), int(window[1]), _ptr(d), dbs, 1.0, _ptr(wm), wmbs,
                                          _ptr(ca), cabs, _ptr(cb), cbbs, mch, 1 if occlude else 0, _ptr(dst), None, None,
                                          _ptr(valid), None, _ptr(ws), ws.numel(), _ptr(accum), n, c, h, w, int(round_mode),

@@ -401,6 +401,11 @@ inline unsigned blocks_for(int64_t items, int32_t n) {
 
 }  // namespace
 
+// ofl_kernels.hip: the gradient with respect to the flow on the forward's staged column kernel (OFL_E_UNSUPPORTED: not eligible)
+int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
+                                    const float* grad_out, float g_scale, float* grad_flow, int32_t n, int32_t c, int32_t h, int32_t w,
+                                    hipStream_t st);
+
 extern "C" {
 
 __attribute__((visibility("default"))) int ofl_warp_bwd_grad_f32(
@@ -412,6 +417,12 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_grad_f32(
     int rc = dims_ok(n, c, h, w);
     if (rc) return rc;
     if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
+    if (grad_flow && !grad_src) {
+        // the gradient with respect to the flow alone (the one with respect to the source is a gather splat, ofl_splat_sum_f32):
+        // the forward kernel's staged boxes, one ds_read_b128 per tap instead of C scalar gathers
+        rc = ofl_internal_warp_grad_flow_lds(flow, flow_bs, flow_sign, src, src_bs, grad_out, g_scale, grad_flow, n, c, h, w, (hipStream_t)stream);
+        if (rc != OFL_E_UNSUPPORTED) return rc;
+    }
     WarpGradParams p;
     p.flow = flow; p.flow_bs = flow_bs; p.flow_sign = flow_sign; p.src = src; p.src_bs = src_bs;
     p.gout = grad_out; p.g_scale = g_scale; p.gsrc = grad_src; p.gsrc_bs = grad_src_bs; p.gflow = grad_flow;

@@ -477,11 +477,15 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
 }
 
 // step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
-template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, typename WP = WarpParams>
+// GRAD (ofl_warp_bwd_grad_f32, gradient with respect to the FLOW): instead of the blend, the taps of a pixel are combined
+// with its upstream gradient `gq` into ATen's gix / giy sums (grid_sampler_2d_backward), chained through the
+// un-normalisation, normalise_coords and `grid - flow` exactly as autograd does -- same expressions, same order as the
+// one-pixel-per-lane kernel of ofl_aux_kernels.hip (the two are compared bit for bit); outv[k] = (d/du, d/dv, -, -).
+template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, bool GRAD = false, typename WP = WarpParams>
 __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                                                 const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                                 const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
-                                                const float* __restrict__ sbb = nullptr) {
+                                                const float* __restrict__ sbb = nullptr, const f4* gq = nullptr) {
     const int w = p.w, h = p.h;
     const int cw16 = B.cw * 16, P16 = B.Pp * 16;
     const float wf = (float)w, hf = (float)h;
@@ -545,6 +549,17 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                 tv[j] = t;
             }
         }
+        if (GRAD) {
+            float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float g = p.g_sign * gq[c][k];                       // (g_sign carries the upstream scale)
+                gix -= tv[0][c] * s * g; gix += tv[1][c] * s * g; gix -= tv[2][c] * nn * g; gix += tv[3][c] * nn * g;
+                giy -= tv[0][c] * e * g; giy -= tv[1][c] * ww * g; giy += tv[2][c] * e * g; giy += tv[3][c] * ww * g;
+            }
+            outv[k] = (f4){-p.flow_sign * (((gix * p.half_wm1) / p.wm1) * 2.0f), -p.flow_sign * (((giy * p.half_hm1) / p.hm1) * 2.0f), 0.f, 0.f};
+            continue;
+        }
         // v_nw*nw, then fma(v_ne, ne, .), fma(v_sw, sw, .), fma(v_se, se, .): the reference's contraction order
         f4 r = tv[0] * wg[0];
         r = __builtin_elementwise_fma(tv[1], (f4){wg[1], wg[1], wg[1], wg[1]}, r);
@@ -554,13 +569,13 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
     }
 }
 
-template <int NC, bool VALID, bool SUB = false, typename TS = float, typename WP = WarpParams>
+template <int NC, bool VALID, bool SUB = false, typename TS = float, bool GRAD = false, typename WP = WarpParams>
 __device__ __forceinline__ void lds_gather(const WP& p, uint32_t hw,
                                            const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                            const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
-                                           const float* __restrict__ sbb = nullptr) {
-    if (B.interior) lds_gather_impl<NC, VALID, true, SUB, TS>(p, hw, sb, sm, T, B, smem, outv, sbb);
-    else lds_gather_impl<NC, VALID, false, SUB, TS>(p, hw, sb, sm, T, B, smem, outv, sbb);
+                                           const float* __restrict__ sbb = nullptr, const f4* gq = nullptr) {
+    if (B.interior) lds_gather_impl<NC, VALID, true, SUB, TS, GRAD>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
+    else lds_gather_impl<NC, VALID, false, SUB, TS, GRAD>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
 }
 
 // the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
@@ -688,7 +703,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
 // T = 2: written as this loop it leaves its small arrays in scratch).  The two dependent round trips of a tile (flow, then
 // its staged box) and the drain of its stores are paid once per BLOCK: a taller column of tiles amortises them over more
 // pixels with the same registers and the same LDS -- flow two tiles ahead, staging loads one tile ahead, stores behind.
-template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float>
+// GRAD: the same column pipeline computing the gradient with respect to the flow (`addend` = the upstream gradient [N,NC,H,W],
+// `dst` = [N,2,H,W]; see lds_gather_impl) -- the forward's staged boxes instead of 4 * NC scalar gathers per pixel.
+template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p_by_value) {
 #if OFL_WARP_KARG
     // parameters through the kernarg segment (see OFL_OPAQUE_S at the gather splat): the ~250 bytes of WarpParams are not
@@ -763,10 +780,18 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         lds_barrier();
         f4 outv[4], ad[NC];
         if (EARLY) { if (reuse) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; } else lds_load_addend<NC>(p, tx, tyk, n, hw, ad); }
+        if (GRAD) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);              // the upstream gradient of the tile, ahead of the younger loads
         if (k + 1 < T) {
             if (more) lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[k + 1], S, sbb);   // the next tile's staging loads fly while this one is gathered and stored
         }
-        lds_gather<NC, VALID, SUB, TS>(p, hw, sb, sm, Tc[k], Bx[k], smem, outv, sbb);
+        lds_gather<NC, VALID, SUB, TS, GRAD>(p, hw, sb, sm, Tc[k], Bx[k], smem, outv, sbb, ad);
+        if (GRAD) {
+            const f4 none[2] = {};
+            lds_store<2, false, false, false, float>(p, tx, tyk, n, hw, 0u, outv, none);
+            if (!more) break;
+            lds_barrier();
+            continue;
+        }
         if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
         lds_store<NC, VALID, ADD, DF, TD>(p, tx, tyk, n, hw, fmk[k], outv, ad, &dflags);
         if (!more) break;
@@ -923,6 +948,7 @@ struct SplatParams {
     int32_t fh, fw, foy, fox;
     const int32_t* run_if_set;   // optional device flags int32[n]: the atomics path runs for image i only when run_if_set[i] != 0
     const int32_t* any_set;      // (with run_if_set) one word: some image of the pass is flagged
+    int32_t fb_round, fb_slots;  // (with run_if_set) the accumulator holds fb_slots images: this launch serves the flagged images ranked [fb_round * fb_slots, (fb_round + 1) * fb_slots) among the flagged ones, image of rank r in slot r % fb_slots
     int32_t* dst_flags;          // optional int32[N] (2-channel data only): flag word of the OUTPUT read as a flow under `valid`
     int32_t raw;                 // 1: the weighted sums themselves, not divided by the density (ofl_splat_sum_f32: the transpose of the backward warp)
 };
@@ -935,6 +961,16 @@ __device__ __forceinline__ uint32_t sp_win(const SP& s, int x, int y, bool& insi
     return (uint32_t)(min(max(fy, 0), s.fh - 1) * s.fw + min(max(fx, 0), s.fw - 1));
 }
 
+// Two-pass fallback inside ofl_splat_tiled_f32: the accumulator is bounded (fb_slots images, not the whole pass), so flagged
+// images are served in rounds by their rank among the flagged ones -- accumulator slot of image n in this round, or -1 (not
+// flagged / another round's).  The rank is a scan over the flags below n: this code only runs when some image IS flagged.
+__device__ __forceinline__ int fb_slot(const SplatParams& p, int n) {
+    if (p.run_if_set[n] == 0) return -1;
+    int rank = 0;
+    for (int i = 0; i < n; ++i) rank += p.run_if_set[i] != 0;
+    return (rank / p.fb_slots == p.fb_round) ? rank % p.fb_slots : -1;
+}
+
 template <int CT, typename TF = float>
 __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
     // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid that leaves at once when no
@@ -944,7 +980,8 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
     const int tx = (int)(tile % p.tiles_x);
     const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
     const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
-    if (p.run_if_set && p.run_if_set[n] == 0) continue;
+    const int slot = p.run_if_set ? fb_slot(p, n) : n;
+    if (slot < 0) continue;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = tx * kTileW + lane;
     const int w = p.w, h = p.h;
@@ -959,7 +996,7 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
     const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
     const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
-    float* __restrict__ acc = p.accum + (int64_t)n * planes * hw;
+    float* __restrict__ acc = p.accum + (int64_t)slot * planes * hw;
 
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
@@ -1032,7 +1069,8 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
     const int tx = (int)(tile % p.tiles_x);
     const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
     const int n = (int)(tile / ((int64_t)p.tiles_x * p.tiles_y));
-    if (p.run_if_set && p.run_if_set[n] == 0) continue;
+    const int slot = p.run_if_set ? fb_slot(p, n) : n;
+    if (slot < 0) continue;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = tx * kTileW + lane;
     const int w = p.w, h = p.h;
@@ -1046,7 +1084,7 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
     const uint8_t* __restrict__ wmk = p.weight_mask ? p.weight_mask + n * p.weight_mask_bs : nullptr;
     const uint8_t* __restrict__ cma = p.chan_mask_a ? p.chan_mask_a + n * p.chan_mask_a_bs : nullptr;
     const uint8_t* __restrict__ cmb = p.chan_mask_b ? p.chan_mask_b + n * p.chan_mask_b_bs : nullptr;
-    const float* __restrict__ acc = p.accum + (int64_t)n * planes * hw;
+    const float* __restrict__ acc = p.accum + (int64_t)slot * planes * hw;
     TO* __restrict__ dst = reinterpret_cast<TO*>(p.dst) + (int64_t)n * p.dst_bs;
     int dflags = 0;
 
@@ -1368,9 +1406,6 @@ __device__ __forceinline__ void sp_corners(float xv, float yv, float wmax, float
     ix[0] = (int)x0s - dx0; ix[1] = (int)x1s - dx0; iy[0] = (int)y0s - dy0; iy[1] = (int)y1s - dy0;
 }
 
-#ifndef OFL_SP_FASTDIV
-#define OFL_SP_FASTDIV 1   // sp_finalize: the division's core sequence without range scaling / fix-up for in-range operands (same bits)
-#endif
 #ifndef OFL_SP_MINB
 #define OFL_SP_MINB 4   // blocks per CU the gather kernel's register budget is sized for (what its 39.7 KB of LDS allow)
 #endif
@@ -1487,71 +1522,17 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
     const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
     f2 den2, out[NC], mch2;
     uint32_t warped2 = 0, valid2 = 0;
-    // The 2 * (NC + MCH) quotients of a thread share two denominators, and their operands sit in the middle of the exponent range:
-    // the denominator is a density clamped to >= 1e-3 and at most the number of pixels of a frame (< 2^24).  There the
-    // correctly rounded division the compiler emits (v_div_scale x 2, v_rcp, 4 fma, mul, v_div_fmas, v_div_fixup: 11 VALU)
-    // reduces to its core -- y = rcp refined once, q = a y, two residual corrections -- with scaling and fix-up the identity:
-    // 3 VALU per denominator + 5 per numerator, the same bits (OFL_SP_FASTDIV=0 builds take `/`; compared bit for bit by the
-    // parity tests).  Numerators outside [2^-100, 2^80] (a NaN, an infinity, sums of denormal-sized data: the hardware
-    // sequence rescales those) send the wave through `/`.
-    float quot[2][NC + (MCH ? 1 : 0)];
-    {
-        float dcl[2], nb[2], y[2];
-        bool odd_range = false;
-        bool mch_trivial = true;             // the mask channel equals the density (every contributor valid) or 0: no division
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const float den = tot[k][0];
-            dcl[k] = s.raw ? 1.0f : (den < kDenMin ? kDenMin : den);      // clamp_min utils.py:1144 (raw sums: x / 1 = x)
-            float r0 = __builtin_amdgcn_rcpf(dcl[k]);
-            const float e = __builtin_fmaf(-dcl[k], r0, 1.0f);
-            y[k] = __builtin_fmaf(e, r0, r0);
-            nb[k] = -dcl[k];
-            float amax = 0.0f;
-            int emin = 0;
-#pragma unroll
-            for (int c = 0; c < NC + (MCH ? 1 : 0); ++c) {
-                const float a = tot[k][1 + c];
-                amax = fmaxf(amax, fabsf(a));
-                emin = min(emin, __builtin_amdgcn_frexp_expf(a));           // (0 for a zero)
-                odd_range |= !(fabsf(a) <= 0x1p80f);                        // also a NaN
-            }
-            odd_range |= emin < -100 || !(amax <= 0x1p80f);
-            if (MCH) mch_trivial &= (tot[k][1 + NC] == 0.0f) || (tot[k][1 + NC] == den && den >= kDenMin);
-        }
-        const bool fast = OFL_SP_FASTDIV && !__builtin_expect(__any(odd_range), 0);     // wave-uniform
-        const bool skip_m = MCH && OFL_SP_FASTDIV && __all(mch_trivial);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-#pragma unroll
-            for (int c = 0; c < NC + (MCH ? 1 : 0); ++c) {
-                const float a = tot[k][1 + c];
-                float q;
-                if (MCH && c == NC && skip_m) {
-                    q = a == 0.0f ? 0.0f : 1.0f;                                // den / den, den >= 1e-3
-                } else if (fast) {
-                    q = a * y[k];
-                    float r = __builtin_fmaf(nb[k], q, a);
-                    q = __builtin_fmaf(r, y[k], q);
-                    r = __builtin_fmaf(nb[k], q, a);
-                    q = __builtin_fmaf(r, y[k], q);
-                } else {
-                    q = a / dcl[k];
-                }
-                quot[k][c] = q;
-            }
-        }
-    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float den = tot[k][0];
+        const float dcl = s.raw ? 1.0f : (den < kDenMin ? kDenMin : den);          // clamp_min utils.py:1144 (raw sums: x / 1 = x)
         const bool warped = den > 0.0f;                            // utils.py:1197
         const bool fill = t.fill_ok[k] && !warped && mine;
         den2[k] = den;
         warped2 |= (uint32_t)warped << (8 * k);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            out[c][k] = stored_as<TO>(apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)) : quot[k][c], s.round_mode));
+            out[c][k] = stored_as<TO>(apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)) : tot[k][1 + c] / dcl, s.round_mode));
         if (MCH) {
             float mv;
             if (fill) {
@@ -1564,7 +1545,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
                 }
                 mv = (a && b) ? 1.0f : 0.0f;
             } else {
-                mv = quot[k][NC + (MCH ? 1 : 0) - 1];
+                mv = tot[k][1 + NC] / dcl;
             }
             mch2[k] = mv;
             valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
@@ -2071,10 +2052,12 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
 }
 
 // zero the fallback accumulator of the images that take the atomics path
-__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t count_per_image, const int32_t* __restrict__ flags) {
+__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t count_per_image, const SplatParams p) {
+    if (*p.any_set == 0) return;
     const int n = blockIdx.y;
-    if (flags[n] == 0) return;
-    float* __restrict__ q = ptr + (int64_t)n * count_per_image;
+    const int slot = fb_slot(p, n);
+    if (slot < 0) return;
+    float* __restrict__ q = ptr + (int64_t)slot * count_per_image;
     const int64_t n4 = count_per_image >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
         reinterpret_cast<f4u*>(q)[i] = (f4){0.f, 0.f, 0.f, 0.f};
@@ -2248,6 +2231,7 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
+int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
 
 template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
@@ -2363,17 +2347,47 @@ int launch_splat_gather_half(const GatherParams& gp, unsigned grid, hipStream_t 
 
 }  // namespace
 
+// The gradient of the backward warp with respect to its FLOW on the staged column kernel (called by ofl_warp_bwd_grad_f32 in
+// ofl_aux_kernels.hip; not exported).  OFL_E_UNSUPPORTED: the frame is not eligible (the caller's one-pixel-per-lane kernel takes it).
+int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float flow_sign, const float* src, int64_t src_bs,
+                                    const float* grad_out, float g_scale, float* grad_flow, int32_t n, int32_t c, int32_t h, int32_t w,
+                                    hipStream_t st) {
+    const bool lds_ok = g_warp_path != 1 && c >= 1 && c <= 3 && w >= 4 && h >= 2 && w < 32760 && h < 32760 && (int64_t)h * w < (1ll << 24);
+    if (!lds_ok || kLdsT <= 2) return OFL_E_UNSUPPORTED;
+    if ((int64_t)((w + 31) / 32) * ((h + 15) / 16) * n >= (1ll << 31)) return OFL_E_SHAPE;
+    WarpParams p = {};
+    p.flow = flow; p.flow_bs = flow_bs; p.src = src; p.src_bs = src_bs;
+    p.addend = grad_out; p.addend_bs = (int64_t)c * h * w;           // (the column kernel fetches the upstream gradient where mode 3 fetches its addend)
+    p.dst = grad_flow; p.dst_bs = (int64_t)2 * h * w;
+    p.n = n; p.c = c; p.h = h; p.w = w;
+    p.flow_sign = flow_sign; p.a_sign = 1.0f; p.g_sign = g_scale; p.round_mode = OFL_ROUND_NONE;
+    p.wm1 = (float)(w - 1); p.hm1 = (float)(h - 1);
+    p.half_wm1 = p.wm1 / 2.0f; p.half_hm1 = p.hm1 / 2.0f;
+    p.rcp_wm1 = 1.0f / p.wm1; p.rcp_hm1 = 1.0f / p.hm1;
+    p.lds_bytes = kLdsBytes;
+    p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;
+    const unsigned g = warp_geometry(p, kLdsTWQ * 4, kLdsT * kLdsTH);
+    constexpr int TT = kLdsT > 2 ? kLdsT : 3;
+    switch (c) {
+        case 1: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 1, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
+        case 2: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
+        default: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 3, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
+    }
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 25; }   // 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 26; }   // 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
+    if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }
     return OFL_E_ARG;
 }
 
@@ -2657,6 +2671,21 @@ static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
 
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w) { return splat_chunk_images(n, h, w); }
 
+// images the two-pass fallback accumulator of ofl_splat_tiled_f32 holds: the whole pass while that stays under 1 GiB, else as
+// many as fit (at least one) -- flagged images beyond that are served in further rounds of the fallback launches (all of
+// them no-ops unless the bin kernel flagged an image), so the footprint of a call no longer grows with the batch
+static int64_t splat_fallback_slots(int32_t n, int32_t planes, int32_t h, int32_t w) {
+    const int64_t pass = splat_chunk_images(n, h, w);
+    const int64_t per_image = (int64_t)planes * h * w * (int64_t)sizeof(float);
+    int64_t k = ((int64_t)1 << 30) / (per_image > 0 ? per_image : 1);
+    if (g_splat_fallback_slots > 0) k = g_splat_fallback_slots;
+    if (k < 1) k = 1;
+    return k < pass ? k : pass;
+}
+__attribute__((visibility("default"))) int64_t ofl_splat_tiled_fallback_images(int32_t n, int32_t planes, int32_t h, int32_t w) {
+    return splat_fallback_slots(n, planes, h, w);
+}
+
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w) {
     return splat_pass_words(splat_chunk_images(n, h, w), h, w);
 }
@@ -2777,22 +2806,28 @@ static int splat_tiled_impl(
             fb.accum = accum_fallback;
             fb.run_if_set = gp.img_over;
             fb.any_set = gp.stats;                            // stats[0]: some image (of this or an earlier pass) is flagged
+            // the accumulator holds `slots` images (sized for the planes of the call's first channel group, the largest):
+            // flagged images are served `slots` at a time; every launch below leaves at once when nothing is flagged
+            fb.fb_slots = (int32_t)splat_fallback_slots(n, 1 + (c < 3 ? c : 3) + (with_mask_chan ? 1 : 0), h, w);
             const int planes = 1 + cg + (fb.with_mask_chan ? 1 : 0);
-            hipLaunchKernelGGL(zero_if_set_kernel, dim3(64, (unsigned)nn), dim3(256), 0, st, accum_fallback, (int64_t)planes * hw, gp.img_over);
             unsigned g2;
             tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
             if (g2 > 2048u) g2 = 2048u;                       // (strided: the kernels walk the tiles of the flagged images)
-            if (half_in) {
-                hipLaunchKernelGGL((splat_fwd_kernel<2, _Float16>), dim3(g2), dim3(256), 0, st, fb);
-                if (elem == 2) hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, _Float16>), dim3(g2), dim3(256), 0, st, fb);
-                else hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, float>), dim3(g2), dim3(256), 0, st, fb);
-            } else switch (cg) {
-                case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
-                        hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
-                case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
-                        hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
-                default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
-                         hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
+            for (int64_t r0 = 0; r0 < nn; r0 += fb.fb_slots) {
+                fb.fb_round = (int32_t)(r0 / fb.fb_slots);
+                hipLaunchKernelGGL(zero_if_set_kernel, dim3(64, (unsigned)nn), dim3(256), 0, st, accum_fallback, (int64_t)planes * hw, fb);
+                if (half_in) {
+                    hipLaunchKernelGGL((splat_fwd_kernel<2, _Float16>), dim3(g2), dim3(256), 0, st, fb);
+                    if (elem == 2) hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, _Float16>), dim3(g2), dim3(256), 0, st, fb);
+                    else hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, float>), dim3(g2), dim3(256), 0, st, fb);
+                } else switch (cg) {
+                    case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
+                            hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
+                    case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
+                            hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
+                    default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
+                             hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
+                }
             }
         }
     }

@@ -216,3 +216,76 @@ def test_gradients_with_more_than_three_channels(shape, dev):
     (_ref_splat(xb, yb, db, None)[0] * wts).sum().backward()
     _close(da.grad.cpu(), db.grad, "splat: grad wrt data, C = %d" % c, rtol=1e-3)
     _close(fa2.grad.cpu(), fb2.grad, "splat: grad wrt positions, C = %d" % c, rtol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: the gradient with respect to the flow on the forward's staged kernel; gradients at full frame size
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 300, 400), (1, 1, 64, 96), (3, 2, 37, 131), (2, 3, 130, 6), (1, 3, 1080, 1920)])
+@pytest.mark.parametrize("flow_sign", [1.0, -1.0])
+def test_staged_and_generic_grad_flow_kernels_agree(shape, flow_sign, dev):
+    """ofl_warp_bwd_grad_f32 (gradient wrt the flow only): the staged column kernel (taps from the LDS box) and the
+    one-pixel-per-lane kernel restate the same expressions in the same order -- bit for bit, borders and odd widths included."""
+    from oflibpytorch_amd import _native
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 7 + c)
+    f = _smooth(n, h, w, 7.0, 21 + c).to(dev)
+    f[0] += torch.tensor([0.4 * w, -0.3 * h], device=dev).view(2, 1, 1)       # taps beyond the border
+    src = torch.rand(n, c, h, w, generator=g).to(dev) * 10
+    gout = torch.randn(n, c, h, w, generator=g).to(dev)
+    try:
+        _native.set_warp_path(1)
+        _, ref = _native.warp_bwd_grad(f, src, gout, flow_sign=flow_sign, g_scale=-1.0, want_src=False, want_flow=True)
+    finally:
+        _native.set_warp_path(0)
+    _, got = _native.warp_bwd_grad(f, src, gout, flow_sign=flow_sign, g_scale=-1.0, want_src=False, want_flow=True)
+    assert torch.equal(got, ref)
+    # a broadcast source (B = 1 image against N flows)
+    _, got1 = _native.warp_bwd_grad(f, src[:1], gout, flow_sign=flow_sign, want_src=False, want_flow=True)
+    try:
+        _native.set_warp_path(1)
+        _, ref1 = _native.warp_bwd_grad(f, src[:1], gout, flow_sign=flow_sign, want_src=False, want_flow=True)
+    finally:
+        _native.set_warp_path(0)
+    assert torch.equal(got1, ref1)
+
+
+@pytest.mark.gpu
+def test_gradients_at_1080p_against_torch_cpu_autograd(dev):
+    """gradient parity at the frame size of the benchmark (B = 2, 1080 x 1920, the sigma = 8 bench flow, so the
+    gather splat behind the gradient wrt the warp's source crosses fold tiles): apply_flow 't' and 's' and switch_ref against
+    torch's CPU autograd through the restated op sequence.  Bar: GRAD_RTOL of the gradient's scale (5e-4 for positions)."""
+    import bench
+    import oflibpytorch_amd as ofl
+    n, h, w = 2, 1080, 1920
+    f = bench.smooth_flow(n, h, w, 8.0, 1003, torch.device('cpu'))
+    g = torch.Generator().manual_seed(77)
+    img = torch.rand(n, 3, h, w, generator=g)
+    wts = torch.randn(n, 3, h, w, generator=g)
+    mask = bench.hole_mask(n, h, w, torch.device('cpu'))
+    # 't': backward warp
+    fa, ia = f.to(dev).requires_grad_(), img.to(dev).requires_grad_()
+    (ofl.apply_flow(fa, ia, 't') * wts.to(dev)).sum().backward()
+    fb, ib = f.clone().requires_grad_(), img.clone().requires_grad_()
+    (_ref_apply_t(fb, ib) * wts).sum().backward()
+    _close(fa.grad.cpu(), fb.grad, "1080p 't': grad wrt flow")
+    _close(ia.grad.cpu(), ib.grad, "1080p 't': grad wrt target")
+    # 's': forward splat (apply_flow with a mask: utils.py:1157-1205; no exactly-zero vectors in a smooth random flow)
+    fa, ia = f.to(dev).requires_grad_(), img.to(dev).requires_grad_()
+    (ofl.apply_flow(fa, ia, 's', mask.to(dev)) * wts.to(dev)).sum().backward()
+    fb, ib = f.clone().requires_grad_(), img.clone().requires_grad_()
+    xb = fb[:, 0] + torch.arange(w)[None, None, :]
+    yb = fb[:, 1] + torch.arange(h)[None, :, None]
+    (_ref_splat(xb, yb, ib, mask)[0] * wts).sum().backward()
+    _close(ia.grad.cpu(), ib.grad, "1080p 's': grad wrt target")
+    _close(fa.grad.cpu(), fb.grad, "1080p 's': grad wrt flow", rtol=5e-4)
+    # switch_ref 's' -> 't': the flow splatted along itself
+    fa = f.to(dev).requires_grad_()
+    out = ofl.Flow(fa, 's', mask.to(dev)).switch_ref()
+    (out.vecs * wts[:, :2].to(dev)).sum().backward()
+    fb = f.clone().requires_grad_()
+    xb = fb[:, 0] + torch.arange(w)[None, None, :]
+    yb = fb[:, 1] + torch.arange(h)[None, :, None]
+    (_ref_splat(xb, yb, fb, mask)[0] * wts[:, :2]).sum().backward()
+    _close(fa.grad.cpu(), fb.grad, "1080p switch_ref: grad wrt flow", rtol=5e-4)
