@@ -729,7 +729,7 @@ def flow_from_matrix(matrix: torch.Tensor, n: int, h: int, w: int, sign: float =
             raise ValueError("oflibpytorch_amd: %d matrices cannot broadcast to a batch of %d" % (m.shape[0], n))
         dst = torch.empty((n, 2, h, w), dtype=torch.float32, device=dev)
         _check(lib.ofl_flow_from_matrix_f32(_ptr(m), 0 if m.shape[0] == 1 else 9, float(sign), _ptr(dst), n, h, w, _stream(dev)),
-               "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images")
+               "ofl_flow_from_matrix_f32")
     return dst
 
 

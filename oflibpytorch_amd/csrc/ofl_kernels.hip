@@ -73,6 +73,19 @@ __device__ __forceinline__ void flag_or(int32_t* addr, int f) {
     if ((cur | f) != cur) atomicOr(addr, f);
 }
 
+// One look / atomic per BLOCK on an image's shared word (the waves' words are combined in LDS first; every thread of the
+// block calls this): with a few images, hundreds of waves end within microseconds of each other on the same word, and every
+// such access is served one after the other at the memory side -- B = 8, 512 blocks: 55 us per wave-level OR, 42 us per
+// block-level OR; B = 1: 26 -> 17 us (tools/ab_flags.py, profiles/r3_flags_host_route.txt).
+__device__ __forceinline__ void block_flag_or(int32_t* addr, int f) {
+    __shared__ int bflags;
+    if (threadIdx.x == 0) bflags = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && f != 0) atomicOr(&bflags, f);
+    __syncthreads();
+    if (threadIdx.x == 0) flag_or(addr, bflags);
+}
+
 // XCD-aware block -> logical tile id: hardware deals blocks round-robin over the 8 XCDs, so block b
 // and b+8 share an L2.  Give every XCD one contiguous range of logical tiles (speed only).
 __device__ __forceinline__ int64_t logical_block(int64_t per_xcd) {
@@ -1976,7 +1989,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     }
     if (NC == 2 && s.dst_flags) {                             // (every thread of the block gets here)
         dflags = wave_or_flags(dflags);
-        if (lane == 0) flag_or(&s.dst_flags[n], dflags);
+        block_flag_or(&s.dst_flags[n], dflags);              // one access per block on the image's word (see block_flag_or)
     }
 #undef s
 #undef p
@@ -2142,7 +2155,7 @@ __global__ __launch_bounds__(256) void flow_flags_kernel(const float* __restrict
             f |= flag_bits(fu[i], fu[hw + i], mk ? (mk[i] != 0) : true);
     }
     f = wave_or_flags(f);
-    if ((threadIdx.x & 63) == 0) flag_or(&flags[n], f);
+    block_flag_or(&flags[n], f);
     if (HOST) flags_publish(flags, fh);
 }
 
@@ -2183,7 +2196,7 @@ __global__ __launch_bounds__(256) void flow_f16_kernel(const _Float16* __restric
         }
     }
     f = wave_or_flags(f);
-    if ((threadIdx.x & 63) == 0) flag_or(&flags[n], f);
+    block_flag_or(&flags[n], f);
     if (HOST) flags_publish(flags, fh);
 }
 
@@ -2280,6 +2293,9 @@ int launch_warp_lds_u8(const WarpParams& p, unsigned grid, hipStream_t st) {
 
 inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
+#ifndef OFL_FLAGS_BLOCKS
+#define OFL_FLAGS_BLOCKS 512
+#endif
 // `fh`: optional hand-over of the words to host-visible memory by the last block (ofl_flow_flags_host)
 void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, int64_t mask_bs, int32_t* flags, int32_t n,
                        int64_t hw, hipStream_t st, const FlagsHost* fhp = nullptr) {
@@ -2290,7 +2306,7 @@ void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, 
         // about 512 blocks in all: every wave ends with a look at (and maybe an atomic on) its image's shared word, and
         // few long-running blocks stream better than many short ones (B=64 1080p: 3.1 -> 5.8 TB/s; B=16: 2.5 -> 5.4)
         int64_t bx = (hw / 4 + 1023) / 1024;               // 4 groups of 4 pixels per thread and step
-        int64_t cap = 512 / n;
+        int64_t cap = OFL_FLAGS_BLOCKS / n;
         cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
         if (bx > cap) bx = cap;
         fh.total_blocks = (int32_t)(bx * n);
