@@ -1184,10 +1184,17 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 //  subtiles spread over > 256 destination tiles takes the two-pass global-atomics path inside the same call, decided on
 //  the device, per image.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSpTW = 32, kSpTH = 16;                        // destination tiles
+#ifndef OFL_SP_TW
+#define OFL_SP_TW 32    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues)
+#endif
+#ifndef OFL_SP_TH
+#define OFL_SP_TH 16
+#endif
+constexpr int kSpTW = OFL_SP_TW, kSpTH = OFL_SP_TH;          // destination tiles
+static_assert(kSpTW == 32 || kSpTW == 64, "destination tile width");
 constexpr int kSpNT2 = kSpTW * kSpTH / 2;                    // gather kernel: 2 destination pixels per thread
 #ifndef OFL_SP_Q
-#define OFL_SP_Q 896    // (1024 leaves room for 3 blocks per CU only; 896: 39.7 KB per block, 4 blocks -- measured -4 % / -13 % on apply 's' / switch_ref)
+#define OFL_SP_Q (kSpTW == 32 ? 896 : 1792)    // (32-wide tiles: 1024 leaves room for 3 blocks per CU only; 896: 39.7 KB per block, 4 blocks -- measured -4 % / -13 % on apply 's' / switch_ref)
 #endif
 constexpr int kSpQ = OFL_SP_Q;                               // records the gather kernel holds in LDS at a time
 #ifndef OFL_SP_SUBH
@@ -1197,7 +1204,7 @@ constexpr int kSubW = 16, kSubH = OFL_SP_SUBH;               // source subtiles:
 constexpr int kSubLanes = 4 * kSubH;                         // lanes per subtile (16: a DPP row; 8: half a row)
 constexpr int kRegH = 16;                                    // a bin block covers a 64 x 16 source region (its wave w: rows 4 w .. 4 w + 3)
 static_assert(kSubH == 2 || kSubH == 4, "subtile height");
-constexpr int kBinCap = 512 / kSubH;                         // subtiles one destination tile can list (fixed-address lists: 4 * kBinCap bytes per tile)
+constexpr int kBinCap = (512 / kSubH) * (kSpTW / 32);        // subtiles one destination tile can list (fixed-address lists: 4 * kBinCap bytes per tile)
 constexpr int kBinSpread = 256;                              // destination tiles one subtile may touch
 constexpr int kSpLong = 64;   // longest cell list (source pixels whose end points share one unit cell) that is summed in raster order
 
@@ -1420,7 +1427,7 @@ __device__ __forceinline__ void sp_corners(float xv, float yv, float wmax, float
 }
 
 #ifndef OFL_SP_MINB
-#define OFL_SP_MINB 4   // blocks per CU the gather kernel's register budget is sized for (what its 39.7 KB of LDS allow)
+#define OFL_SP_MINB 4   // waves per SIMD the gather kernel's register budget is sized for (4 blocks of 256 threads / 2 of 512 per CU: what its LDS allows)
 #endif
 #ifndef OFL_SP_U
 #define OFL_SP_U 1      // list entries (subtiles) per thread and step of the gather kernel's walk
@@ -1486,8 +1493,8 @@ __device__ __forceinline__ void sp_tile_setup(const SP& s, int tx, int ty, int n
     const int tid = threadIdx.x, w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
     t.n = n; t.dx0 = tx * kSpTW; t.dy0 = ty * kSpTH;
-    const int lx = tid & 15;
-    t.ly = tid >> 4;
+    const int lx = tid % (kSpTW / 2);                                // (pairs of pixels along a row of the tile)
+    t.ly = tid / (kSpTW / 2);
     const int x2 = min(t.dx0 + lx * 2, w - 2), y = t.dy0 + t.ly;     // (odd widths: the last pair re-computes pixel w - 2)
     t.lx2 = x2 - t.dx0;                                              // tile-local column of the pair (may be lx * 2 - 1)
     t.solo = t.lx2 < 0;
@@ -1708,7 +1715,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     // the first 32 entries of the list are fetched WITH its length (the list has a fixed address and kBinCap slots: entries
     // past the length are stale ids that are never used): one round trip for the list, one for the end points, one for the data
     const uint32_t pre[2] = {lst[tid / kSubLanes], lst[kHalf + tid / kSubLanes]};
-    const int nlist = min(p.cnt[tile], kBinCap);
+#ifndef OFL_SP_ABL
+#define OFL_SP_ABL 0             // measurement-only builds (wrong outputs): 1 no scan at all, 2 scan loads + end points only, 3 no phase C, 4 no phases S and C
+#endif
+    const int nlist = OFL_SP_ABL == 1 ? 0 : min(p.cnt[tile], kBinCap);
     OFL_OPAQUE_S(pp);
     SpTile t;
     sp_tile_setup<TF>(s, tx, ty, n, t);
@@ -1796,6 +1806,13 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
                 if (inb[u]) sp_load_data<NC, MCH, TF>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
             }
+            if (OFL_SP_ABL == 2) {       // keep the loads alive without the hit test / records
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { asm volatile("" :: "v"(q[u].x[0]), "v"(q[u].y[3]), "v"(q[u].on), "v"(mc4[u]));
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) asm volatile("" :: "v"(dat[u][c][0]), "v"(dat[u][c][3])); }
+                continue;
+            }
             process(q[0], sx4[0], sy[0], dat[0], mc4[0], r0, r1);
             if (two) process(q[1], sx4[1], sy[1], dat[1], mc4[1], r0, r1);
         }
@@ -1803,7 +1820,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     using std::integral_constant;
     // bands of destination rows: 1 when every record fits the LDS; decided from the number of records the whole tile wants
     int nb = 1;
-    bool over = false;
+#ifndef OFL_SP_FORCE_FOLD
+#define OFL_SP_FORCE_FOLD 0      // 1 (measurement only): every tile on the LDS-float-atomics path -- what the in-order sums cost
+#endif
+    bool over = OFL_SP_FORCE_FOLD != 0;
     for (int attempt = 0; attempt < 2 && !over; ++attempt) {
         const int rows = kSpTH / nb;
         bool redo = false;
@@ -1848,7 +1868,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
 #pragma unroll
             for (int r = 0; r < kCellRounds; ++r) {
                 const int c = tid + r * kSpNT2;
-                if (c < kCells && ccnt[c] > 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)c;
+                if (OFL_SP_ABL != 4 && c < kCells && ccnt[c] > 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)c;
             }
             __syncthreads();
             const int nlong = lqn;
@@ -1929,7 +1949,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
-            if (mine) {
+            if (mine && OFL_SP_ABL != 3 && OFL_SP_ABL != 4) {
                 float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
                 auto clear = [&]() {
 #pragma unroll
