@@ -8,14 +8,23 @@ One "step" = one pass of the hot path over one batch of synthetic input resident
 
 on B x 1080 x 1920 fp32 per GPU (BASELINE.json configs[1]/[3]: Flow.apply + combine_flows mode 3).  Every step builds
 its `Flow` objects from the raw tensors again -- construction is the reference's validation (`isfinite().all()`,
-utils.py:98; here one fused flag reduction + one host sync per flow) -- so `value` is the streaming, validation-inclusive
-rate; the same step on pre-built (already validated, flag-cached) objects is reported as `value_cached_flow_objects`.
-The metric is Mpix/s = global batch * H * W / t_step ("warped+composed").
+utils.py:98; here one fused flag reduction whose last block hands the words to the host: one launch, one wait per flow) --
+so `value` is the streaming, validation-inclusive rate; the same step on pre-built (already validated, flag-cached) objects
+is reported as `value_cached_flow_objects`.  The metric is Mpix/s = global batch * H * W / t_step ("warped+composed").
+
+Timing: `--blocks` R blocks (default max(5, 500 / steps)) of EXACTLY `--steps` K steps each, every block bracketed by a
+barrier + `torch.cuda.synchronize()` on both sides (MAX over the ranks per block); `value` / `ms_per_step` are the MEDIAN
+block, `timing` carries min / median / max.  `roofline` is the dominant kernel (Flow.apply 't'), its average launch duration
+from HIP events on the launch stream over >= 100 launches; `traffic` comes from an earlier rocprofv3 --pmc pass of this
+command (`traffic_source` says which).  `secondary` (N = 1): the other single-GPU configurations of BASELINE.json --
+configs[1] B = 1 apply 't', configs[2] B = 16 apply 's', configs[4] per GPU (B = 16 4K fp16: switch_ref + mode 1) -- each with
+ms, algorithmic B/px and the fraction of 8 TB/s.
 
     --scaling weak   (default) B = --batch (64) PER GPU: every rank owns its own shard, no data-path collective
     --scaling strong           --batch (64) is the GLOBAL batch (BASELINE.json configs[3]): 64 / 32 / 16 / 8 per GPU at 1 / 2 / 4 / 8
 At N = 1 the line also carries `strong_scaling_probe`: the same step at the 8 elements per GPU that config 4 leaves each
 of 8 GPUs, with the per-step host overhead (wall time minus HIP-event kernel time) -- what bounds strong scaling.
+Under torch.distributed.run the process group (backend "nccl" = RCCL) is initialised at every N, also N = 1.
 
     python bench.py                       # 1 GPU, defaults finish in a couple of minutes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -185,6 +194,10 @@ def secondary_lines(ofl, dev):
     st3 = _event_ms(lambda: fs.apply(img, target_mask=tm, return_valid_area=True), 50, 2)
     line("configs[2]: B=16 1080x1920 fp32 Flow.apply 's' (forward splat, C=3, masks, valid area; sigma 8)", 16 * h * w, 35, st3,
          {"fold_tiles_on_lds_atomics": int(stats[1]), "images_on_two_pass_path": int(stats[2])})
+    fs0 = ofl.Flow(smooth_flow(16, h, w, 8.0, 1000, dev), 's', m1)
+    line("configs[2] on the flow of rounds 1-2 (sigma 8, seed 1000: profiles/r2_bench_ops_B16.txt)", 16 * h * w, 35,
+         _event_ms(lambda: fs0.apply(img, target_mask=tm, return_valid_area=True), 50, 3))
+    del fs0
     fs2 = ofl.Flow(smooth_flow(16, h, w, 2.0, 1003, dev), 's', m1)
     line("configs[2] on a smooth flow (sigma 2)", 16 * h * w, 35,
          _event_ms(lambda: fs2.apply(img, target_mask=tm, return_valid_area=True), 50, 3))
