@@ -624,10 +624,10 @@ def splat_sum(flow, data, *, flow_sign=1.0, data_sign=1.0):
     """ofl_splat_sum_f32: the weighted sums of the forward splat of data [N,C,H,W] along flow_sign * flow [N|1,2,H,W], NOT divided
     by the density (every pixel contributes) -- the transpose of the backward warp.  None for shapes the gather splat does not
     take (W < 4)."""
-    lib, dev = load_library(), device(flow, data)
     n, c, h, w = data.shape
     if w < 4 or h * w >= (1 << 24) or h >= 32768 or w >= 32768:
         return None              # frames the gather splat does not take (its own limit, utils.py:1118): the caller's atomics kernel does
+    lib, dev = load_library(), device(flow, data)
     with _on(dev):
         f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
         d = data.detach().to(dev, torch.float32).contiguous()

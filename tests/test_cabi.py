@@ -65,6 +65,31 @@ def test_argument_validation_needs_no_gpu():
     assert lib.ofl_set_option(1, 5) == -3 and lib.ofl_set_option(1, 0) == 0
 
 
+def test_round3_entry_points_reject_bad_arguments_without_a_gpu():
+    lib = _native.load_library()
+    null, one = ctypes.c_void_p(0), ctypes.c_void_p(16)
+    # frames of 2^24 pixels and more are beyond the gather splat (utils.py:1118) -- a shape error from the C ABI, and
+    # `_native.splat_sum` steps aside (None) so that the warp's backward takes its atomics kernel instead of raising
+    assert lib.ofl_splat_sum_f32(one, 0, 1.0, one, 0, 1.0, one, one, 1 << 30, one, 1, 1, 4096, 4096, null) == -2
+    import torch
+    assert _native.splat_sum(torch.zeros(1, 2, 4096, 4096), torch.zeros(1, 1, 4096, 4096)) is None
+    assert _native.splat_sum(torch.zeros(1, 2, 8, 3), torch.zeros(1, 1, 8, 3)) is None
+    # validation read-back: required pointers, threshold, 8-byte aligned host words
+    assert lib.ofl_flow_flags_host(null, 0, 0, null, 0, 1e-3, one, one, 1, 1, 4, 4, null) == -1
+    assert lib.ofl_flow_flags_host(one, 0, 0, null, 0, 0.5, one, one, 1, 1, 4, 4, null) == -3
+    assert lib.ofl_flow_flags_host(one, 0, 0, null, 0, 1e-3, one, ctypes.c_void_p(20), 1, 1, 4, 4, null) == -3
+    assert lib.ofl_flow_flags_host(one, 1, 0, null, 0, 1e-3, one, one, 1, 1, 5, 7, null) == -4          # fp16 layout the vector kernel does not take
+    assert lib.ofl_host_words_alloc(0, ctypes.byref(ctypes.c_void_p())) == -3 and lib.ofl_host_words_free(null) == 0
+    # generators
+    assert lib.ofl_flow_from_matrix_f32(null, 9, 1.0, one, 1, 4, 4, null) == -1
+    assert lib.ofl_flow_from_matrix_f32(one, 9, 0.5, one, 1, 4, 4, null) == -3
+    assert lib.ofl_flow_from_matrix_f32(one, 9, 1.0, one, 0, 4, 4, null) == -2
+    # the fallback accumulator is bounded: the pass, capped at 1 GiB
+    assert lib.ofl_splat_tiled_fallback_images(64, 5, 1080, 1920) == 25 and lib.ofl_splat_tiled_fallback_images(4, 5, 1080, 1920) == 4
+    assert lib.ofl_splat_tiled_fallback_images(16, 4, 2160, 3840) == 8 and lib.ofl_splat_tiled_fallback_images(3, 5, 16384, 16384) == 1
+    assert lib.ofl_set_option(5, -1) == -3 and lib.ofl_set_option(5, 0) == 0
+
+
 def test_no_gpu_means_loud_failure(monkeypatch):
     import torch
     if torch.cuda.is_available():
