@@ -214,13 +214,20 @@ print("RCCL_CHILD_OK")
 '''
 
 
+def _free_port() -> str:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return str(sock.getsockname()[1])
+
+
 def test_sharded_path_on_a_real_rccl_communicator(dev, tmp_path):
     """`init_process_group("nccl")`, `enable_batch_sharding()`, Flow / apply / combine_with / with_global_or /
     broadcast_operand / all_gather_batch on the HIP path against the oracle -- in a fresh child, RCCL first."""
     script = tmp_path / "rccl_child.py"
     script.write_text(_RCCL_CHILD)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run([sys.executable, str(script), ROOT, "29533"], capture_output=True, text=True, timeout=600, env=env)
+    res = subprocess.run([sys.executable, str(script), ROOT, _free_port()], capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0 and "RCCL_CHILD_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
 
 
@@ -228,7 +235,7 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank(dev):
     """bench.py's launcher path (RANK / WORLD_SIZE from the environment, init_process_group("nccl"), barriers) at N = 1."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "4",
            "--no-cpu-baseline", "--no-probe", "--no-secondary", "--blocks", "1"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
