@@ -150,6 +150,33 @@ def run_case(case, golden, device):
         else:
             out = fl.pad(a["padding"]).unpad(a["padding"])
         return {"vecs": out.vecs, "mask": out.mask, "_ref": out.ref}
+    if op == 'raises':
+        try:
+            _bad_call(a["fn"], [list(x) if isinstance(x, list) else x for x in a["args"]], d)
+        except Exception as exc:  # noqa: BLE001
+            return {"_raised": type(exc).__name__, "_message": str(exc)}
+        return {"_raised": None, "_message": None}
+    if op == 'Flow.binop':
+        fl = _flow(i, "f", "m", a["ref"], d)
+        operand = a["operand"] if "operand" not in i else (np.asarray(i["operand"]) if a.get("numpy") else T(i["operand"], d))
+        out = {'div': lambda x, y: x / y, 'pow': lambda x, y: x ** y, 'mul': lambda x, y: x * y}[a["op"]](fl, operand)
+        return {"vecs": out.vecs, "mask": out.mask}
+    if op in ('Flow.select', 'Flow.getitem', 'Flow.copy'):
+        fl = _flow(i, "f", "m", a["ref"], d)
+        if op == 'Flow.select':
+            out = fl.select(a["item"])
+        elif op == 'Flow.getitem':
+            out = fl[tuple(slice(*it) if isinstance(it, list) else slice(None) for it in a["item"])]
+        else:
+            out = fl.copy()
+            head = str(out)
+            assert head[:head.index(';')].replace(str(out.device), 'cpu') == a["str"], (head, a["str"])
+            assert (out.vecs.data_ptr() == fl.vecs.data_ptr()) == a["aliases"]
+        return {"vecs": out.vecs, "mask": out.mask}
+    if op == 'batch_flows':
+        f, m = T(i["f"], d), T(i["m"], d)
+        out = ofl.batch_flows([Flow(f[:1], a["ref"], m[:1]), Flow(f, a["ref"], m), Flow(f[1:], a["ref"])])
+        return {"vecs": out.vecs, "mask": out.mask}
     if op.startswith('grad_'):
         return run_grad_case(case, golden, device)
     if op == 'kat_gfud':
@@ -169,6 +196,41 @@ def run_case(case, golden, device):
             out = fields[a["self"]].combine_with(fields[a["flow"]], a["mode"])
         return {"_vec": out.vecs, "_mask": out.mask}
     raise KeyError(op)
+
+
+def _bad_call(fn, args, d):
+    """One row of tests/golden/gen_golden.py's BAD_CALLS, against this package (same calls the reference was given)."""
+    f = Flow(torch.ones(2, 2, 12, 16, device=d), 't')
+    if fn == 'from_transforms':
+        return ofl.from_transforms(*[([list(t) if isinstance(t, list) else t for t in x] if isinstance(x, list) and k == 0 else x)
+                                     for k, x in enumerate(args)])
+    if fn == 'from_matrix_eye':
+        return ofl.from_matrix(torch.eye(3), *args)
+    if fn == 'resize_flow_f':
+        return ofl.resize_flow(f.vecs, *args)
+    if fn == 'flow_pad':
+        return f.pad(*args)
+    if fn == 'flow_unpad':
+        return f.unpad(*args)
+    if fn == 'flow_mul':
+        return f * args[0]
+    if fn == 'flow_div':
+        return f / args[0]
+    if fn == 'flow_pow':
+        return f ** args[0]
+    if fn == 'flow_select':
+        return f.select(*args)
+    if fn == 'flow_apply_kw':
+        return f.apply(torch.zeros(2, 1, 12, 16, device=d), **args[0])
+    if fn == 'flow_combine_with':
+        return f.combine_with(Flow(torch.ones(2, 2, 12, 16, device=d) * 2, 't'), *args)
+    if fn == 'flow_switch_ref':
+        return f.switch_ref(*args)
+    if fn == 'flow_invert':
+        return f.invert(*args)
+    if fn == 'flow_is_zero':
+        return f.is_zero(*args)
+    raise KeyError(fn)
 
 
 def run_grad_case(case, golden, device):
@@ -251,6 +313,10 @@ def check_case(case, golden, got, exact_values=True, rtol=0.0, atol=0.0, max_mas
         return report
     if "raises" in a and a["raises"]:
         assert got["_raised"] == a["raises"], (got["_raised"], a["raises"])
+        return report
+    if op == 'raises':                                       # the exception class AND the reference's message
+        assert got["_raised"] == a["exception"], (a["fn"], a["args"], got["_raised"], a["exception"])
+        assert got["_message"] == a["message"], (got["_message"], a["message"])
         return report
     if op in ('Flow.get_padding', 'get_flow_padding'):
         assert got["_padding"] == a["padding"], (got["_padding"], a["padding"])

@@ -799,12 +799,147 @@ def gen_generators():
         {"vecs": out.vecs, "mask": out.mask})
 
 
+# ------------------------------------------------------------------------------------------------
+# group: contract  (SURVEY.md 8b "error conventions": what the reference RAISES, class and message, for a table of bad calls;
+#   plus the remaining Flow operators / accessors: / ** with scalars, lists and arrays, select, __getitem__, batch_flows)
+# ------------------------------------------------------------------------------------------------
+BAD_CALLS = [
+    # (id, function, positional args as JSON)
+    ('ft_not_list', 'from_transforms', ['test', [20, 30], 't']),
+    ('ft_item_not_list', 'from_transforms', [['test'], [20, 30], 't']),
+    ('ft_rotation_missing', 'from_transforms', [[['translation', 20, 10], ['rotation']], [20, 30], 't']),
+    ('ft_rotation_incomplete', 'from_transforms', [[['translation', 20, 10], ['rotation', 1]], [20, 30], 't']),
+    ('ft_rotation_invalid', 'from_transforms', [[['translation', 20, 10], ['rotation', 1, 'test', 10]], [20, 30], 't']),
+    ('ft_translation_missing', 'from_transforms', [[['translation', 20, 10], ['translation']], [20, 30], 't']),
+    ('ft_translation_incomplete', 'from_transforms', [[['translation', 20, 10], ['translation', 1]], [20, 30], 't']),
+    ('ft_translation_invalid', 'from_transforms', [[['translation', 20, 10], ['translation', 1, 'test']], [20, 30], 't']),
+    ('ft_scaling_missing', 'from_transforms', [[['translation', 20, 10], ['scaling']], [20, 30], 't']),
+    ('ft_scaling_incomplete', 'from_transforms', [[['translation', 20, 10], ['scaling', 1]], [20, 30], 't']),
+    ('ft_scaling_invalid', 'from_transforms', [[['translation', 20, 10], ['scaling', 1, 'test', 2]], [20, 30], 't']),
+    ('ft_unknown', 'from_transforms', [[['shear', 1, 2]], [20, 30], 't']),
+    ('ft_bad_ref', 'from_transforms', [[['translation', 1, 2]], [20, 30], 'x']),
+    ('ft_ref_type', 'from_transforms', [[['translation', 1, 2]], [20, 30], 3]),
+    ('ft_bad_padding_type', 'from_transforms', [[['translation', 1, 2]], [20, 30], 't', 'pad']),
+    ('ft_bad_padding_len', 'from_transforms', [[['translation', 1, 2]], [20, 30], 't', [1, 2, 3]]),
+    ('ft_bad_padding_neg', 'from_transforms', [[['translation', 1, 2]], [20, 30], 't', [1, 2, 3, -4]]),
+    ('ft_batched_shape', 'from_transforms', [[['translation', 1, 2]], [2, 20, 30], 's']),
+    ('ft_bad_shape', 'from_transforms', [[['translation', 1, 2]], [20, 30, 4, 5], 's']),
+    ('fm_shape_type', 'from_matrix_eye', ['shape', 't']),
+    ('fm_shape_len', 'from_matrix_eye', [[10], 't']),
+    ('fm_shape_neg', 'from_matrix_eye', [[10, -3], 't']),
+    ('fm_shape_batched', 'from_matrix_eye', [[2, 10, 10], 't']),
+    ('fm_inverse_type', 'from_matrix_eye', [[10, 10], 't', 'yes']),
+    ('fm_inverse_with_s', 'from_matrix_eye', [[10, 10], 's', True]),
+    ('rf_scale_type', 'resize_flow_f', ['test']),
+    ('rf_scale_values', 'resize_flow_f', [['test', 0]]),
+    ('rf_scale_len', 'resize_flow_f', [[1, 2, 3]]),
+    ('rf_scale_zero', 'resize_flow_f', [0]),
+    ('rf_scale_neg', 'resize_flow_f', [-0.1]),
+    ('pad_mode', 'flow_pad', [[1, 1, 1, 1], 'wrap']),
+    ('pad_type', 'flow_pad', ['pad', None]),
+    ('pad_len', 'flow_pad', [[1, 2, 3], None]),
+    ('pad_float', 'flow_pad', [[1, 2, 3, 4.0], None]),
+    ('pad_neg', 'flow_pad', [[1, 2, 3, -4], None]),
+    ('unpad_too_much', 'flow_unpad', [[10, 10, 0, 0]]),
+    ('mul_list_len', 'flow_mul', [[1, 2, 3]]),
+    ('mul_str', 'flow_mul', ['two']),
+    ('div_list_len', 'flow_div', [[1, 2, 3]]),
+    ('pow_str', 'flow_pow', ['two']),
+    ('select_type', 'flow_select', ['0']),
+    ('select_range', 'flow_select', [5]),
+    ('apply_valid_type', 'flow_apply_kw', [{"return_valid_area": 1}]),
+    ('apply_consider_type', 'flow_apply_kw', [{"consider_mask": 'yes'}]),
+    ('apply_cut_type', 'flow_apply_kw', [{"cut": 0}]),
+    ('apply_padding_mismatch', 'flow_apply_kw', [{"padding": [1, 1, 1, 1]}]),
+    ('combine_mode', 'flow_combine_with', [4]),
+    ('combine_thresholded', 'flow_combine_with', [3, 'no']),
+    ('switch_ref_mode', 'flow_switch_ref', ['maybe']),
+    ('invert_ref', 'flow_invert', ['x']),
+    ('is_zero_masked', 'flow_is_zero', [None, 'x']),
+    ('is_zero_thresholded', 'flow_is_zero', [1, None]),
+]
+
+
+def bad_call(mod, flow_cls, utils_mod, fn, args):
+    """Run one row of BAD_CALLS against a package (the reference here, the build in tests/case_runner.py)."""
+    f = flow_cls(torch.ones(2, 2, 12, 16), 't')
+    if fn == 'from_transforms':
+        return utils_mod.from_transforms(*[([list(t) if isinstance(t, list) else t for t in a] if isinstance(a, list) and i == 0 else a)
+                                           for i, a in enumerate(args)])
+    if fn == 'from_matrix_eye':
+        return utils_mod.from_matrix(torch.eye(3), *args)
+    if fn == 'resize_flow_f':
+        return utils_mod.resize_flow(f.vecs, *args)
+    if fn == 'flow_pad':
+        return f.pad(*args)
+    if fn == 'flow_unpad':
+        return f.unpad(*args)
+    if fn == 'flow_mul':
+        return f * args[0]
+    if fn == 'flow_div':
+        return f / args[0]
+    if fn == 'flow_pow':
+        return f ** args[0]
+    if fn == 'flow_select':
+        return f.select(*args)
+    if fn == 'flow_apply_kw':
+        return f.apply(torch.zeros(2, 1, 12, 16), **args[0])
+    if fn == 'flow_combine_with':
+        return f.combine_with(flow_cls(torch.ones(2, 2, 12, 16) * 2, 't'), *args)
+    if fn == 'flow_switch_ref':
+        return f.switch_ref(*args)
+    if fn == 'flow_invert':
+        return f.invert(*args)
+    if fn == 'flow_is_zero':
+        return f.is_zero(*args)
+    raise KeyError(fn)
+
+
+def gen_contract():
+    g = 'contract'
+    for cid, fn, args in BAD_CALLS:
+        try:
+            bad_call(of, Flow, ofu, fn, json.loads(json.dumps(args)))
+            got = None
+        except Exception as exc:  # noqa: BLE001
+            got = [type(exc).__name__, str(exc)]
+        assert got is not None, cid
+        rec(g, 'raises_' + cid, 'raises', {"fn": fn, "args": args, "exception": got[0], "message": got[1]}, {}, {})
+    # operators and accessors with tensors behind them
+    h, w = 12, 16
+    f = smooth_flow(2, h, w, 2.0, 601)
+    m = hole_mask(2, h, w, 61)
+    fl = Flow(f, 't', m)
+    arr = (torch.rand(2, 2, h, w, generator=torch.Generator().manual_seed(62)) + 0.5)
+    for name, op, operand in (('div_scalar', 'div', 2.5), ('div_list', 'div', [2.0, -4.0]), ('div_hw', 'div', arr[0, 0]),
+                              ('div_2hw', 'div', arr[0]), ('div_hw2', 'div', arr[0].permute(1, 2, 0).contiguous()), ('div_n2hw', 'div', arr),
+                              ('pow_scalar', 'pow', 2), ('pow_list', 'pow', [2, 3]), ('pow_2hw', 'pow', torch.round(arr[0] * 2)),
+                              ('mul_list', 'mul', [2.0, -0.5]), ('mul_hw', 'mul', arr[0, 0]), ('mul_n2hw', 'mul', arr),
+                              ('mul_numpy', 'mul', arr[0].numpy())):
+        out = {'div': lambda a, b: a / b, 'pow': lambda a, b: a ** b, 'mul': lambda a, b: a * b}[op](fl, operand)
+        is_arr = isinstance(operand, (torch.Tensor, np.ndarray))
+        rec(g, 'flow_' + name, 'Flow.binop', {"ref": 't', "op": op, "operand": None if is_arr else operand,
+                                              "numpy": isinstance(operand, np.ndarray)},
+            {"f": f, "m": m, **({"operand": operand} if is_arr else {})}, {"vecs": out.vecs, "mask": out.mask})
+    out = fl.select(1)
+    rec(g, 'flow_select_1', 'Flow.select', {"ref": 't', "item": 1}, {"f": f, "m": m}, {"vecs": out.vecs, "mask": out.mask})
+    for name, item in (('rows', [[2, 9, None], None]), ('window', [[1, 10, 2], [3, 14, None]]), ('cols', [None, [4, 12, None]])):
+        idx = tuple(slice(*i) if isinstance(i, list) else (slice(None) if i is None else i) for i in item)
+        out = fl[idx]
+        rec(g, 'flow_getitem_' + name, 'Flow.getitem', {"ref": 't', "item": item}, {"f": f, "m": m}, {"vecs": out.vecs, "mask": out.mask})
+    b = of.batch_flows([Flow(f[:1], 's', m[:1]), Flow(f, 's', m), Flow(f[1:], 's')])
+    rec(g, 'batch_flows', 'batch_flows', {"ref": 's'}, {"f": f, "m": m}, {"vecs": b.vecs, "mask": b.mask})
+    c = fl.copy()
+    rec(g, 'flow_copy_str', 'Flow.copy', {"ref": 't', "str": str(c)[:str(c).index(';')], "aliases": bool(c.vecs.data_ptr() == fl.vecs.data_ptr())},
+        {"f": f, "m": m}, {"vecs": c.vecs, "mask": c.mask})
+
+
 def main():
     """`gen_golden.py` regenerates everything; `gen_golden.py --groups gen ...` only the named groups (the other groups' npz
     files and manifest entries stay as they are, byte for byte)."""
     of.set_pure_pytorch()
     gens = {'prims': gen_prims, 'flow_apply': gen_flow_apply, 'flow_ops': gen_flow_ops, 'kats': gen_kats, 'next': gen_next,
-            'grads': gen_grads, 'gen': gen_generators}
+            'grads': gen_grads, 'gen': gen_generators, 'contract': gen_contract}
     only = sys.argv[sys.argv.index('--groups') + 1:] if '--groups' in sys.argv else list(gens)
     for name in only:
         gens[name]()
