@@ -446,8 +446,13 @@ class Flow(object):
         return self._result_of(self._vecs * o)
 
     def __truediv__(self, other) -> FlowAlias:
-        """flow_class.py:582-629"""
-        return self._result_of(self._vecs / self._scalar_or_field(other, "dividing", "Divisor"))
+        """flow_class.py:582-629.  A Python-number divisor is handed to ATen as a DEVICE scalar tensor: with a host scalar
+        ATen's GPU kernel multiplies by the reciprocal instead of dividing, which differs from the reference's (CPU) quotient
+        in the last bit for a third of the values; tensor / tensor is the correctly rounded division on either device."""
+        o = self._scalar_or_field(other, "dividing", "Divisor")
+        if isinstance(o, float) and self._vecs.device.type == 'cuda':
+            o = torch.tensor(o, dtype=self._vecs.dtype, device=self._vecs.device)
+        return self._result_of(self._vecs / o)
 
     def __pow__(self, other) -> FlowAlias:
         """flow_class.py:631-678"""

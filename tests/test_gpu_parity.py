@@ -58,7 +58,13 @@ def dev():
 def test_golden_case_gpu(cid, golden, dev):
     case = golden.cases[cid]
     got = case_runner.run_case(case, golden, dev)
-    if case["op"] == 'Flow.get_padding' or case["op"].startswith('grad_'):
+    if case["op"] == 'Flow.binop' and case["args"]["op"] == 'pow':
+        # `vecs ** exponent` is ATen's own pow on the flow's device in the reference as well (flow_class.py:631-678); its GPU
+        # kernel is not the CPU's libm pow: 1e-6 of the scale (fp32 tolerance, stated here), masks bit for bit
+        _, exp = golden.arrays(case)
+        scale = max(float(np.nanmax(np.abs(exp["vecs"]))), 1.0)
+        case_runner.check_case(case, golden, got, exact_values=False, rtol=2e-6, atol=1e-6 * scale, max_mask_flips=0)
+    elif case["op"] == 'Flow.get_padding' or case["op"].startswith('grad_'):
         # padding lists: exact; gradients: within case_runner.GRAD_RTOL of the gradient scale (forward values and masks
         # recorded with them: bit-exact)
         case_runner.check_case(case, golden, got, exact_values=True)
