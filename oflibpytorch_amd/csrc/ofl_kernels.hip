@@ -445,7 +445,12 @@ __device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb
             // 24-bit multiplies (full rate): i < 2^9, inv <= 2^20, rows and columns < 2^13, h * w < 2^24
             const uint32_t r = __umul24(i, inv) >> 20, c4 = i - __umul24(r, (uint32_t)B.cw);
             const int y = B.miny + (int)r + lds_shear(B.cbase + (int)c4, B.sq);
-            const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h);
+#ifndef OFL_WARP_TRIMTEST
+#define OFL_WARP_TRIMTEST 0      // measurement only (wrong outputs): 1 = the first and last chunk column of every box are not staged at all, 2 = only every other row of them
+#endif
+            const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h) &&
+                            !(OFL_WARP_TRIMTEST == 1 && (c4 == 0u || c4 + 1u == (uint32_t)B.cw)) &&
+                            !(OFL_WARP_TRIMTEST == 2 && (c4 == 0u || c4 + 1u == (uint32_t)B.cw) && (r & 1u));
             const uint32_t g = on ? (uint32_t)(__mul24(y, p.w) + B.bx0) + c4 * 4u : 0u;
             S.slot[it] = on ? 1 + (int)(__umul24(r, (uint32_t)B.Pp) + c4) : -1;
             // the last chunk of a row of an image whose width is not a multiple of 4 would read past the row end (and past
@@ -520,7 +525,11 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
             const int cp0 = __mul24(xl0 & 3, cw16) + ((xl0 & ~3) << 2), cp1 = __mul24(xl1 & 3, cw16) + ((xl1 & ~3) << 2);
             const int yr = yi - B.miny;   // row in the sheared box, per tap column
             const int r0 = 16 + __mul24(yr - lds_shear(xi >> 2, B.sq), P16), r1 = 16 + __mul24(yr - lds_shear((xi + 1) >> 2, B.sq), P16);
-            const int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r1 + cp1 : 0, ok[2] ? r0 + P16 + cp0 : 0, ok[3] ? r1 + P16 + cp1 : 0};
+            int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r1 + cp1 : 0, ok[2] ? r0 + P16 + cp0 : 0, ok[3] ? r1 + P16 + cp1 : 0};
+            if (OFL_WARP_TRIMTEST == 3) {        // measurement only: conflict-free (lane-linear) tap addresses
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { asm volatile("" :: "v"(si[j])); si[j] = 16 + ((((int)threadIdx.x * 4 + j) * 16) & 0x3ff0); }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
         } else if (NC == 3) {
