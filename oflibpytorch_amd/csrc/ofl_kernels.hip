@@ -1193,6 +1193,9 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 //  subtiles spread over > 256 destination tiles takes the two-pass global-atomics path inside the same call, decided on
 //  the device, per image.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_SP_ABL
+#define OFL_SP_ABL 0             // measurement-only builds (wrong outputs): 1 no scan at all, 2 scan loads + end points only, 3 no phase C, 4 no phases S and C, 5 no output stores, 6 no valid / warped mask stores
+#endif
 #ifndef OFL_SP_TW
 #define OFL_SP_TW 32    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues)
 #endif
@@ -1597,6 +1600,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
             const f2 give = odd ? pa : pb, keep = odd ? pb : pa;
             const f2 got = {swap1(give[0]), swap1(give[1])};
             const f4 v = odd ? (f4){got[0], got[1], keep[0], keep[1]} : (f4){keep[0], keep[1], got[0], got[1]};
+            if (OFL_SP_ABL == 5) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }
             if (mine && (odd ? b_on : a_on)) { if (odd) st4o(ptrb + pq, v); else st4o(ptra + pq, v); }
         };
         float* dpl = s.density ? s.density + (int64_t)n * hw : nullptr;
@@ -1614,7 +1618,8 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
         }
         const uint32_t pw = swap1(warped2), pv = swap1(valid2);      // (every lane takes part: no DPP under divergence)
         const uint32_t w4 = warped2 | (pw << 16), v4 = valid2 | (pv << 16);
-        if (mine && !odd) {
+        if (OFL_SP_ABL == 5 || OFL_SP_ABL == 6) asm volatile("" :: "v"(w4), "v"(v4));
+        else if (mine && !odd) {
             if (s.warped) st32(s.warped + (int64_t)n * hw + pq, w4);
             if (MCH && s.valid) st32(s.valid + (int64_t)n * hw + pq, v4);
         }
@@ -1724,9 +1729,6 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     // the first 32 entries of the list are fetched WITH its length (the list has a fixed address and kBinCap slots: entries
     // past the length are stale ids that are never used): one round trip for the list, one for the end points, one for the data
     const uint32_t pre[2] = {lst[tid / kSubLanes], lst[kHalf + tid / kSubLanes]};
-#ifndef OFL_SP_ABL
-#define OFL_SP_ABL 0             // measurement-only builds (wrong outputs): 1 no scan at all, 2 scan loads + end points only, 3 no phase C, 4 no phases S and C
-#endif
     const int nlist = OFL_SP_ABL == 1 ? 0 : min(p.cnt[tile], kBinCap);
     OFL_OPAQUE_S(pp);
     SpTile t;
