@@ -41,11 +41,14 @@ class _NeverEqual(object):
 
 
 def _ver(t: torch.Tensor):
-    """Version counter of a tensor.  Inference tensors have none (reading `_version` raises) yet CAN be edited in place inside
+    """Version counter of a tensor (see below; the common case is one attribute read).  Inference tensors have none (reading `_version` raises) yet CAN be edited in place inside
     `torch.inference_mode()`: nothing tells an edited one from an untouched one, so their flag words are never cached
     across calls (a FRESH key component that compares unequal to everything -- fresh because tuple comparison short-cuts on
     identity)."""
-    return _NeverEqual() if t.is_inference() else t._version
+    try:
+        return t._version
+    except RuntimeError:          # "Inference tensors do not track version counter."
+        return _NeverEqual()
 
 
 class Flow(object):
@@ -616,8 +619,10 @@ class Flow(object):
         m_flow & m_self)."""
         if self._ref == 's' and not get_pure_pytorch():
             _griddata_unavailable("Flow.apply(ref='s')")
-        self._require_finite("Error applying flow to a target: ")
-        if self._all_zero(_native.FLAG_NZ_THR):
+        batch_flags = self._batch_flags()                                             # (one look at the cached word for both tests)
+        if batch_flags & _native.FLAG_NONFINITE:                                      # utils.py:98
+            raise ValueError("Error applying flow to a target: Input contains NaN, Inf or -Inf values")
+        if not (batch_flags & _native.FLAG_NZ_THR):
             # apply_flow's early exit (utils.py:497-498): every |component| < 1e-3 -> the target (and its mask
             # channel) pass through unchanged; batch broadcasting as in flow_class.py:895-898, 922-934
             warped = t.to(torch.float).to(self._device)
