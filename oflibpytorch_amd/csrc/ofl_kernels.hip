@@ -121,6 +121,7 @@ struct WarpParams {
     // flow_mask are fh x fw frames covering rows foy .., columns fox .. of the h x w frame; outside the window the flow is
     // zero (F.pad(mode='constant')) and the flow mask False
     int32_t fh, fw, foy, fox;
+    const int32_t* boxes;            // optional (column kernel): the staging geometry of every tile, made ahead of the launch (8 ints per tile, warp_boxes_kernel)
 };
 
 typedef const WarpParams __attribute__((address_space(4))) WarpParamsK;
@@ -344,7 +345,7 @@ __device__ __forceinline__ int lds_slope_row(const WP& p, const float* __restric
 template <int NC> struct LdsStage { int slot[kLdsIters]; f4 q[kLdsIters][NC]; uint32_t mq[kLdsIters]; };
 
 // steps 1-2 for one tile
-template <typename WP>
+template <bool BOX = true, typename WP>
 __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
                                                LdsCoords& T, LdsBox& B, int (*red)[4]) {
     constexpr int NW = kLdsNT / 64;
@@ -395,6 +396,7 @@ __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, cons
         for (int i = 0; i < 2; ++i) {
             const int k = 2 * j + i;
             T.sx[k] = sx[i]; T.sy[k] = sy[i];
+            if (!BOX) continue;
             // west / north tap as an int, clamped to [-2, size] (beyond that every tap is out of range anyway; a NaN
             // coordinate lands on 0 through the conversion and is blended with NaN weights like the reference's)
             const int xi = (int)__builtin_amdgcn_fmed3f(floorf(sx[i]), -2.0f, wf);
@@ -404,6 +406,7 @@ __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, cons
             miny = min(miny, yi - max(s0, s1)); maxy = max(maxy, yi + 1 - min(s0, s1));
         }
     }
+    if (!BOX) return;
     // block-wide box: columns and (sheared) rows fit 16 bits (checked on the host), so (x, y) pairs reduce together
     int lo = (int)(((uint32_t)minx & 0xffffu) | ((uint32_t)miny << 16)), hi = (int)(((uint32_t)maxx & 0xffffu) | ((uint32_t)maxy << 16));
     lo = wave_pk_min_dpp(lo); hi = wave_pk_max_dpp(hi);
@@ -727,7 +730,38 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
 // pixels with the same registers and the same LDS -- flow two tiles ahead, staging loads one tile ahead, stores behind.
 // GRAD: the same column pipeline computing the gradient with respect to the flow (`addend` = the upstream gradient [N,NC,H,W],
 // `dst` = [N,2,H,W]; see lds_gather_impl) -- the forward's staged boxes instead of 4 * NC scalar gathers per pixel.
-template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false>
+// the staging geometry of every tile of a launch of the column kernel, ahead of it: the same grid, the same functions
+template <int T>
+__global__ __launch_bounds__(kLdsNT) void warp_boxes_kernel(const WarpParams p, int32_t* __restrict__ out) {
+    constexpr int NW = kLdsNT / 64;
+    __shared__ int red[2][NW][4];
+    int tx, tyg, n;
+    if (!decode_tile(p, tx, tyg, n)) return;
+    const uint32_t b = blockIdx.x;
+    const uint32_t group = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int tyk = tyg * T + k;
+        if (tyk * kLdsTH >= h) break;
+        const uint32_t pix = (uint32_t)(min(tyk * kLdsTH + ly, h - 1) * w + xq);
+        const f4 u = ld4(fu + pix), v = ld4(fu + hw + pix);
+        const int sq = p.shear ? lds_slope_row(p, fu, hw, tx, tyk * kLdsTH + kLdsTH / 2) : 0;
+        LdsCoords Tc; LdsBox B;
+        lds_coords_box(p, tx, tyk, u, v, sq, Tc, B, red[k & 1]);
+        if (tid == 0) {
+            int4* o = reinterpret_cast<int4*>(out + ((size_t)group * T + k) * 8);
+            o[0] = make_int4(B.bx0, B.miny, B.cw, B.Pp);
+            o[1] = make_int4(B.bh, B.nch, B.sq, (B.fits ? 1 : 0) | (B.interior ? 2 : 0));
+        }
+    }
+}
+
+template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false, bool PREBOX = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p_by_value) {
 #if OFL_WARP_KARG
     // parameters through the kernarg segment (see OFL_OPAQUE_S at the gather splat): the ~250 bytes of WarpParams are not
@@ -778,11 +812,32 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     // the shear slope is estimated per tile (a column is too tall for one estimate); all of them up front: the scalar loads
     // must not sit between a tile's flow and its box
     int sq[T];
+    if (PREBOX) {
+        // the boxes come from a table made ahead of the launch: the first staging loads leave before the flow has arrived
+        const uint32_t b = blockIdx.x;
+        const uint32_t group = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
+        const int4* __restrict__ tb = reinterpret_cast<const int4*>(p.boxes + (size_t)group * T * 8);
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const int4 a = tb[2 * k], c = tb[2 * k + 1];
+            Bx[k].bx0 = __builtin_amdgcn_readfirstlane(a.x); Bx[k].miny = __builtin_amdgcn_readfirstlane(a.y);
+            Bx[k].cw = __builtin_amdgcn_readfirstlane(a.z); Bx[k].Pp = __builtin_amdgcn_readfirstlane(a.w);
+            Bx[k].bh = __builtin_amdgcn_readfirstlane(c.x); Bx[k].nch = __builtin_amdgcn_readfirstlane(c.y);
+            Bx[k].sq = __builtin_amdgcn_readfirstlane(c.z); Bx[k].cbase = Bx[k].bx0 >> 2;
+            const int fl = __builtin_amdgcn_readfirstlane(c.w);
+            Bx[k].fits = (fl & 1) != 0; Bx[k].interior = (fl & 2) != 0;
+            sq[k] = Bx[k].sq;
+        }
+        lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[0], S, sbb);
+        note_flags(0);
+        lds_coords_box<false>(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
+    } else {
 #pragma unroll
     for (int k = 0; k < T; ++k) sq[k] = p.shear ? lds_slope_row(p, fu, hw, tx, (tyg * T + k) * kLdsTH + kLdsTH / 2) : 0;
     note_flags(0);
     lds_coords_box(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
     lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[0], S, sbb);          // staging loads of tile 0 fly ...
+    }
     // the vmcnt queue is in order: the addend (an L2 hit when it is the flow itself) is fetched BEFORE the next tile's staging
     // loads / this tile's stores, so that waiting for it never waits for them
     // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
@@ -795,7 +850,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         const int tyk = tyg * T + k;
         const bool more = (k + 1 < T) && ((tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
         if (k + 1 < T) {
-            if (more) { note_flags(k + 1); lds_coords_box(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
+            if (more) { note_flags(k + 1); lds_coords_box<!PREBOX>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
         }
         if (k + 2 < T) load_flow(k + 2);
         lds_write<NC, VALID>(lds, Bx[k], S);
@@ -2285,6 +2340,10 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 }
 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
+#ifndef OFL_WARP_PREBOX_EXPERIMENT
+#define OFL_WARP_PREBOX_EXPERIMENT 0
+#endif
+int g_warp_prebox = 0;   // ofl_set_option(6, .), measurement builds only
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
@@ -2312,6 +2371,21 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     if (kLdsT > 2 && !add && !p.flow_flags) {              // a plain warp (Flow.apply 't' of an image or a flow): columns of kLdsT tiles
         WarpParams q = p;
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+#if OFL_WARP_PREBOX_EXPERIMENT
+        if (g_warp_prebox) {                                // measurement: boxes from a pre-pass (its time is the validation pass's to carry)
+            constexpr int TT = (kLdsT > 2 ? kLdsT : 3);
+            static int32_t* table = nullptr; static size_t cap = 0;
+            const size_t need = (size_t)g * TT * 8 * sizeof(int32_t);
+            if (need > cap) { if (table) (void)hipFree(table); if (hipMalloc(&table, need) != hipSuccess) return OFL_E_ARG; cap = need; }
+            hipLaunchKernelGGL((warp_boxes_kernel<TT>), dim3(g), dim3(kLdsNT), 0, st, q, table);
+            q.boxes = table;
+            if (g_warp_prebox == 2) { q.boxes = nullptr; goto product; }     // (the pre-pass beside the product kernel: its own time)
+            if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            return (int)hipGetLastError();
+        }
+        product:
+#endif
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
@@ -2447,6 +2521,9 @@ __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t v
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }
+#if OFL_WARP_PREBOX_EXPERIMENT
+    if (key == 6) { g_warp_prebox = value; return OFL_OK; }
+#endif
     return OFL_E_ARG;
 }
 
@@ -2464,6 +2541,7 @@ static int warp_bwd_impl(
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
     if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     WarpParams p;
+    p.boxes = nullptr;
     p.flow = flow; p.flow_bs = flow_bs; p.src = src; p.src_bs = src_bs;
     p.src_b = nullptr; p.src_b_bs = 0;
     p.src_mask = src_mask; p.src_mask_bs = src_mask_bs; p.flow_mask = flow_mask; p.flow_mask_bs = flow_mask_bs;
