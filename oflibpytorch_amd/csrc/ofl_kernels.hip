@@ -842,7 +842,10 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     // loads / this tile's stores, so that waiting for it never waits for them
     // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
     constexpr bool EARLY = ADD && NC <= 2;
-    const bool reuse = EARLY && NC == 2 && p.add_is_flow;                 // block-uniform
+#ifndef OFL_WARP_NOREUSE
+#define OFL_WARP_NOREUSE 0      // measurement only: the column kernel fetches the addend again (an L2 hit) instead of holding the flow registers
+#endif
+    const bool reuse = !OFL_WARP_NOREUSE && EARLY && NC == 2 && p.add_is_flow;                 // block-uniform
     int dflags = 0;
 #pragma unroll
     for (int k = 0; k < T; ++k) {
