@@ -188,6 +188,34 @@ def test_config5_at_its_per_gpu_batch(dev):
     assert torch.equal(big_b.vecs, rep(small_b.vecs)) and torch.equal(big_b.mask, rep(small_b.mask))
 
 
+def test_config5_unsharded_batch_of_128(dev):
+    """BASELINE.json configs[4] NOT sharded: B = 128, 2160 x 3840, flows stored in fp16, on ONE GPU (2.1 * 10^9 flow values per
+    operand: element offsets pass 2^31, the splat runs in several passes).  64 copies of two frames must repeat the B = 2
+    results bit for bit through `switch_ref` 's' -> 't' and `combine_with` mode 1."""
+    import bench
+    import oflibpytorch_amd as ofl
+    h, w = 2160, 3840
+    f1 = bench.smooth_flow(2, h, w, 2.0, 7000, dev).half()
+    f2 = bench.smooth_flow(2, h, w, 8.0, 5000, dev).half()
+    m1 = torch.ones(2, h, w, dtype=torch.bool, device=dev)
+    m1[:, 300:500, 1000:2500] = False
+    m2 = torch.ones(2, h, w, dtype=torch.bool, device=dev)
+    m2[1, 1500:1550] = False
+    rep = lambda x: x.repeat((64,) + (1,) * (x.dim() - 1))
+    small_a = ofl.Flow(f1, 's', m1).switch_ref()
+    small_b = small_a.combine_with(ofl.Flow(f2, 't', m2), 1)
+    big_a = ofl.Flow(rep(f1), 's', rep(m1)).switch_ref()
+    assert big_a.vecs.shape[0] == 128 and big_a.ref == 't'
+
+    def same(big, small):                     # (compared in slices: no second 8 GB tensor)
+        return all(torch.equal(big[i:i + 2], small) for i in range(0, big.shape[0], 2))
+    assert same(big_a.vecs, small_a.vecs) and same(big_a.mask, small_a.mask)
+    big_b = big_a.combine_with(ofl.Flow(rep(f2), 't', rep(m2)), 1)
+    assert same(big_b.vecs, small_b.vecs) and same(big_b.mask, small_b.mask)
+    del big_a, big_b
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("size", [(300, 400), (1080, 1920)])
 def test_uint8_warp_against_the_oracle(size, dev):
     """ofl_warp_bwd_u8 against the ORACLE (not against the float kernel): round-half-even + clamp of oracle.G on the
