@@ -243,6 +243,7 @@ _HOST_WORDS = 1 << 12        # flag words one call can hand over (larger batches
 _WORK_EXTRA = 33             # OFL_FLAGS_HOST_WORK_EXTRA
 _host_slots = {}             # device index -> [lock, device work words, host address, int32 view of the host {serial, word} pairs, last serial]
 _host_slots_lock = threading.Lock()
+_SPIN_BEFORE_YIELD = 20000   # ~ 5 ms of tight polling (a reduction takes 20 - 250 us), then the wait yields between looks
 HOST_POLL_SECONDS = 20.0     # a reduction that has not reported after this long is a failed launch, not a slow one
 
 
@@ -301,6 +302,8 @@ def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):
             spins, t0 = 0, None
             while not (view[2 * n - 2] == serial and (n == 1 or bool((tags == serial).all()))):
                 spins += 1                 # (the GPU is busy with the reduction itself for most of this wait)
+                if spins > _SPIN_BEFORE_YIELD:
+                    time.sleep(5e-5)       # a stream with milliseconds of work queued in front: stop holding the GIL and a core
                 if spins & 0xfff == 0:
                     if t0 is None:
                         t0 = time.perf_counter()
