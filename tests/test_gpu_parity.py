@@ -910,3 +910,43 @@ def test_splat_sum_is_the_unnormalised_splat_bit_for_bit(shape, dev):
         st = _native._last_splat_stats.cpu().tolist()
         assert st[0] == 0 and st[1] == 0
         assert np.array_equal(got.cpu().numpy(), _splat_sum_reference(flow.cpu().numpy(), data.numpy(), fs, ds))
+
+
+@pytest.mark.parametrize("case", ["apply", "apply_novalid", "mode3", "bcast_src", "bcast_flow", "sign"])
+def test_lean_binding_equals_the_general_one(case):
+    """`_native._warp_bwd_lean` (the short host path of the plain fp32 warp: Flow.apply 't', combine_with) hands the C ABI the same
+    arguments as `_warp_bwd_raw`: same results, bit for bit, incl. batch broadcasts of either operand and the addend / sign epilogue."""
+    import torch
+    from oflibpytorch_amd import _native
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(91)
+    n, c, h, w = 3, 3, 70, 100
+    flow = (torch.randn(n, 2, h, w, generator=g) * 4).to(dev)
+    src = torch.rand(n, c, h, w, generator=g).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    fm = (torch.rand(n, h, w, generator=g) > 0.2).to(dev)
+    kw = dict(src_mask=sm, flow_mask=fm, want_valid=True)
+    if case == "apply_novalid":
+        kw = dict(src_mask=None, flow_mask=None, want_valid=False)
+    elif case == "mode3":
+        src = (torch.randn(n, 2, h, w, generator=g) * 3).to(dev)
+        kw.update(addend=flow, a_sign=1.0, g_sign=1.0)
+    elif case == "bcast_src":
+        src, kw["src_mask"] = src[:1].contiguous(), sm[:1].contiguous()
+    elif case == "bcast_flow":
+        flow, kw["flow_mask"] = flow[:1].contiguous(), fm[:1].contiguous()
+    elif case == "sign":
+        src = (torch.randn(n, 2, h, w, generator=g) * 3).to(dev)
+        kw.update(flow_sign=-1.0, addend=src, a_sign=-1.0, g_sign=1.0)
+    lean = _native._warp_bwd_lean(flow, src, **kw)
+    assert lean is not None, "the plain contiguous fp32 call must take the short path"
+    with torch.cuda.device(dev):
+        full = _native._warp_bwd_raw(flow, src, **kw)
+    for a, b in zip(lean, full):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.shape == b.shape and a.dtype == b.dtype
+            assert torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())
+    # and the calls it must leave to the general path
+    assert _native._warp_bwd_lean(flow, src, round_mode=_native.ROUND_U8, **kw) is None
+    assert _native._warp_bwd_lean(flow.transpose(2, 3).contiguous().transpose(2, 3), src, **kw) is None
