@@ -430,6 +430,17 @@ int ofl_flow_extents_f32(const float* flow, int64_t flow_bs, const uint8_t* mask
                          int32_t* workspace, float* extents, int32_t n, int32_t h, int32_t w, void* stream);
 
 /*
+ * Valid area of a backward warp -- Flow.valid_target of a 't' flow (flow_class.py:1119-1122) and Flow.valid_source of an 's' flow
+ * (:1151-1157; flow_sign = -1 restates its `-self._vecs`):
+ *   valid[n] = (grid_sample(ones, normalise_coords(grid - flow_sign * flow[n]), align_corners=True) > thr) & mask[n]
+ * replaces torch.ones + F.grid_sample (utils.py:555) + gt + and.  The all-ones image is never made: its taps are the in-frame
+ * indicators of the four neighbours, blended by the same FMA chain -- bit-identical to warping a ones image.  mask may be NULL
+ * (all True); valid uint8 [N,H,W]; thr = 0.9999f in both callers.  9 B/px read, 1 B/px written.
+ */
+int ofl_warp_valid_f32(const float* flow, int64_t flow_bs, float flow_sign, const uint8_t* mask, int64_t mask_bs, float thr,
+                       uint8_t* valid, int32_t n, int32_t h, int32_t w, void* stream);
+
+/*
  * Flow field of a 3 x 3 transformation matrix (flow_from_matrix, utils.py:339-376; the O(HW) half of from_matrix :646-705 and
  * from_transforms :729-807, whose 3 x 3 algebra stays on the host):
  *   hom      = M [x, y, 1]^T    accumulated as ATen's CPU batched matmul does for 3 x 3 operands (acc = 0; acc += m_ik * v_k)

@@ -18,7 +18,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 26              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 27              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -26,7 +26,7 @@ _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
             "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
-            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images")
+            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32")
 _lib = None
 
 
@@ -84,6 +84,7 @@ def load_library(path: str = None):
     lib.ofl_sample_pts_f32.argtypes = [p, i64, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
+    lib.ofl_warp_valid_f32.argtypes = [p, i64, f32, p, i64, f32, p, i32, i32, i32, p]
     lib.ofl_flag_words_or_i32.argtypes = [p, i32, p, p]
     lib.ofl_splat_sum_f32.argtypes = [p, i64, f32, p, i64, f32, p, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_splat_tiled_f16.argtypes = [p, i64, f32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, i32, p, p, p, i64, p, i32, i32, i32, p]
@@ -811,6 +812,20 @@ def flow_extents(vecs, mask, sign: float) -> torch.Tensor:
         _check(lib.ofl_flow_extents_f32(_ptr(v), vbs, _ptr(m), mbs, float(sign), _ptr(ws), _ptr(ext), n, h, w, _stream(dev)),
                "ofl_flow_extents_f32")
     return ext
+
+
+def warp_valid(flow, mask, flow_sign: float = 1.0, thr: float = 0.9999) -> torch.Tensor:
+    """ofl_warp_valid_f32: (an all-ones image warped backward along flow_sign * flow > thr) & mask -> bool [N,H,W] -- the 't'
+    branch of Flow.valid_target / the 's' branch of Flow.valid_source (flow_class.py:1119-1122, 1151-1157) in one launch."""
+    lib, dev = load_library(), device(flow, mask)
+    n, _, h, w = flow.shape
+    with _on(dev):
+        f, fbs = _planes(flow.detach(), dev, torch.float32, n, "flow")
+        m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
+        out = torch.empty((n, h, w), dtype=torch.bool, device=dev)
+        _check(lib.ofl_warp_valid_f32(_ptr(f), fbs, float(flow_sign), _ptr(m), mbs, float(thr), _ptr(out), n, h, w, _stream(dev)),
+               "ofl_warp_valid_f32")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ from .utils import (get_valid_vecs, get_valid_ref, get_valid_mask, get_valid_dev
 
 FlowAlias = 'Flow'
 _VALID_THR = 0.99999   # flow_class.py:922
+_COMBINE_FUSED = True  # False (tests / tools/bench_combine.py): Flow.combine runs its plan through the public operators, one launch per operator
 
 
 class _NeverEqual(object):
@@ -734,19 +735,24 @@ class Flow(object):
             raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
         if self._ref == 's':
             return self._splat_mask_is_one(1.0, consider_mask)
-        ones = torch.ones((self.shape[0], 1) + self.shape[1:], device=self._device)
-        area = apply_flow(self._vecs, ones, 't').squeeze(1)
-        return (area > 0.9999) & self.mask
+        return self._warped_ones_valid(1.0)
 
     def valid_source(self, consider_mask: bool = None) -> torch.Tensor:
         consider_mask = True if consider_mask is None else consider_mask
         if not isinstance(consider_mask, bool):
             raise TypeError("Error applying flow: Consider_mask needs to be a boolean")
         if self._ref == 's':
-            ones = torch.ones((self.shape[0], 1) + self.shape[1:], device=self._device)
-            area = apply_flow(-self._vecs, ones, 't').squeeze(1)
-            return (area > 0.9999) & self.mask
+            return self._warped_ones_valid(-1.0)
         return self._splat_mask_is_one(-1.0, consider_mask)
+
+    def _warped_ones_valid(self, sign: float) -> torch.Tensor:
+        """(apply_flow(sign * vecs, ones, 't') > 0.9999) & mask (flow_class.py:1119-1122, 1151-1157) as ONE launch that reads the
+        flow and its mask and writes the area (`ofl_warp_valid_f32`): no all-ones image, no warped copy of it, no compare and
+        AND passes."""
+        self._require_finite("Error applying flow to a target: ")
+        if self._all_zero(_native.FLAG_NZ_THR):                      # apply_flow's early exit (utils.py:497-498): ones > 0.9999
+            return self.mask.clone()
+        return _native.warp_valid(self._vecs, self._mask, sign, 0.9999).to(self._device)
 
     def _splat_mask_is_one(self, sign: float, consider_mask: bool) -> torch.Tensor:
         """apply_flow(sign * vecs, mask.float(), 's', mask if consider_mask else None) == 1 (flow_class.py:1116-1118,
@@ -907,8 +913,11 @@ class Flow(object):
     # ------------------------------------------------------------------------------------------
     def combine(self, other: FlowAlias, mode: int, ref: str = None) -> FlowAlias:
         """flow_1 (+) flow_2 = flow_3 for two flows of equal shape and ANY references, result in reference `ref`
-        (default: that of self); `mode` names the unknown.  Table-driven over apply / invert / switch_ref exactly as
-        the reference: every step below is a fused kernel launch of this package."""
+        (default: that of self); `mode` names the unknown.  Same results as the reference (flow_class.py:1812-1939, every
+        (mode, self.ref, other.ref, ref) cell pinned by fixtures), computed from a per-cell PLAN (`_combine_plan`): at most
+        one `switch_ref`, then ONE fused launch -- the linear combination of the two fields rides the epilogue of the
+        backward gather (`a_sign * close + g_sign * G(+-close, far)`) or is formed inside the forward splat (`data - data_b`),
+        and the `invert` of the carrying flow is a sign of the kernel's sample positions / end points."""
         if not isinstance(other, Flow):
             raise TypeError("Error combining flows: Flow need to be of type 'Flow'")
         if self.shape != other.shape:
@@ -918,41 +927,99 @@ class Flow(object):
         if mode not in [1, 2, 3]:
             raise ValueError("Error combining flows: Mode needs to be 1, 2 or 3")
         ref = self._ref if ref is None else get_valid_ref(ref)
-
-        # time points 0, 1, 2: flow_1 goes 0 -> 1, flow_2 1 -> 2, flow_3 0 -> 2
-        direction = [[0, +1, +1], [-1, 0, +1], [-1, -1, 0]]
-        indices = [[1, 2], [0, 2], [0, 1]]
-        timetable = [[0, 1], [1, 2], [0, 2]]            # (source time, target time) of flow_1, flow_2, flow_3
-        r_time_list = [2, 0, 1]
-        mode -= 1
-        s_time, t_time = timetable[mode]                 # source / target time of the result
-        g_time = timetable[mode][0 if ref == 's' else 1]  # time the result is referenced in
-        r_time = r_time_list[mode]                       # the remaining time point
-        flow_ind = indices[mode]                         # which of flow_1..3 self and other are
-
-        if (mode == 0 and g_time == s_time) or (mode in [1, 2] and g_time == t_time):
-            close_input, far_input = other, self
-            flow_ind = [flow_ind[1], flow_ind[0]]
+        plan = _combine_plan(mode, self._ref, other._ref, ref)
+        close, far = (self, other) if plan.close_is_self else (other, self)
+        if plan.switch_far:                                  # the far field onto the pivot grid (a splat, or a relabel)
+            far = far.switch_ref()
+        if plan.close_on_goal:
+            result = close._carry_back_and_add(far, plan.carry_sign, plan.sign_close, plan.sign_far)
         else:
-            close_input, far_input = self, other
-        close_time = timetable[flow_ind[0]][0 if close_input.ref == 's' else 1]
-        far_time = timetable[flow_ind[1]][0 if far_input.ref == 's' else 1]
-
-        if far_time in timetable[mode]:                  # far_input is referenced "around the corner"
-            far_input = far_input.switch_ref()
-        if close_time == g_time:                         # move far_input to g_time
-            if direction[r_time][g_time] == 1:
-                far_input = close_input.apply(far_input)
-            else:
-                far_input = close_input.invert(ref='t').apply(far_input)
-        if g_time == t_time:                             # linear combination at a common time
-            result = far_input * direction[s_time][r_time] + close_input * direction[r_time][t_time]
-        else:
-            result = close_input * direction[s_time][r_time] + far_input * direction[r_time][t_time]
-        if close_time != g_time:                         # the result sits at r_time: move it to g_time
-            if direction[r_time][g_time] == 1:
-                result = close_input.apply(result)
-            else:
-                result = close_input.invert(ref='s').apply(result)
+            result = close._add_and_carry_forward(far, plan.carry_sign, plan.sign_close, plan.sign_far)
         result._ref = ref
         return result
+
+    def _carry_back_and_add(self, field: FlowAlias, carry_sign: float, sign_self: float, sign_field: float) -> FlowAlias:
+        """sign_self * self + sign_field * W(field), with W the backward warp of `field` (a flow on another grid) onto this
+        flow's grid along `self` (carry_sign +1: self is 't'-referenced) or along Flow(-self.vecs, 't') (carry_sign -1: self
+        is 's'-referenced and `invert('t')`-ed, flow_class.py:1081).  Vectors `s_self * self + s_field * G`, mask
+        `theta(G(mask channel)) & self.mask` -- the reference's apply + two scalings + add (flow_class.py:921-934, 450-488,
+        533-549), as the addend epilogue of one gather."""
+        warper_zero = self._all_zero(_native.FLAG_NZ_THR)      # apply_flow's early exit (utils.py:497-498): W is the identity
+        if warper_zero or self.shape[0] != field.shape[0] or not _COMBINE_FUSED:
+            carrier = self if carry_sign > 0 else self._negated('t')
+            return carrier.apply(field) * sign_field + self * sign_self
+        self._require_finite("Error applying flow to a target: ")
+        res = _native.warp_bwd(self._vecs, field._vecs, flow_sign=carry_sign, src_mask=field._mask, flow_mask=self._mask,
+                               want_valid=True, addend=self._vecs, a_sign=sign_self, g_sign=sign_field)
+        return Flow._wrap(res[0], self._ref, res[1], self._device)
+
+    def _add_and_carry_forward(self, field: FlowAlias, carry_sign: float, sign_self: float, sign_field: float) -> FlowAlias:
+        """P(sign_self * self + sign_field * field): the combination of two fields on one grid, carried to the other end of
+        `self` by a forward splat along `self` (carry_sign +1: self is 's'-referenced) or along Flow(-self.vecs, 's')
+        (carry_sign -1: self is 't'-referenced and `invert('s')`-ed, flow_class.py:1084).  A difference is formed inside the
+        splat (`data - data_b`, the same fp32 subtraction: a + (-b) == a - b); a sum takes one elementwise pass first."""
+        if sign_self > 0 and sign_field > 0:
+            total, minus = self + field, None
+        elif sign_self > 0:
+            total, minus = self, field                       # self - field
+        else:
+            total, minus = field, self                       # field - self
+        warper = self if carry_sign > 0 else Flow._wrap(self._fv, 's', self._mask, self._device, like=self)
+        if warper._all_zero(_native.FLAG_NZ_THR) or not get_pure_pytorch() or self.shape[0] != field.shape[0] or not _COMBINE_FUSED:
+            carrier = self if carry_sign > 0 else self._negated('s')
+            return carrier.apply(total if minus is None else total - minus)
+        tmask = total._mask if minus is None else total._and_masks(minus._mask)
+        warped, valid, dflags = warper._warp(total._fv if minus is None else total._vecs, tmask, True, True, flow_sign=carry_sign,
+                                             t_minus=None if minus is None else minus._vecs)
+        return Flow._wrap(warped, self._ref, valid, self._device, flags=dflags)
+
+
+class _CombinePlan(object):
+    """How `Flow.combine` computes one (mode, self.ref, other.ref, ref) cell."""
+    __slots__ = ("close_is_self", "switch_far", "close_on_goal", "carry_sign", "sign_close", "sign_far")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+_PLANS = {}
+
+
+def _combine_plan(mode: int, self_ref: str, other_ref: str, out_ref: str) -> _CombinePlan:
+    """The 24 plans of `Flow.combine`, derived from the geometry rather than tabulated by hand.
+
+    Three instants 0, 1, 2; flow_1 spans (0, 1), flow_2 (1, 2), flow_3 (0, 2).  A flow lives on the pixel grid of its
+    earlier instant when referenced 's', of its later one when 't'.  The unknown flow spans (a, b); the third instant is the
+    PIVOT: both known flows touch it, and the unknown is the vector sum of the hop a -> pivot and the hop pivot -> b once
+    both hops sit on one grid.  The result is wanted on the GOAL grid (a for 's', b for 't').  The known flow that touches
+    the goal is CLOSE, the other FAR.  A known flow counts +1 for a hop that runs with it (earlier -> later), -1 against it.
+      1. FAR must sit on the pivot grid: `switch_ref` if it sits on the unknown's far end instead.
+      2. CLOSE on the goal grid: FAR is carried pivot -> goal by a backward warp along CLOSE (negated when CLOSE runs
+         goal -> pivot), then the two hops are added there.   CLOSE on the pivot grid: the hops are added there, and the
+         sum is carried pivot -> goal by a forward warp along CLOSE (negated when CLOSE runs goal -> pivot)."""
+    key = (mode, self_ref, other_ref, out_ref)
+    plan = _PLANS.get(key)
+    if plan is not None:
+        return plan
+    spans = {1: (0, 1), 2: (1, 2), 3: (0, 2)}
+    a, b = spans[mode]
+    pivot = 3 - a - b
+    goal = a if out_ref == 's' else b
+    known = [k for k in (1, 2, 3) if k != mode]            # self is the lower-numbered known flow, other the higher
+    grid = lambda span, r: span[0] if r == 's' else span[1]
+    self_span, other_span = spans[known[0]], spans[known[1]]
+    close_is_self = goal in self_span
+    close_span, close_ref = (self_span, self_ref) if close_is_self else (other_span, other_ref)
+    far_span, far_ref = (other_span, other_ref) if close_is_self else (self_span, self_ref)
+    along = lambda u, v: 1.0 if u < v else -1.0           # a hop u -> v measured against a flow that runs earlier -> later
+    hop_in, hop_out = along(a, pivot), along(pivot, b)     # a -> pivot, pivot -> b
+    plan = _CombinePlan(
+        close_is_self=close_is_self,
+        switch_far=grid(far_span, far_ref) != pivot,
+        close_on_goal=grid(close_span, close_ref) == goal,
+        carry_sign=along(pivot, goal),
+        sign_close=hop_out if goal == b else hop_in,       # CLOSE spans pivot-goal: the hop that ends (starts) at the goal
+        sign_far=hop_in if goal == b else hop_out)
+    _PLANS[key] = plan
+    return plan

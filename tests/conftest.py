@@ -55,6 +55,6 @@ def oracle_native(monkeypatch):
     import oracle_backend
     from oflibpytorch_amd import _native
     for name in ("flow_flags", "warp_bwd", "splat_fwd", "device", "sample_pts", "flow_extents", "warp_bwd_win", "splat_fwd_win",
-                 "_wants_grad", "flow_from_matrix"):
+                 "_wants_grad", "flow_from_matrix", "warp_valid"):
         monkeypatch.setattr(_native, name, getattr(oracle_backend, name))
     return oracle_backend

@@ -130,6 +130,15 @@ def splat_fwd(flow, data, *, xs=None, ys=None, flow_sign=1.0, data_sign=1.0, wei
     return res
 
 
+def warp_valid(flow, mask, flow_sign=1.0, thr=0.9999):
+    f = _np(flow, np.float32) * np.float32(flow_sign)
+    ones = np.ones((f.shape[0], 1) + f.shape[2:], np.float32)
+    area = oracle.G(f, ones)[:, 0] > np.float32(thr)
+    if mask is not None:
+        area = area & _bcast(_np(mask).astype(bool), f.shape[0])
+    return torch.tensor(area)
+
+
 def sample_pts(flow, pts):
     _no_grad(flow, pts)
     return torch.tensor(oracle.sample_pts(_np(flow, np.float32), _np(pts, np.float32)))

@@ -950,3 +950,65 @@ def test_lean_binding_equals_the_general_one(case):
     # and the calls it must leave to the general path
     assert _native._warp_bwd_lean(flow, src, round_mode=_native.ROUND_U8, **kw) is None
     assert _native._warp_bwd_lean(flow.transpose(2, 3).contiguous().transpose(2, 3), src, **kw) is None
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# round 4: the valid area of a backward warp in one launch (ofl_warp_valid_f32), Flow.combine as one fused launch per cell
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 64, 128), (3, 90, 142), (1, 300, 400), (2, 1080, 1920)])
+def test_warp_valid_matches_a_warped_ones_image_and_the_oracle(shape, dev):
+    """`(G(sign * f, ones) > 0.9999) & mask` from ofl_warp_valid_f32 (no image) == the same through the warp kernel on a real
+    all-ones image == the oracle; vector (W % 4 == 0) and scalar instantiations, both signs, with and without a mask."""
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * h + w)
+    lo = torch.randn(n, 2, max(h // 20, 2), max(w // 20, 2), generator=g) * 9
+    f = torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous()
+    f[:, :, : h // 6] = 0.0                                   # an identity band: every tap weight 0 or 1
+    f[:, 0, h // 3: h // 3 + 4] = torch.round(f[:, 0, h // 3: h // 3 + 4])   # integer shifts: samples on pixel centres
+    m = torch.rand(n, h, w, generator=g) > 0.1
+    ones = torch.ones(n, 1, h, w)
+    for sign in (1.0, -1.0):
+        for mask in (m, None):
+            got = _native.warp_valid(f.to(dev), None if mask is None else mask.to(dev), sign, 0.9999).cpu().numpy()
+            via_image = _native.warp_bwd(f.to(dev), ones.to(dev), flow_sign=sign)[0][:, 0].cpu() > 0.9999
+            exp = oracle.G(f.numpy() * np.float32(sign), ones.numpy())[:, 0] > np.float32(0.9999)
+            if mask is not None:
+                via_image, exp = via_image & mask, exp & mask.numpy()
+            assert np.array_equal(got, exp), "ofl_warp_valid_f32 differs from the oracle (sign %g)" % sign
+            assert np.array_equal(got, via_image.numpy()), "ofl_warp_valid_f32 differs from the warped ones image"
+    fl = ofl.Flow(f.to(dev), 't', m.to(dev))
+    assert np.array_equal(fl.valid_target().cpu().numpy(), (oracle.G(f.numpy(), ones.numpy())[:, 0] > np.float32(0.9999)) & m.numpy())
+    fs = ofl.Flow(f.to(dev), 's', m.to(dev))
+    assert np.array_equal(fs.valid_source().cpu().numpy(), (oracle.G(-f.numpy(), ones.numpy())[:, 0] > np.float32(0.9999)) & m.numpy())
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_fused_combine_equals_the_operator_chain(mode, dev):
+    """Every (self.ref, other.ref, ref) cell of Flow.combine: the fused plan (addend epilogue of the gather / difference formed
+    inside the splat, negations as kernel signs) == the same plan through apply / * / + (one launch per operator), bit for bit,
+    and == the oracle-backed host logic's result is what tests/test_host_logic_golden.py pins on the fixtures."""
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import flow_class
+    n, h, w = 2, 150, 212
+    g = torch.Generator().manual_seed(40 + mode)
+    mk = lambda s: torch.nn.functional.interpolate(torch.randn(n, 2, 5, 6, generator=g) * s, size=(h, w), mode='bicubic', align_corners=True).contiguous()
+    f1, f2 = mk(3.0).to(dev), mk(2.0).to(dev)
+    m1 = (torch.rand(n, h, w, generator=g) > 0.05).to(dev)
+    m2 = (torch.rand(n, h, w, generator=g) > 0.05).to(dev)
+    try:
+        for sr in 'st':
+            for orf in 'st':
+                for ref in 'st':
+                    a, b = ofl.Flow(f1, sr, m1), ofl.Flow(f2, orf, m2)
+                    flow_class._COMBINE_FUSED = False
+                    chain = a.combine(b, mode, ref)
+                    flow_class._COMBINE_FUSED = True
+                    fused = a.combine(b, mode, ref)
+                    assert fused.ref == chain.ref == ref
+                    assert torch.equal(fused.mask, chain.mask), (mode, sr, orf, ref)
+                    assert torch.equal(fused.vecs, chain.vecs), (mode, sr, orf, ref)
+    finally:
+        flow_class._COMBINE_FUSED = True
