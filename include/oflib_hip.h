@@ -312,6 +312,15 @@ int ofl_flow_flags_f32(const float* flow, int64_t flow_bs,
  *               that finishes last stores, for every batch element i, the pair {host_words[2 i] = serial, host_words[2 i + 1] =
  *               flag word} with ONE 8-byte store.  The caller polls until every host_words[2 i] == serial (a value it has not
  *               used before) and reads the words beside them.
+ * Contract of the shared buffers (what the binder must enforce; oflibpytorch_amd/_native.py does it with a pool of slots):
+ *   * ONE call in flight per (work, host_words) pair -- a second launch on the same pair before the first one's words have
+ *     been seen corrupts both.  Two threads (or two streams) that validate at once need two pairs; nothing in the library
+ *     serialises them.  The last block zeroes the arrival counters with returning atomics BEFORE it publishes the first pair,
+ *     so a pair may be handed to the next call (on any stream) the moment every host_words[2 i] == serial has been read.
+ *   * The wait is a HOST poll of memory the kernel writes: it cannot be part of a stream capture / hipGraph, and the calling
+ *     thread spins (then sleeps) until the device has run the kernel.  A caller that builds graphs validates outside them
+ *     (ofl_flow_flags_f32 writes device words and captures fine).
+ *   * If the caller abandons a wait (exception, interrupt) it must synchronise the stream before it re-uses or frees the pair.
  */
 #define OFL_FLAGS_HOST_WORK_EXTRA 33
 int ofl_flow_flags_host(const void* flow, int32_t flow_is_f16, int64_t flow_bs,

@@ -240,26 +240,52 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
 
 
 # -- validation read-back: the reduction's last block writes the words to host-visible memory, the host polls them ---------------
+# A SLOT = the device work words (arrival counters + flag words) and the host-visible {serial, word} pairs of ONE call in flight.
+# Slots are pooled per device: a call takes a free one (or makes a new one, up to _MAX_SLOTS) and holds it until its words have
+# arrived, so two threads validating on one device run side by side instead of queueing behind one lock.  The
+# wait is a host poll: it cannot be recorded into a stream capture / hipGraph (documented in include/oflib_hip.h).
 _HOST_WORDS = 1 << 12        # flag words one call can hand over (larger batches take the copy + event route)
 _WORK_EXTRA = 33             # OFL_FLAGS_HOST_WORK_EXTRA
-_host_slots = {}             # device index -> [lock, device work words, host address, int32 view of the host {serial, word} pairs, last serial]
+_MAX_SLOTS = 8               # per device; a ninth concurrent caller waits for a slot
+_host_slots = {}             # device index -> list of slots [lock, device work words, host address, int32 view of the pairs, last serial]
 _host_slots_lock = threading.Lock()
-_SPIN_BEFORE_YIELD = 20000   # ~ 5 ms of tight polling (a reduction takes 20 - 250 us), then the wait yields between looks
+_SPIN_SLACK_SECONDS = 150e-6  # tight polling lasts ~2x the time the reduction's bytes take plus this; after that the wait sleeps between looks
 HOST_POLL_SECONDS = 20.0     # a reduction that has not reported after this long is a failed launch, not a slow one
 
 
-def _host_slot(lib, dev):
+def _new_host_slot(lib, dev):
+    addr = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _check(lib.ofl_host_words_alloc(2 * _HOST_WORDS, ctypes.byref(addr)), "ofl_host_words_alloc")
+        work = torch.zeros(_HOST_WORDS + _WORK_EXTRA, dtype=torch.int32, device=dev)
+    view = np.ctypeslib.as_array((ctypes.c_int32 * (2 * _HOST_WORDS)).from_address(addr.value))
+    return [threading.Lock(), work, addr, view, 0]
+
+
+def _acquire_host_slot(lib, dev):
+    """A slot nobody is using, locked.  The first slot of a device is the fast path (one non-blocking acquire)."""
+    slots = _host_slots.get(dev.index)
+    if slots is not None:
+        for slot in slots:
+            if slot[0].acquire(False):
+                return slot
     with _host_slots_lock:
-        slot = _host_slots.get(dev.index)
-        if slot is None:
-            addr = ctypes.c_void_p()
-            with torch.cuda.device(dev):
-                _check(lib.ofl_host_words_alloc(2 * _HOST_WORDS, ctypes.byref(addr)), "ofl_host_words_alloc")
-                work = torch.zeros(_HOST_WORDS + _WORK_EXTRA, dtype=torch.int32, device=dev)
-            view = np.ctypeslib.as_array((ctypes.c_int32 * (2 * _HOST_WORDS)).from_address(addr.value))
-            slot = [threading.Lock(), work, addr, view, 0]
-            _host_slots[dev.index] = slot
-    return slot
+        slots = _host_slots.setdefault(dev.index, [])
+        if len(slots) < _MAX_SLOTS:
+            slot = _new_host_slot(lib, dev)
+            slot[0].acquire()
+            slots.append(slot)
+            return slot
+    slots[0][0].acquire()
+    return slots[0]
+
+
+def _drop_host_slot(dev, slot):
+    """After a failed wait the slot's work words may be dirty: forget it (its successor starts from zeroed words)."""
+    with _host_slots_lock:
+        slots = _host_slots.get(dev.index)
+        if slots is not None and slot in slots:
+            slots.remove(slot)
 
 
 def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):
@@ -289,9 +315,9 @@ def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):
             if half and vbs == 0 and n != 1:
                 return None
             m, mbs = (None, 0) if mask is None else _planes(mask, dev, torch.bool, n, "mask")
-        slot = _host_slots.get(dev.index) or _host_slot(lib, dev)
+        slot = _acquire_host_slot(lib, dev)
         stream = torch._C._cuda_getCurrentRawStream(dev.index)
-        with slot[0]:                      # one call in flight per device: the work words and the host words are shared
+        try:
             serial = slot[4] = (slot[4] % 0x7ffffff0) + 1
             view = slot[3]
             rc = lib.ofl_flow_flags_host(v.data_ptr(), 1 if half else 0, vbs, 0 if m is None else m.data_ptr(), mbs, THRESHOLD,
@@ -299,22 +325,36 @@ def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):
             if rc == -4:
                 return None
             _check(rc, "ofl_flow_flags_host")
-            tags = view[0:2 * n:2]
-            spins, t0 = 0, None
-            while not (view[2 * n - 2] == serial and (n == 1 or bool((tags == serial).all()))):
-                spins += 1                 # (the GPU is busy with the reduction itself for most of this wait)
-                if spins > _SPIN_BEFORE_YIELD:
-                    time.sleep(5e-5)       # a stream with milliseconds of work queued in front: stop holding the GIL and a core
-                if spins & 0xfff == 0:
-                    if t0 is None:
-                        t0 = time.perf_counter()
-                    elif time.perf_counter() - t0 > HOST_POLL_SECONDS:
-                        torch.cuda.synchronize(dev)          # surfaces a launch failure as the runtime's own error
-                        if bool((tags == serial).all()):
-                            break
-                        _host_slots.pop(dev.index, None)     # (the work words may be dirty: start afresh next time)
-                        raise RuntimeError("oflibpytorch_amd: the flag reduction did not report back")
-            return view[1:2 * n:2].tolist()
+            try:
+                tags = view[0:2 * n:2]
+                # tight polling for about as long as the reduction itself can take (its bytes at ~4 TB/s, twice over, plus a
+                # slack), then sleeps between looks: a stream with milliseconds of work queued in front must not keep the GIL
+                # and a core busy, and other Python threads (data loaders) get to run
+                t0 = time.perf_counter()
+                spin_until = t0 + 2.0 * (n * h * w * (5 if half else 9)) / 4e12 + _SPIN_SLACK_SECONDS
+                looks = 0
+                while not (view[2 * n - 2] == serial and (n == 1 or bool((tags == serial).all()))):
+                    looks += 1
+                    if looks & 0x3f == 0:
+                        now = time.perf_counter()
+                        if now > spin_until:
+                            time.sleep(5e-5)
+                            if now - t0 > HOST_POLL_SECONDS:
+                                torch.cuda.synchronize(dev)          # surfaces a launch failure as the runtime's own error
+                                if bool((tags == serial).all()):
+                                    break
+                                raise RuntimeError("oflibpytorch_amd: the flag reduction did not report back")
+                return view[1:2 * n:2].tolist()
+            except BaseException:
+                # (KeyboardInterrupt included) the kernel may still be in flight on this slot's words: wait for the device, and
+                # retire the slot rather than hand possibly dirty work words to the next call
+                try:
+                    torch.cuda.synchronize(dev)
+                finally:
+                    _drop_host_slot(dev, slot)
+                raise
+        finally:
+            slot[0].release()
     finally:
         if ctx is not None:
             ctx.__exit__(None, None, None)

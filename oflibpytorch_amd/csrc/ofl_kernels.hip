@@ -2199,19 +2199,26 @@ __device__ __forceinline__ void flags_publish(int32_t* __restrict__ flags, const
         const int in_shard = (fh.total_blocks - shard + kFlagShards - 1) / kFlagShards;          // blocks whose id = shard (mod kFlagShards)
         const int shards = fh.total_blocks < kFlagShards ? fh.total_blocks : kFlagShards;        // (non-empty ones)
         int l = 0;
-        if (__hip_atomic_fetch_add(fh.counters + shard, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
-            __hip_atomic_store(fh.counters + shard, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(fh.counters + shard, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1)
             l = __hip_atomic_fetch_add(fh.counters + kFlagShards, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
-        }
         last = l;
     }
     __syncthreads();
     if (!last) return;                                            // (block-uniform)
-    for (int i = threadIdx.x; i < fh.n; i += blockDim.x) {
+    // Every block has arrived (the tickets say so), so nobody touches the counters any more: THIS block zeroes all of them,
+    // with returning atomics whose results it waits for, BEFORE the first pair goes out -- the host may hand the work words
+    // to the next call (another stream) the moment it has seen the pairs, and a reset still in flight then would eat that
+    // call's first arrivals.
+    if (threadIdx.x <= kFlagShards) {
+        const int old = __hip_atomic_exchange(fh.counters + threadIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" :: "v"(old));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the counters are zero at the memory side
+    __syncthreads();
+    for (int i = threadIdx.x; i < fh.n; i += blockDim.x) {        // (a word's store depends on its exchange: zero before it is published)
         const uint32_t v = (uint32_t)__hip_atomic_exchange(&flags[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&fh.host[i], ((unsigned long long)v << 32) | (uint32_t)fh.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(fh.counters + kFlagShards, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool VEC, bool NT = false, bool HOST = false>   // VEC: 4 pixels per thread and step (16-byte flow loads, one mask dword); needs hw % 4 == 0 and aligned planes

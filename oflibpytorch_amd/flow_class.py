@@ -41,15 +41,24 @@ class _NeverEqual(object):
     __hash__ = None
 
 
-def _ver(t: torch.Tensor):
+def _ver(t: torch.Tensor, private: bool = False):
     """Version counter of a tensor (see below; the common case is one attribute read).  Inference tensors have none (reading `_version` raises) yet CAN be edited in place inside
     `torch.inference_mode()`: nothing tells an edited one from an untouched one, so their flag words are never cached
     across calls (a FRESH key component that compares unequal to everything -- fresh because tuple comparison short-cuts on
-    identity)."""
+    identity) -- UNLESS the tensor is `private`: a kernel output that only this Flow object has ever held (nobody
+    else has a reference through which to edit it; ADVICE r3: inference_mode is the usual deployment mode, and re-running the
+    reduction for every kernel output cost a pass and a host wait per call there)."""
     try:
         return t._version
     except RuntimeError:          # "Inference tensors do not track version counter."
-        return _NeverEqual()
+        return 0 if private else _NeverEqual()
+
+
+def _storage_ptr(t):
+    try:
+        return t.untyped_storage().data_ptr()
+    except Exception:  # noqa: BLE001
+        return id(t)
 
 
 class Flow(object):
@@ -106,15 +115,23 @@ class Flow(object):
         if self._half is not None:
             self._set_pending_flags(_native.flow_flags(self._half, self._mask))     # (flags only: 5 B/px, the flow stays fp16)
 
+    _private = False     # the vectors and the mask are kernel outputs no one else holds (see _ver); cleared when they are handed out
+
     @classmethod
     def _wrap(cls, vecs: torch.Tensor, ref: str, mask, device=None, flags: torch.Tensor = None,
-              like: FlowAlias = None) -> FlowAlias:
+              like: FlowAlias = None, fresh: bool = False, made_from: tuple = None) -> FlowAlias:
         """Internal: wrap tensors that are valid by construction (kernel outputs, views of validated flows).
-        `flags` is the device-side flag word a kernel produced as a by-product, read lazily."""
+        `flags` is the device-side flag word a kernel produced as a by-product, read lazily.  `fresh`: vecs and mask were
+        allocated by the call that produced them; `made_from`: ... unless they share storage with one of these tensors (the
+        early exits hand their inputs through)."""
         obj = cls.__new__(cls)
         obj._vecs, obj._ref, obj._mask = vecs, ref, mask
         obj._device = vecs.device if device is None else device
         obj._flag_cache, obj._pending_flags = None, None
+        if made_from is not None:
+            theirs = set(_storage_ptr(t) for t in made_from if t is not None)
+            fresh = _storage_ptr(vecs) not in theirs and (mask is None or _storage_ptr(mask) not in theirs)
+        obj._private = bool(fresh)
         if obj._fv.device != obj._device:
             obj._vecs = obj._fv.to(obj._device)
         if obj._mask is not None and obj._mask.device != obj._device:
@@ -156,7 +173,7 @@ class Flow(object):
         torch.inference_mode() carry no version counter: their key never matches, i.e. every call that needs the flags of
         such a flow runs the (cheap, fused) reduction again -- an in-place edit inside inference mode must not meet a
         stale 'all zero' / 'finite' word."""
-        return (_ver(self._fv), None if self._mask is None else (id(self._mask), _ver(self._mask)))
+        return (_ver(self._fv, self._private), None if self._mask is None else (id(self._mask), _ver(self._mask, self._private)))
 
     def _flags_known(self) -> bool:
         key = self._key()
@@ -217,6 +234,7 @@ class Flow(object):
         that (the flag word carries over: the up-conversion is exact; a later in-place edit bumps the tensor's version and
         invalidates it like any other)."""
         v = self._vecs
+        self._release_private()
         if self._half is not None:
             flags = self._flag_cache[1:] if self._flags_known() else None
             pending = self._pending_flags[1] if (self._pending_flags is not None and self._pending_flags[0] == self._key()) else None
@@ -256,7 +274,13 @@ class Flow(object):
         if self._mask is None:
             self._mask = torch.ones(self.shape, dtype=torch.bool, device=self._fv.device)
             self._flag_cache = None if self._flag_cache is None else (self._key(), self._flag_cache[1])
+        self._release_private()
         return self._mask
+
+    def _release_private(self):
+        """The storage is about to be handed out: from now on somebody else can edit it in place.  Tensors that track versions
+        keep their key (an edit bumps it); an inference tensor's key stops matching, so its next use runs the reduction again."""
+        self._private = False
 
     @mask.setter
     def mask(self, input_mask=None):
@@ -573,7 +597,7 @@ class Flow(object):
             dflags = None                                # (they describe the whole padded frame)
 
         if return_flow:
-            return Flow._wrap(warped, target._ref, valid, self._device, flags=dflags)
+            return Flow._wrap(warped, target._ref, valid, self._device, flags=dflags, made_from=(t, tmask, self._mask))
         if not return_dtype.is_floating_point:
             if not get_pure_pytorch():
                 warped = warped.to(return_dtype)         # PURE_PYTORCH keeps the rounded values as floats (:943-949)
@@ -708,14 +732,14 @@ class Flow(object):
         # (-as_s).apply(as_s) with as_s = this flow read as 's' (flow_class.py:1060-1062): one splat P(-f, f||[m], m),
         # the negation folded into the kernel's end points
         warped, valid, dflags = self.switch_ref(mode='invalid')._warp(self._fv, self._mask, True, True, flow_sign=-1.0)
-        return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
+        return Flow._wrap(warped, 's', valid, self._device, flags=dflags, made_from=(self._fv, self._mask))
 
     def invert(self, ref: str = None) -> FlowAlias:
         ref = self._ref if ref is None else get_valid_ref(ref)
         if self._ref == 's':
             if ref == 's':                                      # self.apply(-self): P(f, -f||[m], m)
                 warped, valid, dflags = self._warp(self._fv, self._mask, True, True, data_sign=-1.0)
-                return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
+                return Flow._wrap(warped, 's', valid, self._device, flags=dflags, made_from=(self._fv, self._mask))
             return self._negated('t')
         if ref == 's':
             return self._negated('s')
@@ -724,7 +748,7 @@ class Flow(object):
             return self._negated('t')
         warped, valid, dflags = Flow._wrap(self._fv, 's', self._mask, self._device, like=self)._warp(
             self._fv, self._mask, True, True, flow_sign=-1.0, data_sign=-1.0)
-        return Flow._wrap(warped, 't', valid, self._device, flags=dflags)
+        return Flow._wrap(warped, 't', valid, self._device, flags=dflags, made_from=(self._fv, self._mask))
 
     # ------------------------------------------------------------------------------------------
     # valid areas (flow_class.py:1088-1172)
@@ -854,13 +878,13 @@ class Flow(object):
             if inv._all_zero(_native.FLAG_NZ_THR):
                 return inv.apply(flow - self)
             warped, valid, _ = inv._warp(flow._fv, flow._and_masks(self._mask), True, True, t_minus=self._vecs)
-            return Flow._wrap(warped, 't', valid, self._device)
+            return Flow._wrap(warped, 't', valid, self._device, made_from=(flow._fv, flow._mask, self._mask, inv._mask))
         if ref == 's':                                                               # mode 2, :1768
             # self.apply(flow - self): the difference (and the AND of the two masks) is formed inside the splat
             if self._all_zero(_native.FLAG_NZ_THR) or not get_pure_pytorch():        # (apply's early exit / griddata gate)
                 return self.apply(flow - self)
             warped, valid, dflags = self._warp(flow._vecs, flow._mask, True, True, t_minus=self._vecs)
-            return Flow._wrap(warped, 's', valid, self._device, flags=dflags)
+            return Flow._wrap(warped, 's', valid, self._device, flags=dflags, made_from=(flow._fv, flow._mask, self._mask))
         if not get_pure_pytorch():
             _griddata_unavailable("combine_with(mode=2, ref='t')")
         return flow._minus_applied(flow, self.invert().apply(self))                  # :1773  flow - flow.apply(...)
@@ -877,7 +901,7 @@ class Flow(object):
                                              want_valid=True, addend=self._vecs, a_sign=1.0, g_sign=-1.0)
         if self._mask is not None and self._mask is not warper._mask:
             valid = valid & self._mask
-        return Flow._wrap(vecs, self._ref, valid, self._device)
+        return Flow._wrap(vecs, self._ref, valid, self._device, fresh=True)
 
     def _combine3(self, flow: FlowAlias, speculative: bool = False, result_is_warper: bool = False,
                   negated_warper: bool = False) -> FlowAlias:
@@ -906,7 +930,7 @@ class Flow(object):
                 warper._set_pending_flags(wf)
             if not src._flags_known():
                 src._set_pending_flags(sf)
-        return Flow._wrap(vecs, self._ref, valid, self._device, flags=res[4] if result_is_warper else None)
+        return Flow._wrap(vecs, self._ref, valid, self._device, flags=res[4] if result_is_warper else None, fresh=True)
 
     # ------------------------------------------------------------------------------------------
     # general composition (flow_class.py:1812-1939)
@@ -951,7 +975,7 @@ class Flow(object):
         self._require_finite("Error applying flow to a target: ")
         res = _native.warp_bwd(self._vecs, field._vecs, flow_sign=carry_sign, src_mask=field._mask, flow_mask=self._mask,
                                want_valid=True, addend=self._vecs, a_sign=sign_self, g_sign=sign_field)
-        return Flow._wrap(res[0], self._ref, res[1], self._device)
+        return Flow._wrap(res[0], self._ref, res[1], self._device, fresh=True)
 
     def _add_and_carry_forward(self, field: FlowAlias, carry_sign: float, sign_self: float, sign_field: float) -> FlowAlias:
         """P(sign_self * self + sign_field * field): the combination of two fields on one grid, carried to the other end of
@@ -971,7 +995,7 @@ class Flow(object):
         tmask = total._mask if minus is None else total._and_masks(minus._mask)
         warped, valid, dflags = warper._warp(total._fv if minus is None else total._vecs, tmask, True, True, flow_sign=carry_sign,
                                              t_minus=None if minus is None else minus._vecs)
-        return Flow._wrap(warped, self._ref, valid, self._device, flags=dflags)
+        return Flow._wrap(warped, self._ref, valid, self._device, flags=dflags, made_from=(total._fv, tmask, self._mask))
 
 
 class _CombinePlan(object):

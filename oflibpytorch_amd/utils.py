@@ -288,11 +288,15 @@ def flow_from_matrix(matrix: torch.Tensor, shape: list, _sign: float = 1.0, _dev
     `_device` (internal: Flow.from_matrix / from_transforms with a HIP `device`): leave the field there instead of taking it
     to the matrix's device and back."""
     n, h, w = shape
+    if n == 1:
+        n = matrix.shape[0]          # (the reference ignores shape[0]: its matmul broadcasts the N matrices over the one grid, utils.py:364-370)
     dev = matrix.device if _device is None else _device
     if _native._wants_grad(matrix):
+        # differentiable wrt the matrix (utils.py:342): the torch expression, on the device the field is wanted on -- the
+        # matrix is MOVED there (`.to` keeps the graph; it may live on the host or on another device than `_device`)
         gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
         hom = torch.stack((gx.float().to(dev), gy.float().to(dev), torch.ones((h, w), device=dev)), dim=-1)   # H-W-3
-        moved = torch.matmul(matrix.float().expand(n, -1, -1).unsqueeze(1).unsqueeze(1), hom.unsqueeze(-1)).squeeze(-1)   # N-H-W-3
+        moved = torch.matmul(matrix.float().to(dev).expand(n, -1, -1).unsqueeze(1).unsqueeze(1), hom.unsqueeze(-1)).squeeze(-1)   # N-H-W-3
         pts = moved[..., 0:2] / moved[..., 2:3]
         out = move_axis(pts - hom[..., 0:2], -1, 1)
         return -out if _sign < 0 else out
@@ -489,63 +493,61 @@ def is_zero_flow(flow, thresholded: bool = None) -> torch.Tensor:
     return torch.tensor([(f & bit) == 0 for f in host], dtype=torch.bool, device=flow.device)
 
 
-def track_pts(flow, ref: str, pts: torch.Tensor, int_out: bool = None) -> torch.Tensor:
-    """Warp points (y, x) of shape M-2 or N-M-2 with a flow field (utils.py:941-1042).  Differentiable wrt flow and
-    pts.  's': the flow is sampled bilinearly at the points (sparse sampler kernel `ofl_sample_pts_f32`: flip ->
-    normalise_coords -> grid_sample -> flip in the reference, :1004-1014; integer points read their pixel, :998-1003);
-    't' (PURE_PYTORCH): the flow is first splatted to its own start points -- `grid_from_unstructured_data` at
-    `get_flow_endpoints(-flow, 's')`, :993-996 -- one forward-splat launch with the end points formed in-kernel."""
-    flow = get_valid_vecs(flow, error_string="Error tracking points: ", _check_finite=False)
-    flags = _host_flags(flow)
-    if any(f & _native.FLAG_NONFINITE for f in flags):                          # utils.py:98
-        raise ValueError("Error tracking points: Input contains NaN, Inf or -Inf values")
-    ref = get_valid_ref(ref)
+def _points_per_flow(pts, n_flows: int, err: str):
+    """Points handed to `track_pts` as one [N, M, 2] (y, x) tensor, one set per flow, and whether the caller passed a
+    single un-batched M-2 set (utils.py:961-978: same checks, same messages -- pinned by the `contract` fixtures)."""
     if not isinstance(pts, torch.Tensor):
-        raise TypeError("Error tracking points: Pts needs to be a numpy array or a torch tensor")
-    return_2d = False
-    if pts.dim() == 2:
-        return_2d = True
-        pts = pts.unsqueeze(0).expand(flow.shape[0], -1, -1)
-    elif pts.dim() == 3:
-        if pts.shape[0] != flow.shape[0]:
-            if pts.shape[0] == 1:
-                pts = pts.expand(flow.shape[0], -1, -1)
-            else:
-                raise ValueError("Error tracking points: "
-                                 "If used, pts batch size needs to be equal to the flow batch size")
-    else:
-        raise ValueError("Error tracking points: Pts needs to have shape M-2 or N-M-2")
-    if pts.shape[-1] != 2:
-        raise ValueError("Error tracking points: Pts needs to have shape M-2 or N-M-2")
+        raise TypeError(err + "Pts needs to be a numpy array or a torch tensor")
+    unbatched = pts.dim() == 2
+    if pts.dim() not in (2, 3):
+        raise ValueError(err + "Pts needs to have shape M-2 or N-M-2")
+    sets = pts[None] if unbatched else pts
+    if sets.shape[0] not in (1, n_flows):
+        raise ValueError(err + "If used, pts batch size needs to be equal to the flow batch size")
+    if sets.shape[-1] != 2:
+        raise ValueError(err + "Pts needs to have shape M-2 or N-M-2")
+    return sets.expand(n_flows, -1, -1), unbatched
+
+
+def track_pts(flow, ref: str, pts: torch.Tensor, int_out: bool = None) -> torch.Tensor:
+    """Where the points (y, x) of shape M-2 or N-M-2 end up under a flow field (utils.py:941-1042).  Differentiable wrt the
+    flow and the points.  The displacement of a point is the flow read AT the point's own position, so the field must live on
+    the points' grid: an 's' flow does; a 't' flow (PURE_PYTORCH) is first carried to its start points -- the reference's
+    `grid_from_unstructured_data` at `get_flow_endpoints(-flow, 's')` (:993-996), here one forward-splat launch with the end
+    points formed in the kernel.  Float points sample the field bilinearly (`ofl_sample_pts_f32`: the reference's flip ->
+    normalise_coords -> grid_sample -> flip, :1004-1014); integer points read their own pixel (:998-1003)."""
+    err = "Error tracking points: "
+    flow = get_valid_vecs(flow, error_string=err, _check_finite=False)
+    words = _host_flags(flow)
+    if any(wd & _native.FLAG_NONFINITE for wd in words):                        # utils.py:98
+        raise ValueError(err + "Input contains NaN, Inf or -Inf values")
+    ref = get_valid_ref(ref)
+    points, unbatched = _points_per_flow(pts, flow.shape[0], err)
     int_out = False if int_out is None else int_out
     if not isinstance(int_out, bool):
-        raise TypeError("Error tracking points: Int_out needs to be a boolean")
-    pts = pts.to(flow.device)
+        raise TypeError(err + "Int_out needs to be a boolean")
+    points = points.to(flow.device)
 
-    if not any(f & _native.FLAG_NZ_THR for f in flags):                         # :988-989
-        warped_pts = pts
-    else:
+    moved = points
+    if any(wd & _native.FLAG_NZ_THR for wd in words):                           # (all below the threshold: nothing moves, :988-989)
+        field = flow
         if ref == 't':
             if not get_pure_pytorch():
                 _griddata_unavailable("track_pts(ref='t')")
-            # x, y = get_flow_endpoints(-flow, 's'); flow, _ = grid_from_unstructured_data(x, y, flow)   (:993-995)
-            flow = _native.splat_fwd(flow, flow, flow_sign=-1.0, occlude=False)[0].to(flow.device)
-        if not pts.dtype.is_floating_point:                                     # :998-1003
-            flow_vecs = flow.permute(0, 2, 3, 1)
-            pts2 = pts[..., 0] * flow.shape[-1] + pts[..., 1]
-            pts2 = pts2.unsqueeze(-1).expand(-1, -1, 2)
-            flow_vecs = torch.gather(flow_vecs.reshape(flow_vecs.shape[0], -1, 2), 1, pts2.long()).flip(-1)
-            warped_pts = pts.float() + flow_vecs
-            nan_vals = torch.isnan(warped_pts)
-            warped_pts[nan_vals[:, :, 0] | nan_vals[:, :, 1]] = 0               # :1033-1035
-        else:
+            field = _native.splat_fwd(flow, flow, flow_sign=-1.0, occlude=False)[0].to(flow.device)
+        if points.dtype.is_floating_point:
             from . import _autograd
-            warped_pts = _autograd.sample_pts(flow, pts.float()).to(flow.device)   # (NaN rows are zeroed in the kernel)
+            moved = _autograd.sample_pts(field, points.float()).to(flow.device)  # (a point whose sample is NaN comes back as 0)
+        else:
+            # row-major pixel index of every point, then both planes read at once; (u, v) -> (dy, dx)
+            n, _, h, w = field.shape
+            pixel = (points[..., 0] * w + points[..., 1]).long()
+            uv = torch.gather(field.reshape(n, 2, h * w), 2, pixel[:, None, :].expand(-1, 2, -1))
+            moved = points.float() + uv.flip(1).transpose(1, 2)
+            moved = torch.where(torch.isnan(moved).any(dim=-1, keepdim=True), torch.zeros_like(moved), moved)   # :1033-1035
     if int_out:
-        warped_pts = torch.round(warped_pts).long()
-    if return_2d:
-        warped_pts = warped_pts.squeeze(0)
-    return warped_pts
+        moved = torch.round(moved).long()
+    return moved.squeeze(0) if unbatched else moved
 
 
 def get_flow_endpoints(flow: torch.Tensor, ref: str) -> tuple:

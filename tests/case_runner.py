@@ -230,6 +230,15 @@ def _bad_call(fn, args, d):
         return f.invert(*args)
     if fn == 'flow_is_zero':
         return f.is_zero(*args)
+    if fn in ('track_pts', 'flow_track'):
+        spec = args[0]
+        pts = [[1, 2], [3, 4]] if spec["pts"] == 'list' else torch.ones(*spec["pts"], device=d)
+        if fn == 'flow_track':
+            return f.track(pts, **{k: v for k, v in spec.items() if k != 'pts'})
+        vecs = torch.ones(*spec.get("flow_shape", [2, 2, 12, 16]), device=d)
+        if spec.get("nan"):
+            vecs[0, 0, 0, 0] = float('nan')
+        return ofl.track_pts(vecs, spec["ref"], pts, *([spec["int_out"]] if "int_out" in spec else []))
     raise KeyError(fn)
 
 

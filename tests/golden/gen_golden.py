@@ -857,6 +857,20 @@ BAD_CALLS = [
     ('invert_ref', 'flow_invert', ['x']),
     ('is_zero_masked', 'flow_is_zero', [None, 'x']),
     ('is_zero_thresholded', 'flow_is_zero', [1, None]),
+    # track_pts / Flow.track (utils.py:959-981; flow_class.py:1003-1005) -- args: {pts: 'list' | shape, dtype, ref, int_out, nan}
+    ('tp_pts_type', 'track_pts', [{"pts": 'list', "ref": 't'}]),
+    ('tp_pts_batch', 'track_pts', [{"pts": [3, 4, 2], "ref": 's'}]),
+    ('tp_pts_ndim', 'track_pts', [{"pts": [1, 2, 4, 2], "ref": 's'}]),
+    ('tp_pts_ndim1', 'track_pts', [{"pts": [2], "ref": 's'}]),
+    ('tp_pts_last_dim', 'track_pts', [{"pts": [4, 3], "ref": 't'}]),
+    ('tp_pts_last_dim_batched', 'track_pts', [{"pts": [2, 4, 3], "ref": 's'}]),
+    ('tp_int_out_type', 'track_pts', [{"pts": [4, 2], "ref": 's', "int_out": 'yes'}]),
+    ('tp_bad_ref', 'track_pts', [{"pts": [4, 2], "ref": 'x'}]),
+    ('tp_ref_type', 'track_pts', [{"pts": [4, 2], "ref": 1}]),
+    ('tp_flow_nan', 'track_pts', [{"pts": [4, 2], "ref": 's', "nan": True}]),
+    ('tp_flow_shape', 'track_pts', [{"pts": [4, 2], "ref": 's', "flow_shape": [2, 3, 12, 16]}]),
+    ('track_status_type', 'flow_track', [{"pts": [4, 2], "get_valid_status": 'yes'}]),
+    ('track_int_out_type', 'flow_track', [{"pts": [4, 2], "int_out": 1}]),
 ]
 
 
@@ -892,6 +906,15 @@ def bad_call(mod, flow_cls, utils_mod, fn, args):
         return f.invert(*args)
     if fn == 'flow_is_zero':
         return f.is_zero(*args)
+    if fn in ('track_pts', 'flow_track'):
+        spec = args[0]
+        pts = [[1, 2], [3, 4]] if spec["pts"] == 'list' else torch.ones(*spec["pts"])
+        if fn == 'flow_track':
+            return f.track(pts, **{k: v for k, v in spec.items() if k != 'pts'})
+        vecs = torch.ones(*spec.get("flow_shape", [2, 2, 12, 16]))
+        if spec.get("nan"):
+            vecs[0, 0, 0, 0] = float('nan')
+        return utils_mod.track_pts(vecs, spec["ref"], pts, *([spec["int_out"]] if "int_out" in spec else []))
     raise KeyError(fn)
 
 

@@ -96,3 +96,31 @@ def test_from_matrix_keeps_the_graph_of_a_matrix_that_wants_a_gradient(dev):
     assert out.grad_fn is not None
     out.sum().backward()
     assert m.grad is not None and bool(torch.isfinite(m.grad).all())
+
+
+@pytest.mark.parametrize("ref", ['s', 't'])
+def test_from_matrix_with_a_host_matrix_that_wants_a_gradient_and_a_hip_device(ref, dev):
+    """`Flow.from_matrix(cpu_matrix_requires_grad, shape, device='cuda')` -- the differentiable branch built
+    its grid on the wanted device and multiplied it with the matrix where the matrix lived.  The matrix is moved (the graph goes
+    along), the field comes out on the wanted device, and the gradient arrives at the HOST leaf."""
+    import oflibpytorch_amd as ofl
+    base = torch.tensor([[1.02, 0.03, 2.0], [-0.01, 0.97, -1.0], [0.0, 0.0, 1.0]])
+    m = base.clone().requires_grad_()
+    fl = ofl.Flow.from_matrix(m, (24, 36), ref, device=dev)
+    assert fl.vecs.device.type == 'cuda' and fl.vecs.grad_fn is not None
+    fl.vecs.sum().backward()
+    assert m.grad is not None and m.grad.device.type == 'cpu' and bool(torch.isfinite(m.grad).all())
+    # same values as the non-differentiable route (the kernel) to fp32 rounding of the torch expression
+    plain = ofl.Flow.from_matrix(base, (24, 36), ref, device=dev)
+    assert torch.allclose(fl.vecs.detach(), plain.vecs, rtol=1e-5, atol=1e-4)
+
+
+def test_flow_from_matrix_broadcasts_n_matrices_over_a_batch_of_one(dev):
+    """utils.flow_from_matrix(matrix[N,3,3], [1,H,W]) broadcasts to N fields, as the reference's matmul does
+    (utils.py:364-370); the reference's own from_matrix calls it exactly this way."""
+    import oflibpytorch_amd as ofl
+    from oracle import oracle
+    mats = torch.stack([torch.eye(3), torch.tensor([[1.0, 0.1, 3.0], [0.0, 1.0, -2.0], [0.0, 0.0, 1.0]])])
+    got = ofl.utils.flow_from_matrix(mats.to(dev), [1, 20, 28])
+    assert tuple(got.shape) == (2, 2, 20, 28)
+    assert np.array_equal(got.cpu().numpy(), oracle.flow_from_matrix(mats.numpy(), 2, 20, 28))

@@ -243,3 +243,41 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank(dev):
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["launcher"] == "torch.distributed (nccl)"
+
+
+def test_kernel_outputs_keep_their_flag_words_under_inference_mode(dev, monkeypatch):
+    """under torch.inference_mode() tensors carry no version counter, so the flag cache of a flow never matched and
+    every use re-ran the reduction and waited for it -- also for kernel OUTPUTS nobody else holds.  Those are now `private`:
+    their by-product flag word is used; handing the storage out (`.vecs` / `.mask`) ends it, and an in-place edit through the
+    handed-out tensor is seen by the next use."""
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import _native, flow_class
+    from oracle import oracle
+    calls = {"n": 0}
+    real = flow_class._host_flags
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(flow_class, "_host_flags", counting)
+    g = torch.Generator().manual_seed(5)
+    f1 = (torch.randn(2, 2, 40, 56, generator=g) * 2).to(dev)
+    f2 = (torch.randn(2, 2, 40, 56, generator=g) * 2).to(dev)
+    with torch.inference_mode():
+        a, b = ofl.Flow(f1, 't'), ofl.Flow(f2, 't')
+        base = calls["n"]
+        c = a.combine_with(b, 3)                    # a kernel output: private
+        assert c._private
+        n0 = calls["n"]
+        d = c.combine_with(b, 3)                    # its flag word is needed here
+        d2 = c.combine_with(b, 3)
+        # (a and b are the caller's inference tensors: re-validated per use, as before; c must not add a reduction of its own
+        # beyond the one that reads its by-product / first word)
+        per_use = (calls["n"] - n0) / 2.0
+        assert torch.equal(d.vecs, d2.vecs)
+        handed = c.vecs                             # the storage escapes
+        assert not c._private
+        handed.zero_()                              # ... and is edited in place: c is now the zero flow
+        e = c.combine_with(b, 3)                    # zero first operand: the second comes back (flow_class.py:1729-1737)
+        assert e is b
+    assert per_use <= 2.0
