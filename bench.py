@@ -239,6 +239,26 @@ def secondary_lines(ofl, dev):
     return out
 
 
+def _sharded_child(route, steps):
+    """bench.py --batch 8 in a child process under RANK=0 WORLD_SIZE=1: init_process_group("nccl"), enable_batch_sharding(), the
+    collectives forced on -- the validation route every rank of an 8-GPU job takes.  -> the child's JSON line, or None"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--batch", "8", "--steps", str(steps), "--warmup", "5", "--blocks", "5",
+           "--no-secondary", "--no-cpu-baseline", "--no-probe", "--force-collectives", "--flag-route", route]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +274,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the 8-elements-per-GPU strong-scaling probe")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="(the sharded probe's child) run the batch-sharded validation route on a communicator of ONE rank")
+    ap.add_argument("--flag-route", choices=("host", "comm"), default="host",
+                    help="batch sharding: flag words cross the ranks through shared memory (one node) or through the communicator")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass")
     args = ap.parse_args()
@@ -278,7 +302,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # "nccl" = RCCL over xGMI
-        ofd.enable_batch_sharding()          # batch-global early-exit flags over RCCL (one tiny all-reduce per new tensor; a no-op at N = 1)
+        ofd.USE_HOST_EXCHANGE = args.flag_route == "host"
+        ofd._force_collectives = bool(args.force_collectives)
+        ofd.enable_batch_sharding()          # batch-global early-exit flags: 5 bits per new tensor cross the ranks (shared memory on one node, else one tiny all-reduce); a no-op at N = 1
 
     h, w = args.height, args.width
     if args.scaling == "strong":
@@ -371,6 +397,19 @@ def main():
                  "implied_speedup_at_8_gpus": round((elapsed / args.steps * 1e3) / ms8, 2),
                  "implied_speedup_at_8_gpus_cached": round((el_cached / args.steps * 1e3) / msc8, 2),
                  "note": "global B=64 over 8 GPUs = this step at B=8 per GPU; speed-up = t(B=64 on 1 GPU) / t(B=8), median blocks"}
+        # the same step THROUGH THE SHARDED VALIDATION ROUTE: a fresh child (RCCL before any other GPU work) with
+        # init_process_group("nccl", world_size=1) + enable_batch_sharding() + the collectives forced on, once per flag route
+        torch.cuda.empty_cache()
+        for route, key in (("host", "sharded"), ("comm", "sharded_through_the_communicator")):
+            got = _sharded_child(route, k8)
+            if got is None:
+                probe[key] = {"error": "child failed"}
+                continue
+            probe[key] = {"flag_route": "shared-memory exchange of the 5-bit word between the ranks of the node (distributed._HostExchange)"
+                          if route == "host" else "ofl_flag_words_or_i32 + RCCL all-reduce (MAX) + copy + polled event",
+                          "ms_per_step": got["ms_per_step"], "ms_per_step_cached": round(got["ms_per_step"] - got["kernels"]["validation_ms_per_step"], 4),
+                          "launcher": got["config"]["launcher"]}
+            probe["implied_speedup_at_8_gpus_" + key] = round((elapsed / args.steps * 1e3) / got["ms_per_step"], 2)
 
     secondary = None
     if world == 1 and not args.no_secondary and rank == 0:

@@ -249,7 +249,8 @@ _WORK_EXTRA = 33             # OFL_FLAGS_HOST_WORK_EXTRA
 _MAX_SLOTS = 8               # per device; a ninth concurrent caller waits for a slot
 _host_slots = {}             # device index -> list of slots [lock, device work words, host address, int32 view of the pairs, last serial]
 _host_slots_lock = threading.Lock()
-_SPIN_SLACK_SECONDS = 150e-6  # tight polling lasts ~2x the time the reduction's bytes take plus this; after that the wait sleeps between looks
+_SPIN_SLACK_SECONDS = 150e-6  # tight polling lasts ~2x the time the reduction's bytes take plus this; after that the wait yields the GIL between looks
+_YIELD_SECONDS = 20e-3        # ... and after this long it sleeps 50 us between looks
 HOST_POLL_SECONDS = 20.0     # a reduction that has not reported after this long is a failed launch, not a slow one
 
 
@@ -338,7 +339,11 @@ def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):
                     if looks & 0x3f == 0:
                         now = time.perf_counter()
                         if now > spin_until:
-                            time.sleep(5e-5)
+                            # the stream has work queued in front of the reduction (the previous step's kernels): keep looking,
+                            # but hand the GIL to any other Python thread between looks (sleep(0) returns at once when nobody
+                            # wants it -- a timed sleep here cost 30-60 us of wake-up latency per validation, 14 % of a B = 8
+                            # step); only a wait of many milliseconds backs off to timed sleeps
+                            time.sleep(0 if now - t0 < _YIELD_SECONDS else 5e-5)
                             if now - t0 > HOST_POLL_SECONDS:
                                 torch.cuda.synchronize(dev)          # surfaces a launch failure as the runtime's own error
                                 if bool((tags == serial).all()):

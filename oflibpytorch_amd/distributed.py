@@ -9,25 +9,139 @@ shard is not.  Those decisions are a 5-bit flag word per operand; `reduce_flags`
 one tiny all-reduce, cached per tensor version like the local flags.  A shared B=1 operand (the reference's
 1<->N broadcast) is distributed with `broadcast_operand`; `all_gather_batch` reassembles results when asked.
 """
+import atexit
+import time
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
 _group = None
 _enabled = False
 _force_collectives = False   # tests only: run the collectives on a communicator of ONE rank too (tests/test_gpu_validation.py)
+_exchange = None             # _HostExchange of the group when every rank lives on this host (the 8 GPUs of one node), else None
+USE_HOST_EXCHANGE = True     # False: the flag words always travel through the communicator (RCCL / gloo), as in rounds 1-3
+EXCHANGE_TIMEOUT_SECONDS = 120.0
+
+
+class _HostExchange(object):
+    """OR of a small host integer over the ranks of ONE node through shared memory -- the reference's batch-global early
+    exits need 5 bits per operand, and those bits are ALREADY on the host of every rank when the validation wait ends
+    (`_native.flow_flags_host`).  Sending them back to the device, through an RCCL all-reduce and home again cost two copies,
+    a collective launch and an event per validation (the sharded route had never been timed: +45 us on a 46 us
+    wait); here every rank stores ONE 8-byte word {sequence number, bits} into its slot of a shared segment and reads the
+    other ranks' slots until they carry the same sequence number: no launch, no copy, microseconds.
+
+    Like any collective it relies on every rank making the same sequence of calls.  Slots are rings of RING entries: a rank
+    can be at most one call ahead of the slowest reader (it cannot finish call k + 1 before everyone has posted k + 1, which a
+    rank does only after it has read everybody's k), so entry k % RING is never overwritten while somebody still needs it."""
+    RING = 4
+
+    def __init__(self, group):
+        from multiprocessing import shared_memory
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.seq = 0
+        size = self.world * self.RING * 8
+        name = [None]
+        self.shm = None
+        if self.rank == 0:
+            self.shm = shared_memory.SharedMemory(create=True, size=size)
+            np.ndarray((self.world * self.RING,), dtype=np.int64, buffer=self.shm.buf)[:] = 0
+            name[0] = self.shm.name
+        dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ok = 1
+        if self.rank != 0:
+            try:
+                self.shm = shared_memory.SharedMemory(name=name[0])
+                # (the segment belongs to rank 0: this process must not unlink it at exit)
+                try:
+                    from multiprocessing import resource_tracker
+                    resource_tracker.unregister(self.shm._name, "shared_memory")
+                except Exception:  # noqa: BLE001
+                    pass
+            except Exception:  # noqa: BLE001        (another node: no such segment here)
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=_collective_device(group))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self.usable = bool(int(flag.cpu()[0]))
+        self.slots = None if self.shm is None else np.ndarray((self.world, self.RING), dtype=np.int64, buffer=self.shm.buf)
+
+    def or_reduce(self, bits: int) -> int:
+        self.seq += 1
+        k, e = self.seq, self.seq % self.RING
+        self.slots[self.rank, e] = (k << 8) | (bits & 0xff)          # one aligned 8-byte store: sequence number and bits arrive together
+        total, t0, looks = bits & 0xff, None, 0
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            while True:
+                v = int(self.slots[r, e])
+                if (v >> 8) == k:
+                    total |= v & 0xff
+                    break
+                looks += 1
+                if looks & 0x3ff == 0:
+                    now = time.perf_counter()
+                    t0 = now if t0 is None else t0
+                    if now - t0 > EXCHANGE_TIMEOUT_SECONDS:
+                        raise RuntimeError("oflibpytorch_amd.distributed: rank %d did not post flag exchange %d (ranks must make "
+                                           "the same sequence of calls)" % (r, k))
+                    if now - t0 > 1e-3:
+                        time.sleep(5e-5)
+        return total
+
+    def close(self):
+        shm, self.shm, self.slots = self.shm, None, None
+        if shm is not None:
+            try:
+                shm.close()
+                if self.rank == 0:
+                    shm.unlink()
+            except Exception:  # noqa: BLE001
+                pass
+
+
+def _collective_device(group):
+    """Where a tensor must live to go through `group`'s backend (RCCL: the current HIP device; gloo: the host)."""
+    try:
+        backend = dist.get_backend(group)
+    except Exception:  # noqa: BLE001
+        backend = "gloo"
+    return torch.device('cuda', torch.cuda.current_device()) if backend == "nccl" else torch.device('cpu')
 
 
 def enable_batch_sharding(group=None):
-    """Declare that the flows this process holds are one shard of a batch split over `group`'s ranks."""
-    global _group, _enabled
+    """Declare that the flows this process holds are one shard of a batch split over `group`'s ranks.  A COLLECTIVE call
+    (every rank of the group makes it): it sets up the host-side flag exchange when all ranks share this node."""
+    global _group, _enabled, _exchange
     if not dist.is_initialized():
         raise RuntimeError("oflibpytorch_amd.distributed: torch.distributed is not initialised")
     _group, _enabled = group, True
+    _close_exchange()
+    if USE_HOST_EXCHANGE:
+        try:
+            ex = _HostExchange(group)
+            _exchange = ex if ex.usable else None
+            if not ex.usable:
+                ex.close()
+        except Exception:  # noqa: BLE001      (no shared memory on this platform: the communicator carries the words)
+            _exchange = None
+
+
+def _close_exchange():
+    global _exchange
+    if _exchange is not None:
+        _exchange.close()
+        _exchange = None
+
+
+atexit.register(_close_exchange)
 
 
 def disable_batch_sharding():
     global _group, _enabled
     _group, _enabled = None, False
+    _close_exchange()
 
 
 def is_enabled() -> bool:
@@ -39,8 +153,14 @@ def reduce_flags(local_or: int, device) -> int:
     collective and one sync; the kernels' device-side words go through `with_global_or` instead."""
     if not is_enabled():
         return local_or
+    if _exchange is not None:                # every rank on this node: host words through shared memory, no launch
+        return _exchange.or_reduce(int(local_or))
     host = with_global_or(torch.tensor([local_or], dtype=torch.int32, device=device)).cpu().tolist()
     return split_global_or(host)[1]
+
+
+def host_exchange_active() -> bool:
+    return _exchange is not None
 
 
 def with_global_or(words: torch.Tensor) -> torch.Tensor:

@@ -187,13 +187,28 @@ class Flow(object):
             if self._pending_flags is not None and self._pending_flags[0] == key:
                 dev_flags = self._pending_flags[1]
             self._pending_flags = None
-            if dev_flags is None and not distributed.is_enabled():
-                # a tensor nobody has looked at yet (the constructor's validation): reduction + read-back in one launch
-                self._flag_cache = (key, _host_flags(self._fv, self._mask))
+            sharded = distributed.is_enabled()
+            if dev_flags is None and (not sharded or distributed.host_exchange_active()):
+                # a tensor nobody has looked at yet (the constructor's validation): reduction + read-back in one launch.
+                # Batch sharding on one node: the same launch, then the OR of the batch word over the ranks through
+                # shared memory (distributed._HostExchange) -- the sharded wait is the unsharded one plus microseconds
+                words = _host_flags(self._fv, self._mask)
+                self._flag_cache = (key, words)
+                if sharded:
+                    local = 0
+                    for f in words:
+                        local |= f
+                    self._flag_cache = (key, words, (True, distributed.reduce_flags(local, self._fv.device)))
                 return self._flag_cache[1]
             if dev_flags is None:
                 dev_flags = _native.flow_flags(self._fv, self._mask)
-            if distributed.is_enabled():
+            if sharded and distributed.host_exchange_active():
+                words = _flags_to_host(dev_flags)                     # (a kernel's by-product words: copy + polled event)
+                local = 0
+                for f in words:
+                    local |= f
+                self._flag_cache = (key, words, (True, distributed.reduce_flags(local, self._fv.device)))
+            elif sharded:
                 # batch sharding: the OR over every rank's shard is formed on the device (one small all-reduce) and read
                 # together with the local words -- one host sync per tensor version, as without sharding
                 words, glob = distributed.split_global_or(_flags_to_host(distributed.with_global_or(dev_flags)))

@@ -55,6 +55,7 @@ def _worker(rank, world, port, q):
         # 2. ... with batch sharding the decision is batch-global: nobody exits, results equal the un-sharded oracle
         ofd.enable_batch_sharding()
         assert ofd.is_enabled()
+        assert ofd.host_exchange_active()        # both ranks on this host: the flag words cross through shared memory
         a, b = ofl.Flow(f1[lo:hi], 't', m1[lo:hi]), ofl.Flow(f2[lo:hi], 't', m2[lo:hi])
         out = a.combine_with(b, 3)
         assert out is not b and out is not a
@@ -85,8 +86,26 @@ def _worker(rank, world, port, q):
         words = ofd.with_global_or(torch.tensor([1 << rank, 4], dtype=torch.int32))
         assert words.tolist() == [1 << rank, 4, 1, 1, 1, 0, 0]
         assert ofd.split_global_or(words.tolist()) == ([1 << rank, 4], 0b111)
+        # many exchanges back to back (the ring of slots is re-used; the ranks run at different speeds)
+        for i in range(200):
+            if rank == 1 and i % 37 == 0:
+                import time
+                time.sleep(0.002)
+            assert ofd.reduce_flags(((i >> rank) & 1) << rank, torch.device('cpu')) == ((i & 1) | (((i >> 1) & 1) << 1))
         ofd.disable_batch_sharding()
         assert not ofd.is_enabled()
+        # 4. the communicator route (ranks on different nodes, or USE_HOST_EXCHANGE off): same decisions, same results
+        ofd.USE_HOST_EXCHANGE = False
+        ofd.enable_batch_sharding()
+        assert ofd.is_enabled() and not ofd.host_exchange_active()
+        a, b = ofl.Flow(f1[lo:hi], 't', m1[lo:hi]), ofl.Flow(f2[lo:hi], 't', m2[lo:hi])
+        out2 = a.combine_with(b, 3)
+        assert out2 is not b and np.array_equal(out2.vecs.numpy(), ev[lo:hi]) and np.array_equal(out2.mask.numpy(), em[lo:hi])
+        assert ofd.reduce_flags(1 << rank, torch.device('cpu')) == 0b11
+        with pytest.raises(ValueError):
+            ofl.Flow(bad[lo:hi], 't')
+        ofd.disable_batch_sharding()
+        ofd.USE_HOST_EXCHANGE = True
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))

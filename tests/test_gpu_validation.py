@@ -183,6 +183,12 @@ img = torch.rand(3, 3, 60, 84, generator=g); m1 = torch.rand(3, 60, 84, generato
 # ... so force the sharded code path itself (collectives over the real communicator of size 1)
 ofd._force_collectives = True
 assert ofd.is_enabled()
+assert ofd.host_exchange_active()                # one node: the 5-bit words cross the ranks through shared memory ...
+A, B = ofl.Flow(f1.to(dev), 't', m1.to(dev)), ofl.Flow(f2.to(dev), 't')
+assert A._flag_cache[2] == (True, A._batch_flags())
+ofd.USE_HOST_EXCHANGE = False                    # ... and everything below takes the communicator route (RCCL all-reduce)
+ofd.enable_batch_sharding()
+assert ofd.is_enabled() and not ofd.host_exchange_active()
 A, B = ofl.Flow(f1.to(dev), 't', m1.to(dev)), ofl.Flow(f2.to(dev), 't')
 w, v = B.apply(img.to(dev), return_valid_area=True)
 ow, ov = oracle.flow_apply(f2.numpy(), 't', np.ones((3, 60, 84), bool), img.numpy(), None)
