@@ -2378,9 +2378,14 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
     }
-    if (kLdsT > 2 && !add && !p.flow_flags) {              // a plain warp (Flow.apply 't' of an image or a flow): columns of kLdsT tiles
-        WarpParams q = p;
-        const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+    // a plain warp (Flow.apply 't' of an image or a flow): columns of kLdsT tiles -- unless the launch is SMALL: a column block
+    // lives 4 tiles long, and with fewer than ~4.5 blocks per resident slot (256 CUs x 6) the chip idles behind the last
+    // ones.  Below that the pair kernel's twice-as-many, half-as-long blocks win: B = 1 / 2 / 4 / 6 at 1080p -4 / -15 / -7 /
+    // -5 %, B >= 8 the column kernel by 1-4 % (profiles/r4_small_batch_kernel_choice.txt)
+    constexpr unsigned kColumnMinGroups = 6912;
+    WarpParams q = p;
+    const unsigned g = (kLdsT > 2 && !add && !p.flow_flags) ? warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) : 0u;
+    if (g >= kColumnMinGroups) {
 #if OFL_WARP_PREBOX_EXPERIMENT
         if (g_warp_prebox) {                                // measurement: boxes from a pre-pass (its time is the validation pass's to carry)
             constexpr int TT = (kLdsT > 2 ? kLdsT : 3);
