@@ -121,7 +121,6 @@ struct WarpParams {
     // flow_mask are fh x fw frames covering rows foy .., columns fox .. of the h x w frame; outside the window the flow is
     // zero (F.pad(mode='constant')) and the flow mask False
     int32_t fh, fw, foy, fox;
-    const int32_t* boxes;            // optional (column kernel): the staging geometry of every tile, made ahead of the launch (8 ints per tile, warp_boxes_kernel)
 };
 
 typedef const WarpParams __attribute__((address_space(4))) WarpParamsK;
@@ -448,12 +447,7 @@ __device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb
             // 24-bit multiplies (full rate): i < 2^9, inv <= 2^20, rows and columns < 2^13, h * w < 2^24
             const uint32_t r = __umul24(i, inv) >> 20, c4 = i - __umul24(r, (uint32_t)B.cw);
             const int y = B.miny + (int)r + lds_shear(B.cbase + (int)c4, B.sq);
-#ifndef OFL_WARP_TRIMTEST
-#define OFL_WARP_TRIMTEST 0      // measurement only (wrong outputs): 1 = the first and last chunk column of every box are not staged at all, 2 = only every other row of them
-#endif
-            const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h) &&
-                            !(OFL_WARP_TRIMTEST == 1 && (c4 == 0u || c4 + 1u == (uint32_t)B.cw)) &&
-                            !(OFL_WARP_TRIMTEST == 2 && (c4 == 0u || c4 + 1u == (uint32_t)B.cw) && (r & 1u));
+            const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h);
             const uint32_t g = on ? (uint32_t)(__mul24(y, p.w) + B.bx0) + c4 * 4u : 0u;
             S.slot[it] = on ? 1 + (int)(__umul24(r, (uint32_t)B.Pp) + c4) : -1;
             // the last chunk of a row of an image whose width is not a multiple of 4 would read past the row end (and past
@@ -529,10 +523,6 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
             const int yr = yi - B.miny;   // row in the sheared box, per tap column
             const int r0 = 16 + __mul24(yr - lds_shear(xi >> 2, B.sq), P16), r1 = 16 + __mul24(yr - lds_shear((xi + 1) >> 2, B.sq), P16);
             int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r1 + cp1 : 0, ok[2] ? r0 + P16 + cp0 : 0, ok[3] ? r1 + P16 + cp1 : 0};
-            if (OFL_WARP_TRIMTEST == 3) {        // measurement only: conflict-free (lane-linear) tap addresses
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { asm volatile("" :: "v"(si[j])); si[j] = 16 + ((((int)threadIdx.x * 4 + j) * 16) & 0x3ff0); }
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
         } else if (NC == 3) {
@@ -730,38 +720,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
 // pixels with the same registers and the same LDS -- flow two tiles ahead, staging loads one tile ahead, stores behind.
 // GRAD: the same column pipeline computing the gradient with respect to the flow (`addend` = the upstream gradient [N,NC,H,W],
 // `dst` = [N,2,H,W]; see lds_gather_impl) -- the forward's staged boxes instead of 4 * NC scalar gathers per pixel.
-// the staging geometry of every tile of a launch of the column kernel, ahead of it: the same grid, the same functions
-template <int T>
-__global__ __launch_bounds__(kLdsNT) void warp_boxes_kernel(const WarpParams p, int32_t* __restrict__ out) {
-    constexpr int NW = kLdsNT / 64;
-    __shared__ int red[2][NW][4];
-    int tx, tyg, n;
-    if (!decode_tile(p, tx, tyg, n)) return;
-    const uint32_t b = blockIdx.x;
-    const uint32_t group = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
-    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
-    const int w = p.w, h = p.h;
-    const uint32_t hw = (uint32_t)(h * w);
-    const float* __restrict__ fu = p.flow + n * p.flow_bs;
-    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
-#pragma unroll
-    for (int k = 0; k < T; ++k) {
-        const int tyk = tyg * T + k;
-        if (tyk * kLdsTH >= h) break;
-        const uint32_t pix = (uint32_t)(min(tyk * kLdsTH + ly, h - 1) * w + xq);
-        const f4 u = ld4(fu + pix), v = ld4(fu + hw + pix);
-        const int sq = p.shear ? lds_slope_row(p, fu, hw, tx, tyk * kLdsTH + kLdsTH / 2) : 0;
-        LdsCoords Tc; LdsBox B;
-        lds_coords_box(p, tx, tyk, u, v, sq, Tc, B, red[k & 1]);
-        if (tid == 0) {
-            int4* o = reinterpret_cast<int4*>(out + ((size_t)group * T + k) * 8);
-            o[0] = make_int4(B.bx0, B.miny, B.cw, B.Pp);
-            o[1] = make_int4(B.bh, B.nch, B.sq, (B.fits ? 1 : 0) | (B.interior ? 2 : 0));
-        }
-    }
-}
-
-template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false, bool PREBOX = false>
+template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p_by_value) {
 #if OFL_WARP_KARG
     // parameters through the kernarg segment (see OFL_OPAQUE_S at the gather splat): the ~250 bytes of WarpParams are not
@@ -812,40 +771,16 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     // the shear slope is estimated per tile (a column is too tall for one estimate); all of them up front: the scalar loads
     // must not sit between a tile's flow and its box
     int sq[T];
-    if (PREBOX) {
-        // the boxes come from a table made ahead of the launch: the first staging loads leave before the flow has arrived
-        const uint32_t b = blockIdx.x;
-        const uint32_t group = (b & 7u) * (uint32_t)p.per_xcd + (b >> 3);
-        const int4* __restrict__ tb = reinterpret_cast<const int4*>(p.boxes + (size_t)group * T * 8);
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const int4 a = tb[2 * k], c = tb[2 * k + 1];
-            Bx[k].bx0 = __builtin_amdgcn_readfirstlane(a.x); Bx[k].miny = __builtin_amdgcn_readfirstlane(a.y);
-            Bx[k].cw = __builtin_amdgcn_readfirstlane(a.z); Bx[k].Pp = __builtin_amdgcn_readfirstlane(a.w);
-            Bx[k].bh = __builtin_amdgcn_readfirstlane(c.x); Bx[k].nch = __builtin_amdgcn_readfirstlane(c.y);
-            Bx[k].sq = __builtin_amdgcn_readfirstlane(c.z); Bx[k].cbase = Bx[k].bx0 >> 2;
-            const int fl = __builtin_amdgcn_readfirstlane(c.w);
-            Bx[k].fits = (fl & 1) != 0; Bx[k].interior = (fl & 2) != 0;
-            sq[k] = Bx[k].sq;
-        }
-        lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[0], S, sbb);
-        note_flags(0);
-        lds_coords_box<false>(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
-    } else {
 #pragma unroll
     for (int k = 0; k < T; ++k) sq[k] = p.shear ? lds_slope_row(p, fu, hw, tx, (tyg * T + k) * kLdsTH + kLdsTH / 2) : 0;
     note_flags(0);
     lds_coords_box(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
     lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[0], S, sbb);          // staging loads of tile 0 fly ...
-    }
     // the vmcnt queue is in order: the addend (an L2 hit when it is the flow itself) is fetched BEFORE the next tile's staging
     // loads / this tile's stores, so that waiting for it never waits for them
     // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
     constexpr bool EARLY = ADD && NC <= 2;
-#ifndef OFL_WARP_NOREUSE
-#define OFL_WARP_NOREUSE 0      // measurement only: the column kernel fetches the addend again (an L2 hit) instead of holding the flow registers
-#endif
-    const bool reuse = !OFL_WARP_NOREUSE && EARLY && NC == 2 && p.add_is_flow;                 // block-uniform
+    const bool reuse = EARLY && NC == 2 && p.add_is_flow;                 // block-uniform
     int dflags = 0;
 #pragma unroll
     for (int k = 0; k < T; ++k) {
@@ -853,7 +788,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         const int tyk = tyg * T + k;
         const bool more = (k + 1 < T) && ((tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
         if (k + 1 < T) {
-            if (more) { note_flags(k + 1); lds_coords_box<!PREBOX>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
+            if (more) { note_flags(k + 1); lds_coords_box(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
         }
         if (k + 2 < T) load_flow(k + 2);
         lds_write<NC, VALID>(lds, Bx[k], S);
@@ -1251,9 +1186,6 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
 //  subtiles spread over > 256 destination tiles takes the two-pass global-atomics path inside the same call, decided on
 //  the device, per image.
 // ------------------------------------------------------------------------------------------------
-#ifndef OFL_SP_ABL
-#define OFL_SP_ABL 0             // measurement-only builds (wrong outputs): 1 no scan at all, 2 scan loads + end points only, 3 no phase C, 4 no phases S and C, 5 no output stores, 6 no valid / warped mask stores
-#endif
 #ifndef OFL_SP_TW
 #define OFL_SP_TW 32    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues)
 #endif
@@ -1286,7 +1218,7 @@ struct GatherParams {
     SplatParams s;
     int32_t* cnt;          // [n * tiles] subtiles listed for the tile
     uint32_t* list;        // [n * tiles][kBinCap] subtile ids (row-major over the image's subtile grid)
-    int32_t* stats;        // [0] some image took the two-pass path | [1] tiles that left the exact path | [2] images that did (the rest: diagnostics of OFL_SP_DIAG builds)
+    int32_t* stats;        // [0] some image took the two-pass path | [1] tiles that left the exact path | [2] images that did
     int32_t* img_over;     // [n] this image takes the two-pass path
     int32_t tiles_x, tiles_y;
     uint32_t tiles_img, mx_m, mx_s, mi_m, mi_s;
@@ -1658,7 +1590,6 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
             const f2 give = odd ? pa : pb, keep = odd ? pb : pa;
             const f2 got = {swap1(give[0]), swap1(give[1])};
             const f4 v = odd ? (f4){got[0], got[1], keep[0], keep[1]} : (f4){keep[0], keep[1], got[0], got[1]};
-            if (OFL_SP_ABL == 5) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); return; }
             if (mine && (odd ? b_on : a_on)) { if (odd) st4o(ptrb + pq, v); else st4o(ptra + pq, v); }
         };
         float* dpl = s.density ? s.density + (int64_t)n * hw : nullptr;
@@ -1676,8 +1607,7 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
         }
         const uint32_t pw = swap1(warped2), pv = swap1(valid2);      // (every lane takes part: no DPP under divergence)
         const uint32_t w4 = warped2 | (pw << 16), v4 = valid2 | (pv << 16);
-        if (OFL_SP_ABL == 5 || OFL_SP_ABL == 6) asm volatile("" :: "v"(w4), "v"(v4));
-        else if (mine && !odd) {
+        if (mine && !odd) {
             if (s.warped) st32(s.warped + (int64_t)n * hw + pq, w4);
             if (MCH && s.valid) st32(s.valid + (int64_t)n * hw + pq, v4);
         }
@@ -1787,7 +1717,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     // the first 32 entries of the list are fetched WITH its length (the list has a fixed address and kBinCap slots: entries
     // past the length are stale ids that are never used): one round trip for the list, one for the end points, one for the data
     const uint32_t pre[2] = {lst[tid / kSubLanes], lst[kHalf + tid / kSubLanes]};
-    const int nlist = OFL_SP_ABL == 1 ? 0 : min(p.cnt[tile], kBinCap);
+    const int nlist = min(p.cnt[tile], kBinCap);
     OFL_OPAQUE_S(pp);
     SpTile t;
     sp_tile_setup<TF>(s, tx, ty, n, t);
@@ -1875,13 +1805,6 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 for (int c = 0; c < NC; ++c) dat[u][c] = (f4){0.f, 0.f, 0.f, 0.f};
                 if (inb[u]) sp_load_data<NC, MCH, TF>(s, n, sx4[u], sy[u], hw, dat[u], mc4[u]);
             }
-            if (OFL_SP_ABL == 2) {       // keep the loads alive without the hit test / records
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { asm volatile("" :: "v"(q[u].x[0]), "v"(q[u].y[3]), "v"(q[u].on), "v"(mc4[u]));
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) asm volatile("" :: "v"(dat[u][c][0]), "v"(dat[u][c][3])); }
-                continue;
-            }
             process(q[0], sx4[0], sy[0], dat[0], mc4[0], r0, r1);
             if (two) process(q[1], sx4[1], sy[1], dat[1], mc4[1], r0, r1);
         }
@@ -1889,10 +1812,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     using std::integral_constant;
     // bands of destination rows: 1 when every record fits the LDS; decided from the number of records the whole tile wants
     int nb = 1;
-#ifndef OFL_SP_FORCE_FOLD
-#define OFL_SP_FORCE_FOLD 0      // 1 (measurement only): every tile on the LDS-float-atomics path -- what the in-order sums cost
-#endif
-    bool over = OFL_SP_FORCE_FOLD != 0;
+    bool over = false;
     for (int attempt = 0; attempt < 2 && !over; ++attempt) {
         const int rows = kSpTH / nb;
         bool redo = false;
@@ -1937,7 +1857,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
 #pragma unroll
             for (int r = 0; r < kCellRounds; ++r) {
                 const int c = tid + r * kSpNT2;
-                if (OFL_SP_ABL != 4 && c < kCells && ccnt[c] > 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)c;
+                if (c < kCells && ccnt[c] > 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)c;
             }
             __syncthreads();
             const int nlong = lqn;
@@ -2003,16 +1923,6 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 }
                 slots[c] = make_uint2(kLongCell | (ia << 16), ib | (ic << 16));
             }
-#if OFL_SP_DIAG
-            {
-                int nl = 0, nc = 0, n2 = 0;
-                for (int r = 0; r < kCellRounds; ++r) { const int c = tid + r * kSpNT2; if (c < kCells) { nl += ccnt[c] > 2u; nc += ccnt[c] > 4u; n2 += ccnt[c] == 2u; } }
-                if (nl) atomicAdd(&p.stats[6], nl);
-                if (nc) atomicAdd(&p.stats[7], nc);
-                if (n2) atomicAdd(&p.stats[3], n2);
-                if (tid == 0) { atomicAdd(&p.stats[4], 1); if (nb > 1 && band == 0) atomicAdd(&p.stats[5], 1); }
-            }
-#endif
             over = __syncthreads_or((int)toolong) != 0;
             if (over) break;
             // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.
@@ -2024,7 +1934,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
-            if (mine && OFL_SP_ABL != 3 && OFL_SP_ABL != 4) {
+            if (mine) {
                 float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
                 auto clear = [&]() {
 #pragma unroll
@@ -2350,10 +2260,6 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 }
 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
-#ifndef OFL_WARP_PREBOX_EXPERIMENT
-#define OFL_WARP_PREBOX_EXPERIMENT 0
-#endif
-int g_warp_prebox = 0;   // ofl_set_option(6, .), measurement builds only
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
@@ -2386,21 +2292,6 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     WarpParams q = p;
     const unsigned g = (kLdsT > 2 && !add && !p.flow_flags) ? warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) : 0u;
     if (g >= kColumnMinGroups) {
-#if OFL_WARP_PREBOX_EXPERIMENT
-        if (g_warp_prebox) {                                // measurement: boxes from a pre-pass (its time is the validation pass's to carry)
-            constexpr int TT = (kLdsT > 2 ? kLdsT : 3);
-            static int32_t* table = nullptr; static size_t cap = 0;
-            const size_t need = (size_t)g * TT * 8 * sizeof(int32_t);
-            if (need > cap) { if (table) (void)hipFree(table); if (hipMalloc(&table, need) != hipSuccess) return OFL_E_ARG; cap = need; }
-            hipLaunchKernelGGL((warp_boxes_kernel<TT>), dim3(g), dim3(kLdsNT), 0, st, q, table);
-            q.boxes = table;
-            if (g_warp_prebox == 2) { q.boxes = nullptr; goto product; }     // (the pre-pass beside the product kernel: its own time)
-            if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-            return (int)hipGetLastError();
-        }
-        product:
-#endif
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
@@ -2536,9 +2427,6 @@ __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t v
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }
-#if OFL_WARP_PREBOX_EXPERIMENT
-    if (key == 6) { g_warp_prebox = value; return OFL_OK; }
-#endif
     return OFL_E_ARG;
 }
 
@@ -2556,7 +2444,6 @@ static int warp_bwd_impl(
     if (round_mode < 0 || round_mode > 2) return OFL_E_ARG;
     if (!(flow_sign == 1.0f || flow_sign == -1.0f)) return OFL_E_ARG;
     WarpParams p;
-    p.boxes = nullptr;
     p.flow = flow; p.flow_bs = flow_bs; p.src = src; p.src_bs = src_bs;
     p.src_b = nullptr; p.src_b_bs = 0;
     p.src_mask = src_mask; p.src_mask_bs = src_mask_bs; p.flow_mask = flow_mask; p.flow_mask_bs = flow_mask_bs;

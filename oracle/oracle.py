@@ -25,7 +25,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libofl_oracle.so")
+_LIB_PATH = os.environ.get("OFL_ORACLE_LIB") or os.path.join(_HERE, "libofl_oracle.so")   # OFL_ORACLE_LIB: `make -C oracle asan`
 _lib = None
 
 THRESHOLD = np.float32(1e-3)        # utils.py:23 DEFAULT_THRESHOLD
@@ -35,6 +35,8 @@ VALID_THRESHOLD = np.float32(0.99999)  # flow_class.py:922
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (recipe: oracle/Makefile)."""
     src = os.path.join(_HERE, "ofl_oracle.c")
+    if os.environ.get("OFL_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "libofl_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
