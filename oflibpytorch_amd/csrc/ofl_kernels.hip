@@ -1768,6 +1768,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                     const uint32_t slot = atomicAdd(&ccnt[cell[k]], 1u);
                     if (slot < 4u) reinterpret_cast<uint16_t*>(slots)[4 * cell[k] + (int)slot] = (uint16_t)pos;
                     else link[pos] = (uint16_t)atomicExch(&ohead[cell[k]], (uint32_t)pos);
+                    // the cell's THIRD record makes it a cell phase S must order: exactly one thread sees slot 2, and it
+                    // queues the cell there and then -- no pass over the cell counters and no barrier for it afterwards
+                    // (round 4: -1.2 ... -3.3 %, profiles/r4_splat_variants.txt)
+                    if (slot == 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)cell[k];
                 }
             }
         }
@@ -1854,13 +1858,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             // order; the four class sums of every channel overwrite the cell's first three records and its readers add them
             // as if they were one record.  (Every reader sorting and walking such cells itself kept 60 lanes of a wave idle
             // while 4 of them worked: -20 % VALU instructions on the bench flow.)
-#pragma unroll
-            for (int r = 0; r < kCellRounds; ++r) {
-                const int c = tid + r * kSpNT2;
-                if (c < kCells && ccnt[c] > 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)c;
-            }
-            __syncthreads();
-            const int nlong = lqn;
+            const int nlong = lqn;                             // (queued by the scan; the barrier after it covers the queue)
             for (int qi = tid; qi < nlong; qi += kSpNT2) {
                 const int c = lq[qi];
                 const uint32_t cn = ccnt[c];
@@ -1923,7 +1921,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 }
                 slots[c] = make_uint2(kLongCell | (ia << 16), ib | (ic << 16));
             }
-            over = __syncthreads_or((int)toolong) != 0;
+            if (nlong != 0) over = __syncthreads_or((int)toolong) != 0;   // (block-uniform: a tile without such cells needs no barrier here)
             if (over) break;
             // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.
             // The pair reads 3 x 2 cells; every record of a cell is fetched once and added to each corner-class sum it
