@@ -1253,8 +1253,10 @@ __device__ __forceinline__ void sp_finish_src(const SP& s, int sx4, int sy, bool
     for (int k = 0; k < 4; ++k) {
         bool zero = false;
         if (s.flow) {
-            q.x[k] = s.flow_sign * a[k] + (float)(sx4 + k);      // get_flow_endpoints utils.py:1056-1057
-            q.y[k] = s.flow_sign * b[k] + (float)sy;
+            // get_flow_endpoints utils.py:1056-1057.  flow_sign is +1 or -1: the product is exact, so ONE fma rounds exactly
+            // as the reference's add does (the entry points reject any other sign)
+            q.x[k] = __builtin_fmaf(s.flow_sign, a[k], (float)(sx4 + k));
+            q.y[k] = __builtin_fmaf(s.flow_sign, b[k], (float)sy);
             if (s.occlude) zero = (a[k] < kZeroThr) && (a[k] > -kZeroThr) && (b[k] < kZeroThr) && (b[k] > -kZeroThr);
         } else {
             q.x[k] = a[k]; q.y[k] = b[k];
@@ -1544,20 +1546,35 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
     const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
     f2 den2, out[NC], mch2;
     uint32_t warped2 = 0, valid2 = 0;
+    bool fill[2];
+    // the un-occlude fill (utils.py:1198-1203) touches a pixel here and there: the common wave has none, and takes no part
+    // of that code (wave-uniform branch below) -- first every pixel as a warped one
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float den = tot[k][0];
         const float dcl = s.raw ? 1.0f : (den < kDenMin ? kDenMin : den);          // clamp_min utils.py:1144 (raw sums: x / 1 = x)
         const bool warped = den > 0.0f;                            // utils.py:1197
-        const bool fill = t.fill_ok[k] && !warped && mine;
+        fill[k] = t.fill_ok[k] && !warped && mine;
         den2[k] = den;
         warped2 |= (uint32_t)warped << (8 * k);
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-            out[c][k] = stored_as<TO>(apply_round(fill ? s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)) : tot[k][1 + c] / dcl, s.round_mode));
+        for (int c = 0; c < NC; ++c) out[c][k] = stored_as<TO>(apply_round(tot[k][1 + c] / dcl, s.round_mode));
         if (MCH) {
-            float mv;
-            if (fill) {
+            // every contributor valid: the mask channel's sums ARE the density's (the same additions of the same weights),
+            // and x / x = 1 -- no division where the whole wave is in that case (all but the neighbourhood of mask holes)
+            const float num = tot[k][1 + NC];
+            const bool unit = num == den && den >= kDenMin && !s.raw;
+            mch2[k] = __all(unit) ? 1.0f : num / dcl;
+        }
+    }
+    if (__any(fill[0] || fill[1])) {                               // (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!fill[k]) continue;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                out[c][k] = stored_as<TO>(apply_round(s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)), s.round_mode));
+            if (MCH) {
                 const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix + k] != 0 : true;
                 bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix + k] != 0 : true;
                 if (s.fw != 0) {                                    // padded apply: chan_mask_b lives in the flow window, False outside
@@ -1565,13 +1582,13 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
                     const uint32_t off = sp_win(s, (int)((pix + k) % (uint32_t)s.w), (int)((pix + k) / (uint32_t)s.w), inside);
                     b = inside && (s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + off] != 0 : true);
                 }
-                mv = (a && b) ? 1.0f : 0.0f;
-            } else {
-                mv = tot[k][1 + NC] / dcl;
+                mch2[k] = (a && b) ? 1.0f : 0.0f;
             }
-            mch2[k] = mv;
-            valid2 |= (uint32_t)(mv > kValidThr) << (8 * k);
         }
+    }
+    if (MCH) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) valid2 |= (uint32_t)(mch2[k] > kValidThr) << (8 * k);
     }
     if (mine && NC == 2 && s.dst_flags) {             // the output read as a flow under its valid mask (by-product)
 #pragma unroll
