@@ -450,6 +450,19 @@ int ofl_warp_valid_f32(const float* flow, int64_t flow_bs, float flow_sign, cons
                        uint8_t* valid, int32_t n, int32_t h, int32_t w, void* stream);
 
 /*
+ * Bilinear resize -- the `F.interpolate(x, scale_factor=[sh, sw], mode='bilinear')` (align_corners=False) of resize_flow
+ * (utils.py:908) and Flow.resize (flow_class.py:710), computed as ATen's CPU kernels compute it, so that a resize on a HIP device
+ * returns the reference's PyTorch-CPU values BIT FOR BIT (ATen's own GPU kernel differs in the last bits):
+ *   source index fmaf(rcp_scale, dst + 0.5, -0.5) clamped at 0; a dimension that keeps its size is copied; ATen's two kernels
+ *   (chosen by oh + ow <= 128) both restated -- see ofl_aux_kernels.hip / oracle/ofl_oracle.c.
+ * src [planes, h, w] fp32 contiguous -> dst [planes, oh, ow]; the caller passes oh = floor(h * sh), ow = floor(w * sw) (doubles, as
+ * torch computes the output size) and rcp_scale_* = (float)(1.0 / s*).  The components of a flow are scaled by the caller
+ * afterwards (utils.py:913-914: two exact multiplications).  planes <= 65535.
+ */
+int ofl_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_t h, int32_t w, int32_t oh, int32_t ow,
+                            float rcp_scale_h, float rcp_scale_w, void* stream);
+
+/*
  * Flow field of a 3 x 3 transformation matrix (flow_from_matrix, utils.py:339-376; the O(HW) half of from_matrix :646-705 and
  * from_transforms :729-807, whose 3 x 3 algebra stays on the host):
  *   hom      = M [x, y, 1]^T    accumulated as ATen's CPU batched matmul does for 3 x 3 operands (acc = 0; acc += m_ik * v_k)

@@ -18,7 +18,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 27              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 28              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -26,7 +26,7 @@ _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
             "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
-            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32")
+            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32", "ofl_resize_bilinear_f32")
 _lib = None
 
 
@@ -85,6 +85,7 @@ def load_library(path: str = None):
     lib.ofl_sample_pts_grad_f32.argtypes = [p, i64, p, i64, p, p, p, i32, i32, i32, i32, p]
     lib.ofl_flow_extents_f32.argtypes = [p, i64, p, i64, f32, p, p, i32, i32, i32, p]
     lib.ofl_warp_valid_f32.argtypes = [p, i64, f32, p, i64, f32, p, i32, i32, i32, p]
+    lib.ofl_resize_bilinear_f32.argtypes = [p, p, i32, i32, i32, i32, i32, f32, f32, p]
     lib.ofl_flag_words_or_i32.argtypes = [p, i32, p, p]
     lib.ofl_splat_sum_f32.argtypes = [p, i64, f32, p, i64, f32, p, p, i64, p, i32, i32, i32, i32, p]
     lib.ofl_splat_tiled_f16.argtypes = [p, i64, f32, p, i64, f32, p, i64, p, i64, p, i64, i32, i32, p, i32, p, p, p, i64, p, i32, i32, i32, p]
@@ -857,6 +858,28 @@ def flow_extents(vecs, mask, sign: float) -> torch.Tensor:
         _check(lib.ofl_flow_extents_f32(_ptr(v), vbs, _ptr(m), mbs, float(sign), _ptr(ws), _ptr(ext), n, h, w, _stream(dev)),
                "ofl_flow_extents_f32")
     return ext
+
+
+def resize_bilinear(x: torch.Tensor, scale) -> torch.Tensor:
+    """ofl_resize_bilinear_f32: F.interpolate(x [N,C,H,W], scale_factor=[sh, sw], mode='bilinear', align_corners=False) with the
+    arithmetic of ATen's CPU kernels (bit-identical to the reference's PyTorch-CPU resize), on x's HIP device."""
+    import math
+    lib, dev = load_library(), device(x)
+    n, c, h, w = x.shape
+    sh, sw = float(scale[0]), float(scale[1])
+    oh, ow = int(math.floor(float(h) * sh)), int(math.floor(float(w) * sw))          # torch/nn/functional.py: floor of the double product
+    if oh < 1 or ow < 1:
+        raise RuntimeError("Input and output sizes should be greater than 0, but got input (H: %d, W: %d) output (H: %d, W: %d)" % (h, w, oh, ow))
+    with _on(dev):
+        src = x.detach().to(dev, torch.float32).contiguous()
+        dst = torch.empty((n, c, oh, ow), dtype=torch.float32, device=dev)
+        planes = n * c
+        for p0 in range(0, planes, 65535):          # (the grid's y dimension)
+            k = min(65535, planes - p0)
+            _check(lib.ofl_resize_bilinear_f32(src.data_ptr() + 4 * p0 * h * w, dst.data_ptr() + 4 * p0 * oh * ow, k, h, w, oh, ow,
+                                               float(np.float32(1.0 / sh)), float(np.float32(1.0 / sw)), _stream(dev)),
+                   "ofl_resize_bilinear_f32")
+    return dst
 
 
 def warp_valid(flow, mask, flow_sign: float = 1.0, thr: float = 0.9999) -> torch.Tensor:

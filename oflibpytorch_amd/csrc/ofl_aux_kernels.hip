@@ -457,6 +457,50 @@ __global__ __launch_bounds__(256) void warp_valid_kernel(const WarpValidParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bilinear resize (ofl_resize_bilinear_f32): the F.interpolate(mode='bilinear', align_corners=False) of resize_flow (utils.py:908)
+// and Flow.resize (flow_class.py:710) as ATen's CPU kernels compute it -- the reference's PyTorch-CPU result bit for bit, where
+// ATen's own GPU kernel rounds its weights differently (1e-5 of the scale, rounds 1-3).  Source index: fmaf(scale, dst + 0.5,
+// -0.5) clamped at 0; a dimension that keeps its size is copied; ATen picks one of TWO kernels from the output size
+// (oh + ow <= 128: four pre-multiplied weights and one fma chain; else rows first, then columns) -- both restated here, probed
+// against torch 2.10 CPU through the oracle (oracle/ofl_oracle.c: orc_resize_bilinear_f32, 18 million values, no mismatch).
+// One output pixel per lane, rows of the output coalesced; a few MB once per call: nowhere near a hot path.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, int32_t h,
+                                                              int32_t w, int32_t oh, int32_t ow, float rh, float rw) {
+    const int p = blockIdx.y;
+    const float* __restrict__ sp = src + (int64_t)p * h * w;
+    float* __restrict__ dp = dst + (int64_t)p * oh * ow;
+    const bool small = (oh + ow) <= 128;
+    const int64_t total = (int64_t)oh * ow;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / ow), x = (int)(i - (int64_t)y * ow);
+        float ry = __builtin_fmaf(rh, (float)y + 0.5f, -0.5f);
+        ry = ry < 0.0f ? 0.0f : ry;
+        int y0 = min((int)ry, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        float ly1 = fminf(fmaxf(ry - (float)y0, 0.0f), 1.0f);
+        if (oh == h) { y0 = y1 = y; ly1 = 0.0f; }
+        const float ly0 = 1.0f - ly1;
+        float rx = __builtin_fmaf(rw, (float)x + 0.5f, -0.5f);
+        rx = rx < 0.0f ? 0.0f : rx;
+        int x0 = min((int)rx, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        float lx1 = fminf(fmaxf(rx - (float)x0, 0.0f), 1.0f);
+        if (ow == w) { x0 = x1 = x; lx1 = 0.0f; }
+        const float lx0 = 1.0f - lx1;
+        const float s00 = sp[(int64_t)y0 * w + x0], s01 = sp[(int64_t)y0 * w + x1];
+        const float s10 = sp[(int64_t)y1 * w + x0], s11 = sp[(int64_t)y1 * w + x1];
+        float out;
+        if (small) {
+            const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+            out = __builtin_fmaf(s11, w11, __builtin_fmaf(s10, w10, __builtin_fmaf(s00, w00, s01 * w01)));
+        } else {
+            const float t0 = __builtin_fmaf(s00, lx0, s01 * lx1), t1 = __builtin_fmaf(s10, lx0, s11 * lx1);
+            out = __builtin_fmaf(t0, ly0, t1 * ly1);
+        }
+        dp[i] = out;
+    }
+}
+
 extern "C" {
 
 __attribute__((visibility("default"))) int ofl_warp_bwd_grad_f32(
@@ -542,6 +586,18 @@ __attribute__((visibility("default"))) int ofl_sample_pts_grad_f32(const float* 
     if (!grad_flow && !grad_pts) return OFL_E_ARG;
     p.gout = grad_out; p.gflow = grad_flow; p.gpts = grad_pts;
     hipLaunchKernelGGL(sample_pts_kernel<true>, dim3(blocks_for(m, n), (unsigned)n), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+__attribute__((visibility("default"))) int ofl_resize_bilinear_f32(const float* src, float* dst, int32_t planes, int32_t h, int32_t w,
+                                                                   int32_t oh, int32_t ow, float rcp_scale_h, float rcp_scale_w,
+                                                                   void* stream) {
+    if (!src || !dst) return OFL_E_NULL;
+    if (planes < 1 || h < 1 || w < 1 || oh < 1 || ow < 1 || planes > 65535) return OFL_E_SHAPE;
+    if ((int64_t)h * w >= (1ll << 31) || (int64_t)oh * ow >= (1ll << 31)) return OFL_E_SHAPE;
+    if (!(rcp_scale_h > 0.0f) || !(rcp_scale_w > 0.0f)) return OFL_E_ARG;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for((int64_t)oh * ow, planes), (unsigned)planes), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, h, w, oh, ow, rcp_scale_h, rcp_scale_w);
     return (int)hipGetLastError();
 }
 

@@ -21,7 +21,8 @@ import torch.nn.functional as F
 from . import _native, distributed
 from .utils import (get_valid_vecs, get_valid_ref, get_valid_mask, get_valid_device, get_valid_padding,
                     get_valid_shape, get_pure_pytorch, move_axis, from_matrix, from_transforms, resize_flow,
-                    apply_flow, _flags_to_host, _host_flags, _griddata_unavailable, track_pts, get_half_flow_outputs)
+                    apply_flow, _flags_to_host, _host_flags, _griddata_unavailable, track_pts, get_half_flow_outputs,
+                    interpolate_bilinear)
 
 FlowAlias = 'Flow'
 _VALID_THR = 0.99999   # flow_class.py:922
@@ -509,15 +510,13 @@ class Flow(object):
     # resize / pad (flow_class.py:694-753) -- thin PyTorch wrappers, not on the kernel path
     # ------------------------------------------------------------------------------------------
     def resize(self, scale) -> FlowAlias:
-        """flow_class.py:694-714: `F.interpolate(bilinear, align_corners=False)` of the vectors (scaled along) and of the mask
-        (then rounded), by ATen on the flow's own device, as in the reference.  (On a HIP device that is ATen's GPU kernel,
-        whose last-bit rounding differs from ATen's CPU kernel: values within 1e-5 of the CPU reference, see
-        tests/test_gpu_generators.py.)  The mask goes through the reference's own `.squeeze(0).squeeze(0)`, so -- exactly like
-        the reference -- a batch of more than one flow raises the mask's shape error."""
+        """flow_class.py:694-714: bilinear interpolation (`align_corners=False`) of the vectors (scaled along) and of the mask
+        (then rounded).  On a HIP device `ofl_resize_bilinear_f32` restates the arithmetic of ATen's CPU kernels, so the result is
+        the reference's PyTorch-CPU result bit for bit; on the host it is ATen itself.  The mask goes through the reference's own
+        `.squeeze(0).squeeze(0)`, so -- exactly like the reference -- a batch of more than one flow raises the mask's shape error."""
         resized = resize_flow(self._vecs, scale)
         sc = [scale, scale] if isinstance(scale, (float, int)) else scale
-        m = F.interpolate(self.mask.float().unsqueeze(1), scale_factor=sc, mode='bilinear',
-                          align_corners=False).squeeze(0).squeeze(0)
+        m = interpolate_bilinear(self.mask.float().unsqueeze(1), sc).squeeze(0).squeeze(0)
         return Flow(resized, self._ref, torch.round(m), device=self._device)
 
     def pad(self, padding: list = None, mode: str = None) -> FlowAlias:

@@ -447,8 +447,19 @@ def apply_flow(flow, target: torch.Tensor, ref: str, mask=None) -> torch.Tensor:
     return out.to(dtype)
 
 
+def interpolate_bilinear(x: torch.Tensor, scale) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False) (utils.py:908, flow_class.py:710).  On the host
+    that is ATen's CPU kernel, as in the reference.  On a HIP device `ofl_resize_bilinear_f32` restates the arithmetic of ATen's
+    CPU kernels, so the result equals the reference's PyTorch-CPU values bit for bit (ATen's GPU kernel would differ in the last
+    bits); a tensor that wants a gradient keeps ATen's differentiable op."""
+    if x.device.type == 'cuda' and x.dtype == torch.float32 and not _native._wants_grad(x):
+        return _native.resize_bilinear(x, scale)
+    import torch.nn.functional as F
+    return F.interpolate(x, scale_factor=[float(v) for v in scale], mode='bilinear', align_corners=False)
+
+
 def resize_flow(flow, scale) -> torch.Tensor:
-    """Bilinear resize of a flow field with the vectors scaled along (utils.py:878-916).  Off the kernel path."""
+    """Bilinear resize of a flow field with the vectors scaled along (utils.py:878-916)."""
     valid_flow = get_valid_vecs(flow, error_string="Error resizing flow: ")
     if isinstance(scale, (float, int)):
         scale = [scale, scale]
@@ -461,8 +472,7 @@ def resize_flow(flow, scale) -> torch.Tensor:
         raise TypeError("Error resizing flow: Scale must be an integer, float, or list or tuple of integers or floats")
     if any(s <= 0 for s in scale):
         raise ValueError("Error resizing flow: Scale values must be larger than 0")
-    import torch.nn.functional as F
-    resized = F.interpolate(valid_flow, scale_factor=list(scale), mode='bilinear', align_corners=False)
+    resized = interpolate_bilinear(valid_flow, scale)
     resized[:, 0] *= scale[1]
     resized[:, 1] *= scale[0]
     return resized.squeeze(0) if len(flow.shape) == 3 else resized

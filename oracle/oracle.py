@@ -62,6 +62,8 @@ def lib():
         L.orc_sample_pts_f32.restype = None
         L.orc_flow_from_matrix_f32.argtypes = [fp, i64, ctypes.c_float, fp, i32, i32, i32]
         L.orc_flow_from_matrix_f32.restype = None
+        L.orc_resize_bilinear_f32.argtypes = [fp, fp, i32, i32, i32, i32, i32, ctypes.c_float, ctypes.c_float]
+        L.orc_resize_bilinear_f32.restype = None
         L.orc_max_threads.restype = ctypes.c_int
         L.orc_set_threads.argtypes = [ctypes.c_int]
         for name in ("orc_warp_bwd_f32", "orc_normalise_coords_f32", "orc_flow_endpoints_f32",
@@ -232,6 +234,33 @@ def flow_from_matrix(matrix, n, h, w, sign=1.0):
     m = _f32(np.asarray(matrix, np.float32).reshape(-1, 9))
     out = np.empty((n, 2, h, w), np.float32)
     lib().orc_flow_from_matrix_f32(_fp(m), 0 if m.shape[0] == 1 else 9, float(sign), _fp(out), n, h, w)
+    return out
+
+
+def resize_output_size(h, w, scale):
+    """(oh, ow) of F.interpolate(scale_factor=scale): floor of the double product (torch/nn/functional.py)."""
+    import math
+    return int(math.floor(float(h) * float(scale[0]))), int(math.floor(float(w) * float(scale[1])))
+
+
+def resize_bilinear(x, scale):
+    """F.interpolate(x [N,C,H,W], scale_factor=[sh, sw], mode='bilinear', align_corners=False) as ATen's CPU kernel computes it
+    (ofl_oracle.c: orc_resize_bilinear_f32)."""
+    x = _f32(x)
+    n, c, h, w = x.shape
+    oh, ow = resize_output_size(h, w, scale)
+    out = np.empty((n, c, oh, ow), np.float32)
+    lib().orc_resize_bilinear_f32(_fp(x), _fp(out), n * c, h, w, oh, ow, float(np.float32(1.0 / float(scale[0]))),
+                                  float(np.float32(1.0 / float(scale[1]))))
+    return out
+
+
+def resize_flow(flow, scale):
+    """utils.py:878-916: the interpolated field with its components scaled along ([:, 0] by the width's factor, [:, 1] by the
+    height's)."""
+    out = resize_bilinear(flow, scale)
+    out[:, 0] *= np.float32(scale[1])
+    out[:, 1] *= np.float32(scale[0])
     return out
 
 

@@ -84,6 +84,14 @@ def test_round3_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.ofl_flow_from_matrix_f32(null, 9, 1.0, one, 1, 4, 4, null) == -1
     assert lib.ofl_flow_from_matrix_f32(one, 9, 0.5, one, 1, 4, 4, null) == -3
     assert lib.ofl_flow_from_matrix_f32(one, 9, 1.0, one, 0, 4, 4, null) == -2
+    # round 4: valid area of a backward warp, bit-exact resize
+    assert lib.ofl_warp_valid_f32(null, 0, 1.0, null, 0, 0.9999, one, 1, 4, 4, null) == -1
+    assert lib.ofl_warp_valid_f32(one, 0, 0.5, null, 0, 0.9999, one, 1, 4, 4, null) == -3
+    assert lib.ofl_warp_valid_f32(one, 0, 1.0, null, 0, 0.9999, one, 0, 4, 4, null) == -2
+    assert lib.ofl_resize_bilinear_f32(null, one, 1, 4, 4, 8, 8, 0.5, 0.5, null) == -1
+    assert lib.ofl_resize_bilinear_f32(one, one, 1, 4, 4, 0, 8, 0.5, 0.5, null) == -2
+    assert lib.ofl_resize_bilinear_f32(one, one, 70000, 4, 4, 8, 8, 0.5, 0.5, null) == -2
+    assert lib.ofl_resize_bilinear_f32(one, one, 1, 4, 4, 8, 8, 0.0, 0.5, null) == -3
     # the fallback accumulator is bounded: the pass, capped at 1 GiB
     assert lib.ofl_splat_tiled_fallback_images(64, 5, 1080, 1920) == 25 and lib.ofl_splat_tiled_fallback_images(4, 5, 1080, 1920) == 4
     assert lib.ofl_splat_tiled_fallback_images(16, 4, 2160, 3840) == 8 and lib.ofl_splat_tiled_fallback_images(3, 5, 16384, 16384) == 1

@@ -7,7 +7,8 @@ Bars:
     batched matmul; pad / unpad move values) -- for a GIVEN matrix; where the matrix itself comes out of host linear algebra
     (`_host_algebra`) the fixture is met within 1e-5 of the field's scale and the kernel is pinned against the oracle on
     matrices formed on this host;
-  * resize: the reference calls `F.interpolate` on the flow's device (utils.py:912) -- on a HIP device that is ATen's GPU kernel,
+  * resize (round 4): BIT-EXACT -- `ofl_resize_bilinear_f32` restates the arithmetic of ATen's CPU kernels; until round 3 the package
+    called `F.interpolate` on the flow's device as the reference does (utils.py:912) -- on a HIP device that is ATen's GPU kernel,
     whose interpolation weights round differently from ATen's CPU kernel in the last bits: |got - expected| <= 1e-5 * max|expected|
     (fp32 tolerance, stated here); the resized MASK (a rounded interpolation of 0 / 1 values) bit for bit.
 """
@@ -48,7 +49,7 @@ def _host_algebra(case):
 def test_generator_case_gpu(cid, golden, dev):
     case = golden.cases[cid]
     got = case_runner.run_case(case, golden, dev)
-    if (case["op"] in ('resize_flow', 'Flow.resize') and not case["args"].get("raises")) or _host_algebra(case):
+    if _host_algebra(case):                    # (round 4: resize is bit-exact -- ofl_resize_bilinear_f32 restates ATen's CPU kernels)
         _, exp = golden.arrays(case)
         scale = max([float(np.abs(v).max()) for v in exp.values() if v.dtype.kind == 'f' and v.size] + [1.0])
         case_runner.check_case(case, golden, got, exact_values=False, rtol=0.0, atol=1e-5 * scale, max_mask_flips=0)
@@ -124,3 +125,27 @@ def test_flow_from_matrix_broadcasts_n_matrices_over_a_batch_of_one(dev):
     got = ofl.utils.flow_from_matrix(mats.to(dev), [1, 20, 28])
     assert tuple(got.shape) == (2, 2, 20, 28)
     assert np.array_equal(got.cpu().numpy(), oracle.flow_from_matrix(mats.numpy(), 2, 20, 28))
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 12, 16), (3, 2, 37, 53), (2, 1, 64, 64), (1, 2, 270, 480), (2, 2, 1080, 1920)])
+def test_resize_on_the_device_equals_atens_cpu_kernels_bit_for_bit(shape, dev):
+    """ofl_resize_bilinear_f32 == F.interpolate on the HOST (the reference's PyTorch-CPU path) == the oracle: both of ATen's
+    kernels (oh + ow <= 128 and above), a copied dimension, up- and down-sampling; resize_flow's component scaling on top."""
+    import torch.nn.functional as F
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) * 9
+    for sf in [(0.5, 0.5), (2, 2), (1.5, 1.5), (0.7, 1.3), (1.3, 0.8), (0.3, 2.7), (1, 1), (1.01, 0.99), (0.125, 0.25)]:
+        if shape[-1] >= 1000 and max(sf) > 1.5:
+            continue
+        ref = F.interpolate(x, scale_factor=[float(sf[0]), float(sf[1])], mode='bilinear', align_corners=False)
+        got = _native.resize_bilinear(x.to(dev), sf)
+        assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (shape, sf)
+        assert np.array_equal(got.cpu().numpy(), oracle.resize_bilinear(x.numpy(), sf))
+    if shape[1] == 2:
+        out = ofl.resize_flow(x.to(dev), [1.5, 0.7])
+        assert out.device.type == 'cuda' and np.array_equal(out.cpu().numpy(), oracle.resize_flow(x.numpy(), [1.5, 0.7]))
+        assert torch.equal(out.cpu(), ofl.resize_flow(x, [1.5, 0.7]))           # the host route (ATen's CPU kernel itself)
+

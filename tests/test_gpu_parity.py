@@ -587,7 +587,7 @@ def test_splat_of_a_difference_equals_the_materialised_difference(kind, dev):
         plain = _native.splat_fwd(flow, a - b, **kw)
     finally:
         _native.set_splat_path(0)
-    if kind in ("two_pass_inside", "general_path"):            # float atomics: order differs from run to run
+    if kind in ("two_pass_inside", "general_path", "narrow"):  # float atomics (W < 4 takes the two-pass path too): order differs from run to run
         np.testing.assert_allclose(fused[0].cpu().numpy(), plain[0].cpu().numpy(), rtol=3e-5, atol=3e-4)
     else:
         assert torch.equal(fused[0], plain[0])

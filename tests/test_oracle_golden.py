@@ -225,3 +225,39 @@ def test_torch_op_sequence_combine_mode3_t(cid, golden):
     v, m = torch_ops.combine_mode3_t(torch.tensor(i["f1"]), torch.tensor(i["m1"]), torch.tensor(i["f2"]), torch.tensor(i["m2"]))
     _exact(v.numpy(), exp["vecs"], "vecs")
     _exact(m.numpy(), exp["mask"], "mask")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 4: ATen's CPU bilinear resize restated (orc_resize_bilinear_f32) -- pinned on the reference's own resize fixtures and on torch
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cid", ["gen.resize_flow_half", "gen.resize_flow_x2", "gen.resize_flow_aniso", "gen.resize_flow_tuple",
+                                 "gen.Flow_resize_half_s", "gen.Flow_resize_aniso_s", "gen.Flow_resize_half_t", "gen.Flow_resize_aniso_t"])
+def test_oracle_resize_against_the_reference_fixtures(cid, golden):
+    case = golden.cases[cid]
+    i, o = golden.arrays(case)
+    sc = case["args"]["scale"]
+    sc = [sc, sc] if isinstance(sc, (int, float)) else list(sc)
+    flow = i["flow"] if "flow" in i else i["f"]
+    got = oracle.resize_flow(flow, sc)
+    exp = o["out"] if "out" in o else o["vecs"]
+    assert got.shape == exp.shape and np.array_equal(got, exp), cid
+    if "mask" in o:                                           # flow_class.py:710-713: the mask interpolated as floats, then rounded
+        m = oracle.resize_bilinear(i["m"].astype(np.float32)[:, None], sc)[:, 0]
+        assert np.array_equal(np.rint(m).astype(bool), o["mask"].astype(bool)), cid
+
+
+def test_oracle_resize_equals_atens_cpu_kernels():
+    """Both of ATen's CPU kernels (it picks by output size: oh + ow <= 128), the copied dimension, up- and down-sampling."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(12)
+    for shape in [(1, 2, 12, 16), (3, 2, 37, 53), (2, 1, 64, 64), (1, 2, 90, 140), (1, 2, 1, 9), (1, 2, 2, 2)]:
+        x = torch.randn(*shape, generator=g) * 7
+        for sf in [(0.5, 0.5), (2, 2), (1.5, 1.5), (0.7, 1.3), (1.3, 0.8), (0.3, 2.7), (1, 1), (1.01, 0.99), (0.125, 4.0)]:
+            try:
+                ref = F.interpolate(x, scale_factor=[float(sf[0]), float(sf[1])], mode='bilinear', align_corners=False).numpy()
+            except RuntimeError:
+                continue
+            got = oracle.resize_bilinear(x.numpy(), sf)
+            assert got.shape == ref.shape and np.array_equal(got, ref), (shape, sf)
+
