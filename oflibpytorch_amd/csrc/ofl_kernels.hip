@@ -1479,6 +1479,61 @@ __device__ __forceinline__ void sp_use_presum(const f4* rec4, uint32_t ia, uint3
     }
 }
 
+#ifndef OFL_SP_LANEMAX
+#define OFL_SP_LANEMAX 12
+#endif
+constexpr int kSpLaneMax = OFL_SP_LANEMAX;   // longest cell ONE lane puts in raster order (insertion on its chain); longer ones (up to kSpLong) are a wave's
+
+// A cell with kSpLaneMax < cn <= 64 records, ordered and summed by the 64 lanes of one wave (every lane of the wave calls this
+// with the same cell).  Leaves what the single-lane path leaves: the four class sums of every channel in the cell's first
+// three records (raster order) and the kLongCell marker in its slots.
+template <int NC, int NCH>
+__device__ __attribute__((noinline)) void sp_order_big_cell(unsigned char* raw, const uint32_t* ccnt, uint2* slots, const uint32_t* ohead,
+                                                  const uint16_t* link, int c, int lane) {
+    constexpr uint32_t kEnd = 0xffffu, kLongCell = 0xfffeu;
+    uint32_t* recw = reinterpret_cast<uint32_t*>(raw);
+    float* recf = reinterpret_cast<float*>(raw);
+    const int cn = (int)__builtin_amdgcn_readfirstlane((int)ccnt[c]);
+    // 1. the cell's record indices, one per lane: its four slots, then its chain (walked once; every lane reads the same word)
+    const uint2 sl4 = slots[c];
+    uint32_t idx = lane == 0 ? (sl4.x & 0xffffu) : lane == 1 ? (sl4.x >> 16) : lane == 2 ? (sl4.y & 0xffffu) : (sl4.y >> 16);
+    uint32_t cur = ohead[c];
+    for (int j = 4; j < cn; ++j) {
+        const uint32_t cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        idx = lane == j ? cs : idx;
+        cur = cs != kEnd ? (uint32_t)link[cs] : kEnd;
+    }
+    const bool mine = lane < cn;
+    // 2. rank of every record = number of keys below its own (keys are source positions: all different)
+    const uint32_t key = mine ? recw[8 * idx + 7] : 0xffffffffu;
+    uint32_t rank = 0;
+    for (int t = 0; t < cn; ++t) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, t) < key) ? 1u : 0u;
+    // 3. lane r gets the index of the r-th record in raster order (forward permute among the cn active lanes)
+    uint32_t sorted = 0;
+    if (mine) sorted = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)idx);
+    // 4. lane (class k, channel ch) adds its sum over the records in that order
+    const int k = lane & 3, ch = lane >> 2;
+    const bool acc_on = ch < 1 + NCH;
+    const bool is_mask = NCH > NC && ch == 1 + NC;
+    const int doff = (ch >= 1 && ch <= NC) ? 3 + ch : 7;          // word of the record this lane multiplies the weight with
+    float acc = 0.0f;
+    for (int r = 0; r < cn; ++r) {
+        const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)sorted, r);
+        const float wv = recf[8 * ir + k];
+        const uint32_t dw = recw[8 * ir + doff];
+        const float dv = ch == 0 ? 1.0f : (is_mask ? (float)(dw & 1u) : __uint_as_float(dw));
+        acc += wv * dv;                                            // (density: the weight itself -- w * 1 is exact)
+    }
+    // 5. the class sums where the cell's readers expect them: one f4 (the four classes) per channel, in the first three records
+    const uint32_t ia = (uint32_t)__builtin_amdgcn_readlane((int)sorted, 0), ib = (uint32_t)__builtin_amdgcn_readlane((int)sorted, 1);
+    const uint32_t ic = (uint32_t)__builtin_amdgcn_readlane((int)sorted, 2);
+    if (acc_on) {
+        const uint32_t f4i = ch < 2 ? 2 * ia + ch : ch < 4 ? 2 * ib + (ch - 2) : 2 * ic;
+        recf[4 * f4i + k] = acc;
+    }
+    if (lane == 0) slots[c] = make_uint2(kLongCell | (ia << 16), ib | (ic << 16));
+}
+
 // exchange with the neighbouring lane (lanes 2j <-> 2j + 1): the pair's partner owns the other half of a 4-pixel group
 __device__ __forceinline__ float swap1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); }
 __device__ __forceinline__ uint32_t swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }
@@ -1715,6 +1770,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     constexpr int kLongQ = (kSpQ / 3 + 7) & ~7;
     __shared__ uint16_t lq[kLongQ];
     __shared__ int lqn;
+    // ... and, of those, the cells with more than kSpLaneMax records: a WAVE orders and sums each of them (below)
+    constexpr int kBigQ = kSpQ / (kSpLaneMax + 1) + 1;
+    __shared__ uint16_t bq[kBigQ];
+    __shared__ int bqn;
     f4* rec4 = reinterpret_cast<f4*>(raw);                            // rec4[2 * i] weights, rec4[2 * i + 1] data | key
     const uint32_t* rwords = reinterpret_cast<const uint32_t*>(raw);  // key of record i: rwords[8 * i + 7]
     uint32_t* ccnt = reinterpret_cast<uint32_t*>(raw + kSpQ * 32);    // [kCellsP]: records of the cell
@@ -1848,6 +1907,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             if (tid == 0) {
                 qcount = 0;
                 lqn = 0;
+                bqn = 0;
             }
             __syncthreads();
             scan(r0, r1, 0);
@@ -1880,6 +1940,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 const int c = lq[qi];
                 const uint32_t cn = ccnt[c];
                 if (cn > (uint32_t)kSpLong) { toolong = true; continue; }   // the limit is on the LENGTH: the same in every run
+                if (cn > (uint32_t)kSpLaneMax) { bq[atomicAdd(&bqn, 1)] = (uint16_t)c; continue; }   // a wave's job (below)
                 const uint2 sl4 = slots[c];
                 uint32_t e[4] = {sl4.x & 0xffffu, sl4.x >> 16, sl4.y & 0xffffu, sl4.y >> 16};
                 // the class sums, in raster order: product rounded, then added (as sp_use does for the short cells)
@@ -1938,7 +1999,21 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 }
                 slots[c] = make_uint2(kLongCell | (ia << 16), ib | (ic << 16));
             }
-            if (nlong != 0) over = __syncthreads_or((int)toolong) != 0;   // (block-uniform: a tile without such cells needs no barrier here)
+            if (nlong != 0) {                                  // (block-uniform: a tile without such cells needs no barrier here)
+                over = __syncthreads_or((int)toolong) != 0;
+                const int nbig = bqn;
+                if (!over && nbig != 0) {
+                    // Cells with more than kSpLaneMax records (a compression of the flow): one lane ordering such a cell by
+                    // insertion walks a chain in LDS -- two dependent round trips per comparison, ~n^2 / 4 of them: 0.1 ms for 64
+                    // records, and the kernel waited for the block that had drawn it (profiles/r4_splat_variants.txt, 4).  A WAVE
+                    // does it instead, one lane per record: the chain is walked once, every lane counts the keys below its own
+                    // (its rank in raster order), a permute puts the record indices in that order, and lane (class, channel)
+                    // adds its corner-class sum over the records in that order -- product rounded, then added, exactly what the
+                    // single lane did.  ~120 cycles per record instead of ~64 per record SQUARED.
+                    for (int b = tid >> 6; b < nbig; b += kSpNT2 / 64) sp_order_big_cell<NC, NCH>(raw, ccnt, slots, ohead, link, bq[b], lane);
+                    __syncthreads();
+                }
+            }
             if (over) break;
             // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.
             // The pair reads 3 x 2 cells; every record of a cell is fetched once and added to each corner-class sum it

@@ -332,11 +332,12 @@ def test_exact_splat_is_bit_identical_to_the_oracle(shape, sigma, dev):
         pass
 
 
-@pytest.mark.parametrize("patch", [(12, 0.5), (16, 0.3), (20, 0.2)])
+@pytest.mark.parametrize("patch", [(12, 0.5), (16, 0.3), (20, 0.2), (24, 0.16), (22, 0.15)])
 def test_compressing_flows_stay_exact(patch, dev):
     """Patches of the image that the flow shrinks put many source pixels into one unit cell of the destination grid (here 4
-    to ~30 per cell, beyond the four sorted slots of a cell): their lists are sorted as lists and still summed in the
-    reference's order -- bit-identical values, no tile leaves the exact path."""
+    to ~50 per cell, beyond the four sorted slots of a cell): their lists are put in raster order -- up to 12 records by one
+    lane, 13 to 64 by a whole wave (round 4: sp_order_big_cell) -- and still summed in the reference's order: bit-identical
+    values, no tile leaves the exact path."""
     from oflibpytorch_amd import _native
     from oracle import oracle
     _native.collect_splat_stats = True
@@ -359,6 +360,8 @@ def test_compressing_flows_stay_exact(patch, dev):
     dd = np.concatenate([data.cpu().numpy(), ca.cpu().numpy()[:, None].astype(np.float32)], 1)
     ref, rwarped, rden = oracle.apply_s_flow(flow.cpu().numpy(), dd, wm.cpu().numpy(), True, return_density=True)
     assert rden.max() > 3.5                                   # the case does exercise long cell lists
+    if sc < 0.18:
+        assert rden.max() > 20.0                              # ... and the wave-ordered ones (more than 12 records in a cell)
     assert np.array_equal(out[0].cpu().numpy(), ref[:, :c])
     assert np.array_equal(out[1].cpu().numpy(), ref[:, c])
     assert np.array_equal(out[2].cpu().numpy(), rden)

@@ -12,7 +12,7 @@ from oflibpytorch_amd import _native
 
 lib = _native.load_library(os.path.join(ROOT, "tools/microbench/var/stamps.so"))
 dev = torch.device('cuda', 0)
-n, h, w = 16, 1080, 1920
+n, h, w = int(os.environ.get('STAMP_BATCH', '16')), 1080, 1920
 names = ["0 list head + tile's own flow (round trip 1)", "1 cell init + barrier", "2 step loads arrive (round trip 2)", "3 hit test, ranks, records",
          "4 scan loop tail", "5 barrier after scan", "6 phase S + barriers", "7 phase C", "8 finalize, stores issued", "9 store drain + flag word"]
 for sigma in (8.0, 2.0):
@@ -22,7 +22,7 @@ for sigma in (8.0, 2.0):
     fn = lambda: A.apply(img, target_mask=tm, return_valid_area=True)
     fn(); torch.cuda.synchronize()
     import numpy as np
-    blocks = 65280
+    blocks = ((n * 60 * 68 + 7) // 8) * 8
     buf = np.zeros(blocks * 16, dtype=np.uint32)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()
@@ -35,3 +35,17 @@ for sigma in (8.0, 2.0):
         sigma, len(b), e0.elapsed_time(e1), tot, tot / 100.0, *np.percentile(b[:, :10].sum(1), [50, 90, 99, 100])))
     for k in range(10):
         print("   %-48s %8.1f ticks/block  %5.1f %%" % (names[k], per[k], 100.0 * per[k] / tot))
+    life = b[:, :10].sum(1)
+    order = np.argsort(-life)[:8]
+    print("   slowest blocks (ticks per phase 0..9):")
+    for o in order:
+        print("      life %7.0f : %s | scans %d steps %d %s" % (life[o], " ".join("%6.0f" % v for v in b[o, :10]), b[o, 10], b[o, 11], "FOLD" if b[o, 15] == 2 else ""))
+    print("   blocks by number of scans: " + ", ".join("%d scans: %d blocks, mean life %.0f" % (k, int((b[:, 10] == k).sum()), life[b[:, 10] == k].mean()) for k in sorted(set(b[:, 10].astype(int)))))
+    for k in sorted(set(b[:, 10].astype(int))):
+        g = b[b[:, 10] == k]
+        print("      %d scans: mean ticks per phase %s  | steps %.1f" % (k, " ".join("%6.0f" % v for v in g[:, :10].mean(0)), g[:, 11].mean()))
+    print("   fold tiles: %d, mean life %.0f" % (int((b[:, 15] == 2).sum()), life[b[:, 15] == 2].mean() if (b[:, 15] == 2).any() else 0))
+    srt = np.sort(life)[::-1]
+    print("   sum of the slowest 1 %% of the blocks: %.1f %% of all block time; blocks over 3x the median: %d" % (
+        100.0 * srt[:max(1, len(srt) // 100)].sum() / life.sum(), int((life > 3 * np.median(life)).sum())))
+
