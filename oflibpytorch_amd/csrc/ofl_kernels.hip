@@ -987,10 +987,9 @@ __device__ __forceinline__ int fb_slot(const SplatParams& p, int n) {
 }
 
 template <int CT, typename TF = float>
-__global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
-    // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid that leaves at once when no
-    // image of the pass is flagged; otherwise one block per tile, XCD-aware
-    if (p.run_if_set && *p.any_set == 0) return;
+__device__ __forceinline__ void splat_fwd_tiles(const SplatParams& p) {
+    // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid walks the tiles of the flagged
+    // images; otherwise one block per tile, XCD-aware
   for (int64_t tile = p.run_if_set ? (int64_t)blockIdx.x : logical_block(p.per_xcd); tile < p.total_tiles; tile += p.run_if_set ? (int64_t)gridDim.x : p.total_tiles) {
     const int tx = (int)(tile % p.tiles_x);
     const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
@@ -1072,14 +1071,17 @@ __global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
   }
 }
 
+template <int CT, typename TF = float>
+__global__ __launch_bounds__(256) void splat_fwd_kernel(const SplatParams p) {
+    if (p.run_if_set && *p.any_set == 0) return;
+    splat_fwd_tiles<CT, TF>(p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward splat, pass 2 (ofl_splat_finalize_f32)
 // ------------------------------------------------------------------------------------------------
 template <int CT, typename TF = float, typename TO = float>
-__global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p) {
-    // armed by device flags (the fallback inside ofl_splat_tiled_f32): a small strided grid that leaves at once when no
-    // image of the pass is flagged; otherwise one block per tile, XCD-aware
-    if (p.run_if_set && *p.any_set == 0) return;
+__device__ __forceinline__ void splat_finalize_tiles(const SplatParams& p) {
   for (int64_t tile = p.run_if_set ? (int64_t)blockIdx.x : logical_block(p.per_xcd); tile < p.total_tiles; tile += p.run_if_set ? (int64_t)gridDim.x : p.total_tiles) {
     const int tx = (int)(tile % p.tiles_x);
     const int ty = (int)((tile / p.tiles_x) % p.tiles_y);
@@ -1152,6 +1154,55 @@ __global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p
   }
 }
 
+template <int CT, typename TF = float, typename TO = float>
+__global__ __launch_bounds__(256) void splat_finalize_kernel(const SplatParams p) {
+    if (p.run_if_set && *p.any_set == 0) return;
+    splat_finalize_tiles<CT, TF, TO>(p);
+}
+
+// The two-pass fallback INSIDE ofl_splat_tiled_f32 as ONE launch: until round 4 every call paid three guard launches (zero the
+// accumulator, scatter, finalize) that left at once when no image was flagged -- 15 us of every call, a fifth of a call on a small
+// frame.  This kernel leaves at once too; when some image IS flagged (a list overflowed: a pathological flow) its blocks run the
+// three passes with a grid-wide barrier in between.  The grid is small enough to be resident as a whole (one block per CU), the
+// barrier is an arrival counter in the call's statistics words (the last block to leave the second barrier zeroes it again for
+// the next launch), and each side of it is a device-scope fence -- the accumulator is zeroed by plain stores that sit in one
+// XCD's L2 until they are written back.
+__device__ __forceinline__ void sp_grid_barrier(int32_t* counter, int32_t target) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __threadfence();
+}
+
+template <int CT, typename TF = float, typename TO = float>
+__global__ __launch_bounds__(256) void splat_fallback_kernel(const SplatParams p, float* __restrict__ accum, int64_t count_per_image,
+                                                             int32_t n_images, int32_t* __restrict__ arrivals) {
+    if (*p.any_set == 0) return;
+    const int32_t blocks = (int32_t)gridDim.x;
+    const int64_t n4 = count_per_image >> 2;
+    for (int n = 0; n < n_images; ++n) {                  // zero the accumulator slots of this round's flagged images
+        const int slot = fb_slot(p, n);
+        if (slot < 0) continue;
+        float* __restrict__ q = accum + (int64_t)slot * count_per_image;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)blocks * 256)
+            reinterpret_cast<f4u*>(q)[i] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (blockIdx.x == 0 && threadIdx.x < (count_per_image & 3)) q[(n4 << 2) + threadIdx.x] = 0.0f;
+    }
+    sp_grid_barrier(arrivals, blocks);
+    splat_fwd_tiles<CT, TF>(p);
+    sp_grid_barrier(arrivals, 2 * blocks);
+    // every block is past the second spin once it gets here: the last one to say so leaves both words zero
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(arrivals + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == blocks - 1) {
+        __hip_atomic_store(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(arrivals + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    splat_finalize_tiles<CT, TF, TO>(p);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // forward splat, GATHER formulation (ofl_splat_tiled_f32): the destination tile finds its own sources
@@ -1208,6 +1259,7 @@ constexpr int kRegH = 16;                                    // a bin block cove
 static_assert(kSubH == 2 || kSubH == 4, "subtile height");
 constexpr int kBinCap = (512 / kSubH) * (kSpTW / 32);        // subtiles one destination tile can list (fixed-address lists: 4 * kBinCap bytes per tile)
 constexpr int kBinSpread = 256;                              // destination tiles one subtile may touch
+constexpr unsigned kFallbackBlocks = 256;                    // grid of the two-pass fallback inside the tiled splat: one block per CU, resident as a whole
 constexpr int kSpLong = 64;   // longest cell list (source pixels whose end points share one unit cell) that is summed in raster order
 
 __device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {   // per byte: non-zero -> 0x01 (SWAR: the low 7 bits carry into bit 7)
@@ -2159,19 +2211,6 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
     }
 }
 
-// zero the fallback accumulator of the images that take the atomics path
-__global__ __launch_bounds__(256) void zero_if_set_kernel(float* __restrict__ ptr, int64_t count_per_image, const SplatParams p) {
-    if (*p.any_set == 0) return;
-    const int n = blockIdx.y;
-    const int slot = fb_slot(p, n);
-    if (slot < 0) return;
-    float* __restrict__ q = ptr + (int64_t)slot * count_per_image;
-    const int64_t n4 = count_per_image >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
-        reinterpret_cast<f4u*>(q)[i] = (f4){0.f, 0.f, 0.f, 0.f};
-    if (blockIdx.x == 0 && threadIdx.x < (count_per_image & 3)) q[(n4 << 2) + threadIdx.x] = 0.0f;
-}
-
 // ------------------------------------------------------------------------------------------------
 // flow flags (ofl_flow_flags_f32)
 // ------------------------------------------------------------------------------------------------
@@ -2941,21 +2980,18 @@ static int splat_tiled_impl(
             const int planes = 1 + cg + (fb.with_mask_chan ? 1 : 0);
             unsigned g2;
             tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
-            if (g2 > 2048u) g2 = 2048u;                       // (strided: the kernels walk the tiles of the flagged images)
+            if (g2 > kFallbackBlocks) g2 = kFallbackBlocks;   // (strided: the kernel walks the tiles of the flagged images; resident as a whole -- its passes meet at grid barriers)
             for (int64_t r0 = 0; r0 < nn; r0 += fb.fb_slots) {
                 fb.fb_round = (int32_t)(r0 / fb.fb_slots);
-                hipLaunchKernelGGL(zero_if_set_kernel, dim3(64, (unsigned)nn), dim3(256), 0, st, accum_fallback, (int64_t)planes * hw, fb);
+                int32_t* arrivals = gp.stats + 4;           // two words, zeroed with the statistics words at the start of the call and left zero by every launch
+                const int64_t cpi = (int64_t)planes * hw;
                 if (half_in) {
-                    hipLaunchKernelGGL((splat_fwd_kernel<2, _Float16>), dim3(g2), dim3(256), 0, st, fb);
-                    if (elem == 2) hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, _Float16>), dim3(g2), dim3(256), 0, st, fb);
-                    else hipLaunchKernelGGL((splat_finalize_kernel<2, _Float16, float>), dim3(g2), dim3(256), 0, st, fb);
+                    if (elem == 2) hipLaunchKernelGGL((splat_fallback_kernel<2, _Float16, _Float16>), dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals);
+                    else hipLaunchKernelGGL((splat_fallback_kernel<2, _Float16, float>), dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals);
                 } else switch (cg) {
-                    case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(g2), dim3(256), 0, st, fb);
-                            hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(g2), dim3(256), 0, st, fb); break;
-                    case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(g2), dim3(256), 0, st, fb);
-                            hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(g2), dim3(256), 0, st, fb); break;
-                    default: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(g2), dim3(256), 0, st, fb);
-                             hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(g2), dim3(256), 0, st, fb); break;
+                    case 1: hipLaunchKernelGGL(splat_fallback_kernel<1>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
+                    case 2: hipLaunchKernelGGL(splat_fallback_kernel<2>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
+                    default: hipLaunchKernelGGL(splat_fallback_kernel<3>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
                 }
             }
         }

@@ -45,6 +45,13 @@ for sigma in (8.0, 2.0):
         g = b[b[:, 10] == k]
         print("      %d scans: mean ticks per phase %s  | steps %.1f" % (k, " ".join("%6.0f" % v for v in g[:, :10].mean(0)), g[:, 11].mean()))
     print("   fold tiles: %d, mean life %.0f" % (int((b[:, 15] == 2).sum()), life[b[:, 15] == 2].mean() if (b[:, 15] == 2).any() else 0))
+    # list length and records wanted (first scan) against the number of scans
+    nl, nr = b[:, 12], b[:, 13]
+    for lo, hi in ((0, 32), (32, 40), (40, 48), (48, 56), (56, 64), (64, 1000)):
+        sel = (nl >= lo) & (nl < hi)
+        if sel.any():
+            print("      list %3d..%3d: %6d tiles, records wanted mean %.0f, > %d records: %.1f %%, mean life %.0f" % (
+                lo, hi, int(sel.sum()), nr[sel].mean(), 896, 100.0 * (nr[sel] > 896).mean(), life[sel].mean()))
     srt = np.sort(life)[::-1]
     print("   sum of the slowest 1 %% of the blocks: %.1f %% of all block time; blocks over 3x the median: %d" % (
         100.0 * srt[:max(1, len(srt) // 100)].sum() / life.sum(), int((life > 3 * np.median(life)).sum())))
