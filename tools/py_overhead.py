@@ -15,8 +15,10 @@ m2 = torch.rand(n, h, w, device=dev) > 0.1
 img = torch.rand(n, 3, h, w, device=dev)
 tm = torch.rand(n, h, w, device=dev) > 0.1
 A, B = ofl.Flow(f1, 't', m1), ofl.Flow(f2, 't', m2)
+S = ofl.Flow(f1, 's', m1)
 calls = {"Flow()": lambda: ofl.Flow(f1, 't', m1), "apply": lambda: B.apply(img, target_mask=tm, return_valid_area=True),
-         "combine3": lambda: A.combine_with(B, 3)}
+         "combine3": lambda: A.combine_with(B, 3), "apply_s": lambda: S.apply(img, target_mask=tm, return_valid_area=True),
+         "switch_ref": lambda: S.switch_ref()}
 for name, fn in calls.items():
     for _ in range(50):
         fn()
@@ -27,7 +29,7 @@ for name, fn in calls.items():
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     print("%-10s %.1f us per call (host)" % (name, (t1 - t0) / 2000 * 1e6))
-for name in ("apply", "combine3", "Flow()"):
+for name in sys.argv[1:] or ("apply", "combine3", "Flow()"):
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(2000):
