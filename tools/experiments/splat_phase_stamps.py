@@ -15,7 +15,7 @@ dev = torch.device('cuda', 0)
 n, h, w = int(os.environ.get('STAMP_BATCH', '16')), 1080, 1920
 names = ["0 list head + tile's own flow (round trip 1)", "1 cell init + barrier", "2 step loads arrive (round trip 2)", "3 hit test, ranks, records",
          "4 scan loop tail", "5 barrier after scan", "6 phase S + barriers", "7 phase C", "8 finalize, stores issued", "9 store drain + flag word"]
-for sigma in (8.0, 2.0):
+for sigma in [float(v) for v in os.environ.get("STAMP_SIGMAS", "8,2").split(",")]:
     f1 = bench.smooth_flow(n, h, w, sigma, 1003, dev)
     _, _, img, m1, m2, tm = bench.make_inputs(n, h, w, dev, 0)
     A = ofl.Flow(f1, 's', m1)
