@@ -248,7 +248,7 @@ def flow_flags(vecs: torch.Tensor, mask: torch.Tensor = None) -> torch.Tensor:
 _HOST_WORDS = 1 << 12        # flag words one call can hand over (larger batches take the copy + event route)
 _WORK_EXTRA = 33             # OFL_FLAGS_HOST_WORK_EXTRA
 _MAX_SLOTS = 8               # per device; a ninth concurrent caller waits for a slot
-_host_slots = {}             # device index -> list of slots [lock, device work words, host address, int32 view of the pairs, last serial]
+_host_slots = {}             # device index -> list of slots [lock, device work words, host address, int32 view of the pairs, last serial, retired]
 _host_slots_lock = threading.Lock()
 _SPIN_SLACK_SECONDS = 150e-6  # tight polling lasts ~2x the time the reduction's bytes take plus this; after that the wait yields the GIL between looks
 _YIELD_SECONDS = 20e-3        # ... and after this long it sleeps 50 us between looks
@@ -261,33 +261,41 @@ def _new_host_slot(lib, dev):
         _check(lib.ofl_host_words_alloc(2 * _HOST_WORDS, ctypes.byref(addr)), "ofl_host_words_alloc")
         work = torch.zeros(_HOST_WORDS + _WORK_EXTRA, dtype=torch.int32, device=dev)
     view = np.ctypeslib.as_array((ctypes.c_int32 * (2 * _HOST_WORDS)).from_address(addr.value))
-    return [threading.Lock(), work, addr, view, 0]
+    return [threading.Lock(), work, addr, view, 0, False]
 
 
 def _acquire_host_slot(lib, dev):
     """A slot nobody is using, locked.  The first slot of a device is the fast path (one non-blocking acquire)."""
-    slots = _host_slots.get(dev.index)
-    if slots is not None:
-        for slot in slots:
-            if slot[0].acquire(False):
+    while True:
+        slots = _host_slots.get(dev.index)
+        if slots is not None:
+            for slot in tuple(slots):
+                if slot[0].acquire(False):
+                    if slot[5]:                      # retired after a failed wait while we were looking
+                        slot[0].release()
+                        continue
+                    return slot
+        with _host_slots_lock:
+            slots = _host_slots.setdefault(dev.index, [])
+            if len(slots) < _MAX_SLOTS:
+                slot = _new_host_slot(lib, dev)
+                slot[0].acquire()
+                slots.append(slot)
                 return slot
-    with _host_slots_lock:
-        slots = _host_slots.setdefault(dev.index, [])
-        if len(slots) < _MAX_SLOTS:
-            slot = _new_host_slot(lib, dev)
-            slot[0].acquire()
-            slots.append(slot)
-            return slot
-    slots[0][0].acquire()
-    return slots[0]
+            busy = slots[0]
+        busy[0].acquire()                            # the pool is full: queue behind its first slot
+        if not busy[5]:
+            return busy
+        busy[0].release()                            # (it was retired while we waited: look again)
 
 
 def _drop_host_slot(dev, slot):
     """After a failed wait the slot's work words may be dirty: forget it (its successor starts from zeroed words)."""
     with _host_slots_lock:
+        slot[5] = True
         slots = _host_slots.get(dev.index)
-        if slots is not None and slot in slots:
-            slots.remove(slot)
+        if slots is not None:
+            _host_slots[dev.index] = [s for s in slots if s is not slot]
 
 
 def flow_flags_host(vecs: torch.Tensor, mask: torch.Tensor = None):

@@ -12,6 +12,7 @@ Differences from the reference that do not change results:
   * intermediates produced by the kernels are not re-validated eagerly.
 """
 import warnings
+import weakref
 from typing import Tuple, Union
 
 import numpy as np
@@ -62,6 +63,21 @@ def _storage_ptr(t):
         return id(t)
 
 
+_private_flows = weakref.WeakSet()   # the flows whose `_private` is set: kernel outputs that are inference tensors (empty outside inference mode)
+
+
+def _sharing_ends_privacy(vecs, mask):
+    """`vecs` / `mask` are about to be wrapped by another flow object (a copy, a view, a relabelled or negated flow that keeps
+    the mask): whoever held their storage privately no longer does -- an in-place edit through the new object must not meet
+    the old one's cached flag word.  Costs nothing unless private flows exist (inference mode only)."""
+    if not _private_flows:
+        return
+    ptrs = set(_storage_ptr(t) for t in (vecs, mask) if t is not None)
+    for f in list(_private_flows):
+        if _storage_ptr(f._fv) in ptrs or (f._mask is not None and _storage_ptr(f._mask) in ptrs):
+            f._release_private()
+
+
 class Flow(object):
     # ------------------------------------------------------------------------------------------
     # construction / properties (flow_class.py:37-236)
@@ -107,6 +123,7 @@ class Flow(object):
             self._require_finite("Error setting flow vectors: ")   # the vecs error comes first in the reference
             raise
         self._from_half()
+        _sharing_ends_privacy(self._fv, self._mask)
         self._require_finite("Error setting flow vectors: ")
         self.device = device
 
@@ -120,11 +137,12 @@ class Flow(object):
 
     @classmethod
     def _wrap(cls, vecs: torch.Tensor, ref: str, mask, device=None, flags: torch.Tensor = None,
-              like: FlowAlias = None, fresh: bool = False, made_from: tuple = None) -> FlowAlias:
+              like: FlowAlias = None, fresh: bool = False, made_from: tuple = None, borrowed: bool = False) -> FlowAlias:
         """Internal: wrap tensors that are valid by construction (kernel outputs, views of validated flows).
         `flags` is the device-side flag word a kernel produced as a by-product, read lazily.  `fresh`: vecs and mask were
         allocated by the call that produced them; `made_from`: ... unless they share storage with one of these tensors (the
-        early exits hand their inputs through)."""
+        early exits hand their inputs through).  `borrowed`: a temporary that never leaves the method that makes it (the same
+        tensors under another reference): whoever holds them privately still does."""
         obj = cls.__new__(cls)
         obj._vecs, obj._ref, obj._mask = vecs, ref, mask
         obj._device = vecs.device if device is None else device
@@ -132,7 +150,11 @@ class Flow(object):
         if made_from is not None:
             theirs = set(_storage_ptr(t) for t in made_from if t is not None)
             fresh = _storage_ptr(vecs) not in theirs and (mask is None or _storage_ptr(mask) not in theirs)
-        obj._private = bool(fresh)
+        if not fresh and not borrowed:
+            _sharing_ends_privacy(vecs, mask)
+        elif vecs.is_inference():                # (only inference tensors need it: the others carry version counters)
+            obj._private = True
+            _private_flows.add(obj)
         if obj._fv.device != obj._device:
             obj._vecs = obj._fv.to(obj._device)
         if obj._mask is not None and obj._mask.device != obj._device:
@@ -296,7 +318,9 @@ class Flow(object):
     def _release_private(self):
         """The storage is about to be handed out: from now on somebody else can edit it in place.  Tensors that track versions
         keep their key (an edit bumps it); an inference tensor's key stops matching, so its next use runs the reduction again."""
-        self._private = False
+        if self._private:
+            self._private = False
+            _private_flows.discard(self)
 
     @mask.setter
     def mask(self, input_mask=None):
@@ -745,7 +769,8 @@ class Flow(object):
             return out
         # (-as_s).apply(as_s) with as_s = this flow read as 's' (flow_class.py:1060-1062): one splat P(-f, f||[m], m),
         # the negation folded into the kernel's end points
-        warped, valid, dflags = self.switch_ref(mode='invalid')._warp(self._fv, self._mask, True, True, flow_sign=-1.0)
+        as_s = Flow._wrap(self._fv, 's', self._mask, self._device, like=self, borrowed=True)
+        warped, valid, dflags = as_s._warp(self._fv, self._mask, True, True, flow_sign=-1.0)
         return Flow._wrap(warped, 's', valid, self._device, flags=dflags, made_from=(self._fv, self._mask))
 
     def invert(self, ref: str = None) -> FlowAlias:
@@ -760,7 +785,7 @@ class Flow(object):
         # self.invert('s').switch_ref(): with g = -f read as 's', g.apply(g) = P(-f, -f||[m], m)   (flow_class.py:1084-1086)
         if self._all_zero(_native.FLAG_NZ_MASKED):              # switch_ref's early exit (:1046) on g
             return self._negated('t')
-        warped, valid, dflags = Flow._wrap(self._fv, 's', self._mask, self._device, like=self)._warp(
+        warped, valid, dflags = Flow._wrap(self._fv, 's', self._mask, self._device, like=self, borrowed=True)._warp(
             self._fv, self._mask, True, True, flow_sign=-1.0, data_sign=-1.0)
         return Flow._wrap(warped, 't', valid, self._device, flags=dflags, made_from=(self._fv, self._mask))
 
@@ -1002,7 +1027,7 @@ class Flow(object):
             total, minus = self, field                       # self - field
         else:
             total, minus = field, self                       # field - self
-        warper = self if carry_sign > 0 else Flow._wrap(self._fv, 's', self._mask, self._device, like=self)
+        warper = self if carry_sign > 0 else Flow._wrap(self._fv, 's', self._mask, self._device, like=self, borrowed=True)
         if warper._all_zero(_native.FLAG_NZ_THR) or not get_pure_pytorch() or self.shape[0] != field.shape[0] or not _COMBINE_FUSED:
             carrier = self if carry_sign > 0 else self._negated('s')
             return carrier.apply(total if minus is None else total - minus)

@@ -8,6 +8,7 @@ import os
 import subprocess
 import sys
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -100,6 +101,51 @@ def test_host_route_from_two_threads(dev):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not bad
+
+
+def test_host_route_with_more_threads_than_slots_and_an_interrupted_wait(dev, monkeypatch):
+    """The slots are a pool of _MAX_SLOTS per device: a dozen threads queue for them and each still gets its own words; a wait
+    that is interrupted (KeyboardInterrupt in the poll) retires its slot -- nobody is handed its possibly dirty work words,
+    not even a thread that was queueing for it -- and the next call works."""
+    from oflibpytorch_amd import _native
+    tensors = [torch.full((1 + k % 3, 2, 64 + 8 * k, 96), float(k % 2), device=dev) for k in range(12)]
+    wants = [_native.flow_flags(t).cpu().tolist() for t in tensors]
+    bad = []
+
+    def work(t, want):
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            for _ in range(100):
+                if _native.flow_flags_host(t, None) != want:
+                    bad.append(1)
+    ths = [threading.Thread(target=work, args=(t, w)) for t, w in zip(tensors, wants)]
+    torch.cuda.synchronize()
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad
+    pool = _native._host_slots[dev.index]
+    assert 1 <= len(pool) <= _native._MAX_SLOTS
+
+    class Interrupting(object):                # stands in for the `time` module inside _native: the first look at the clock raises
+        def __init__(self):
+            self.armed = True
+
+        def perf_counter(self):
+            if self.armed:
+                self.armed = False
+                raise KeyboardInterrupt()
+            return time.perf_counter()
+        sleep = staticmethod(time.sleep)
+    before = list(pool)
+    monkeypatch.setattr(_native, "time", Interrupting())
+    with pytest.raises(KeyboardInterrupt):
+        _native.flow_flags_host(tensors[0], None)
+    monkeypatch.undo()
+    after = _native._host_slots[dev.index]
+    retired = [s for s in before if s[5]]
+    assert len(retired) == 1 and all(s is not retired[0] for s in after)
+    assert not retired[0][0].locked()
+    for t, w in zip(tensors, wants):
+        assert _native.flow_flags_host(t, None) == w
 
 
 def test_fp16_flow_vecs_edit_reaches_the_kernels(dev):
@@ -286,4 +332,19 @@ def test_kernel_outputs_keep_their_flag_words_under_inference_mode(dev, monkeypa
         handed.zero_()                              # ... and is edited in place: c is now the zero flow
         e = c.combine_with(b, 3)                    # zero first operand: the second comes back (flow_class.py:1729-1737)
         assert e is b
+        # another flow object over the same storage ends the privacy too: an edit through the copy must reach the original
+        c2 = a.combine_with(b, 3)
+        assert c2._private
+        twin = c2.copy()
+        assert not c2._private and not twin._private
+        twin.vecs.zero_()
+        assert c2.combine_with(b, 3) is b
+        c3 = a.combine_with(b, 3)
+        relabelled = c3.switch_ref(mode='invalid')  # same tensors under the other reference
+        assert not c3._private
+        relabelled.vecs.zero_()
+        assert c3.combine_with(b, 3) is b
+        c4 = a.combine_with(b, 3)
+        _ = c4.invert()                             # an internal temporary over c4's tensors does not end it
+        assert c4._private
     assert per_use <= 2.0
