@@ -131,7 +131,8 @@ def set_splat_pass_images(k: int):
 
 
 def set_warp_path(mode: int):
-    """0 = auto (LDS-staged kernel when eligible), 1 = generic direct-gather kernel only (tests compare the two)."""
+    """0 = auto (LDS-staged kernel when eligible), 1 = generic direct-gather kernel only, 3 / 4 = staged with two tiles / one tile
+    per block whatever the launch size (tests compare them all)."""
     _check(load_library().ofl_set_option(1, int(mode)), "ofl_set_option")
 
 

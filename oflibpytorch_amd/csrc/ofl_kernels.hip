@@ -714,8 +714,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
 }
 
-// The same pipeline over T vertically adjacent tiles (T >= 3; the hand-scheduled two-tile kernel above stays the one for
-// T = 2: written as this loop it leaves its small arrays in scratch).  The two dependent round trips of a tile (flow, then
+// The same pipeline over T vertically adjacent tiles (T >= 3, and T = 1 for tiny launches: one tile per block, nothing to
+// overlap inside it; the hand-scheduled two-tile kernel above stays the one for T = 2: written as this loop it leaves its small
+// arrays in scratch).  The two dependent round trips of a tile (flow, then
 // its staged box) and the drain of its stores are paid once per BLOCK: a taller column of tiles amortises them over more
 // pixels with the same registers and the same LDS -- flow two tiles ahead, staging loads one tile ahead, stores behind.
 // GRAD: the same column pipeline computing the gradient with respect to the flow (`addend` = the upstream gradient [N,NC,H,W],
@@ -2388,7 +2389,7 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
     return (unsigned)(p.per_xcd * kXcds);
 }
 
-int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto)
+int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
@@ -2418,9 +2419,23 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     // ones.  Below that the pair kernel's twice-as-many, half-as-long blocks win: B = 1 / 2 / 4 / 6 at 1080p -4 / -15 / -7 /
     // -5 %, B >= 8 the column kernel by 1-4 % (profiles/r4_small_batch_kernel_choice.txt)
     constexpr unsigned kColumnMinGroups = 6912;
+    // ... and a TINY launch (fewer single tiles than that: a 1080p frame at B = 1 has 4 080) takes ONE tile per block: 2.7 short
+    // rounds of blocks instead of 1.3 long ones -- B = 1 1080p apply 21.7 -> 19.2 us, mode 3 20.6 -> 18.4 us; from B = 2 the
+    // pair kernel is level or ahead (profiles/r4_small_batch_kernel_choice.txt)
+    {
+        WarpParams q1 = p;
+        const unsigned g1 = warp_geometry(q1, kLdsTWQ * 4, kLdsTH);
+        if (g_warp_path == 4 || (g_warp_path != 3 && g1 < kColumnMinGroups)) {
+            if (valid && add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            else if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            else if (add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, false, false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            return (int)hipGetLastError();
+        }
+    }
     WarpParams q = p;
     const unsigned g = (kLdsT > 2 && !add && !p.flow_flags) ? warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) : 0u;
-    if (g >= kColumnMinGroups) {
+    if (g >= kColumnMinGroups && g_warp_path != 3) {
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
@@ -2552,7 +2567,7 @@ extern "C" {
 __attribute__((visibility("default"))) int ofl_version(void) { return 28; }   // 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
-    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 2) { g_warp_path = value; return OFL_OK; }
+    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 4) { g_warp_path = value; return OFL_OK; }
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }

@@ -178,16 +178,17 @@ def test_lds_and_generic_paths_agree(shape, sigma, dev):
                dict(flow_sign=-1.0, src_mask=sm, want_valid=True, addend=add, a_sign=1.0, g_sign=-1.0),
                dict(round_mode=2), dict(flow_mask=fmk, want_valid=True, want_flags=True, want_src_flags=(c == 2))):
         outs = []
-        for path in (0, 1):
+        for path in (0, 1, 3, 4):               # auto, generic, staged two tiles per block, staged one tile per block
             _native.set_warp_path(path)
             try:
                 outs.append(_native.warp_bwd(flow, src, **kw))
             finally:
                 _native.set_warp_path(0)
-        for a, b in zip(*outs):
-            assert (a is None) == (b is None)
-            if a is not None:
-                assert torch.equal(a, b), "LDS path and generic path differ for %s" % (kw,)
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b), "the warp kernels differ for %s" % (kw,)
         # and against the oracle (values bit-exact, masks bit-exact)
         f = flow.cpu().numpy() * np.float32(kw.get("flow_sign", 1.0))
         s = src.cpu().numpy()
