@@ -245,6 +245,12 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_WARP_CLIP_COLUMN
+#define OFL_WARP_CLIP_COLUMN 1
+#endif
+#ifndef OFL_WARP_CLIP
+#define OFL_WARP_CLIP 8      // 0: an oversize box gathers the whole tile from global memory; n: stage its first rows if at least n fit
+#endif
 constexpr int kLdsNT = 128, kLdsTWQ = 8, kLdsTH = kLdsNT / kLdsTWQ, kLdsIters = 3;
 #ifndef OFL_WARP_T
 #define OFL_WARP_T 4
@@ -315,7 +321,7 @@ __device__ __forceinline__ int lds_pitch(int n) {   // smallest P >= n with P % 
 }
 
 struct LdsCoords { float sx[4], sy[4]; };                              // un-normalised sample positions of 4 pixels
-struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits, interior; };   // wave-uniform staging geometry (interior: box staged, every tap of every pixel inside the image)
+struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits, interior, clipped; };   // wave-uniform staging geometry (interior: box staged, every tap of every pixel inside the image; clipped: only the first bh rows of an oversize box are staged)
 
 // Y-SHEARED box: a 32-wide tile under a flow with dv/dx != 0 touches a slanted band of source rows, and a plain bounding
 // box wastes the two triangles above and below it.  Chunk column c (4 pixels) of the staged box therefore starts at image
@@ -344,7 +350,7 @@ __device__ __forceinline__ int lds_slope_row(const WP& p, const float* __restric
 template <int NC> struct LdsStage { int slot[kLdsIters]; f4 q[kLdsIters][NC]; uint32_t mq[kLdsIters]; };
 
 // steps 1-2 for one tile
-template <bool BOX = true, typename WP>
+template <bool BOX = true, bool CLIP = false, typename WP>
 __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
                                                LdsCoords& T, LdsBox& B, int (*red)[4]) {
     constexpr int NW = kLdsNT / 64;
@@ -427,9 +433,18 @@ __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, cons
     const int bw = empty ? 4 : (((maxx + 4) & ~3) - B.bx0);
     B.bh = empty ? 1 : (maxy - miny + 1); B.cw = bw >> 2; B.Pp = lds_pitch(bw); B.nch = B.bh * B.cw;
     B.fits = !empty && (B.bh <= 4096) && (16 * (1 + B.bh * B.Pp) <= p.lds_bytes) && (B.nch <= kLdsIters * kLdsNT);
+    B.clipped = false;
+    if (CLIP && OFL_WARP_CLIP) {
+    // OVERSIZE box (a flow rougher than the budget was sized for): stage the rows that fit and let only the pixels with a tap
+    // below them gather from global memory (lds_gather_impl) -- not all 512 of the tile.  Block-uniform, cold.
+    if (__builtin_expect(!B.fits && !empty && B.bh <= 4096, 0)) {
+        const int keep = min((p.lds_bytes / 16 - 1) / B.Pp, (kLdsIters * kLdsNT) / B.cw);
+        if (keep >= OFL_WARP_CLIP) { B.bh = keep; B.nch = keep * B.cw; B.fits = true; B.clipped = true; }
+    }
+    }
     // image rows the box's first and last chunk column cover (the shear is monotonic in the column)
     const int sa = lds_shear(B.cbase, sq), sb_ = lds_shear(B.cbase + B.cw - 1, sq);
-    B.interior = B.fits && xin && (miny + min(sa, sb_) >= 0) && (maxy + max(sa, sb_) <= h - 1);
+    B.interior = B.fits && !B.clipped && xin && (miny + min(sa, sb_) >= 0) && (maxy + max(sa, sb_) <= h - 1);
 }
 
 // step 3a: issue the staging loads of a tile into registers (nothing waits here)
@@ -496,7 +511,7 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
 // with its upstream gradient `gq` into ATen's gix / giy sums (grid_sampler_2d_backward), chained through the
 // un-normalisation, normalise_coords and `grid - flow` exactly as autograd does -- same expressions, same order as the
 // one-pixel-per-lane kernel of ofl_aux_kernels.hip (the two are compared bit for bit); outv[k] = (d/du, d/dv, -, -).
-template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, bool GRAD = false, typename WP = WarpParams>
+template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, bool GRAD = false, bool CLIP = false, typename WP = WarpParams>
 __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                                                 const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                                 const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
@@ -517,11 +532,14 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
         const bool y0 = INTERIOR || (uint32_t)yi < (uint32_t)h, y1 = INTERIOR || (uint32_t)(yi + 1) < (uint32_t)h;
         const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
         f4 tv[4];
-        if (INTERIOR || __builtin_expect(B.fits, 1)) {
+        const int yr = yi - B.miny;   // row in the sheared box, per tap column
+        const int ra = yr - lds_shear(xi >> 2, B.sq), rb = yr - lds_shear((xi + 1) >> 2, B.sq);
+        // (clipped box: a pixel whose lower taps fall below the staged rows takes the global path below, the others the LDS)
+        const bool staged = INTERIOR || ((CLIP && OFL_WARP_CLIP) ? (B.fits && (!B.clipped || max(ra, rb) + 1 < B.bh)) : __builtin_expect(B.fits, 1));
+        if (staged) {
             const int xl0 = xi - B.bx0, xl1 = xl0 + 1;
             const int cp0 = __mul24(xl0 & 3, cw16) + ((xl0 & ~3) << 2), cp1 = __mul24(xl1 & 3, cw16) + ((xl1 & ~3) << 2);
-            const int yr = yi - B.miny;   // row in the sheared box, per tap column
-            const int r0 = 16 + __mul24(yr - lds_shear(xi >> 2, B.sq), P16), r1 = 16 + __mul24(yr - lds_shear((xi + 1) >> 2, B.sq), P16);
+            const int r0 = 16 + __mul24(ra, P16), r1 = 16 + __mul24(rb, P16);
             int si[4] = {ok[0] ? r0 + cp0 : 0, ok[1] ? r1 + cp1 : 0, ok[2] ? r0 + P16 + cp0 : 0, ok[3] ? r1 + P16 + cp1 : 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
@@ -584,13 +602,13 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
     }
 }
 
-template <int NC, bool VALID, bool SUB = false, typename TS = float, bool GRAD = false, typename WP = WarpParams>
+template <int NC, bool VALID, bool SUB = false, typename TS = float, bool GRAD = false, bool CLIP = false, typename WP = WarpParams>
 __device__ __forceinline__ void lds_gather(const WP& p, uint32_t hw,
                                            const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                            const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
                                            const float* __restrict__ sbb = nullptr, const f4* gq = nullptr) {
-    if (B.interior) lds_gather_impl<NC, VALID, true, SUB, TS, GRAD>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
-    else lds_gather_impl<NC, VALID, false, SUB, TS, GRAD>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
+    if (B.interior) lds_gather_impl<NC, VALID, true, SUB, TS, GRAD, false>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
+    else lds_gather_impl<NC, VALID, false, SUB, TS, GRAD, CLIP>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
 }
 
 // the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
@@ -734,6 +752,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
 #define OFL_WARP_PHASE()
 #endif
     constexpr int NW = kLdsNT / 64;
+    constexpr bool kClip = OFL_WARP_CLIP_COLUMN && T > 1;   // oversize boxes: stage the rows that fit (lds_coords_box); not in the one-tile kernel of tiny launches (+2 % there)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int red[2][NW][4];
     int tx, tyg, n;                      // the grid counts tile GROUPS: tiles_y = ceil(h / (T * kLdsTH))
@@ -775,7 +794,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
 #pragma unroll
     for (int k = 0; k < T; ++k) sq[k] = p.shear ? lds_slope_row(p, fu, hw, tx, (tyg * T + k) * kLdsTH + kLdsTH / 2) : 0;
     note_flags(0);
-    lds_coords_box(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
+    lds_coords_box<true, kClip>(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
     lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[0], S, sbb);          // staging loads of tile 0 fly ...
     // the vmcnt queue is in order: the addend (an L2 hit when it is the flow itself) is fetched BEFORE the next tile's staging
     // loads / this tile's stores, so that waiting for it never waits for them
@@ -789,7 +808,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         const int tyk = tyg * T + k;
         const bool more = (k + 1 < T) && ((tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
         if (k + 1 < T) {
-            if (more) { note_flags(k + 1); lds_coords_box(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
+            if (more) { note_flags(k + 1); lds_coords_box<true, kClip>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
         }
         if (k + 2 < T) load_flow(k + 2);
         lds_write<NC, VALID>(lds, Bx[k], S);
@@ -800,7 +819,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         if (k + 1 < T) {
             if (more) lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[k + 1], S, sbb);   // the next tile's staging loads fly while this one is gathered and stored
         }
-        lds_gather<NC, VALID, SUB, TS, GRAD>(p, hw, sb, sm, Tc[k], Bx[k], smem, outv, sbb, ad);
+        lds_gather<NC, VALID, SUB, TS, GRAD, kClip>(p, hw, sb, sm, Tc[k], Bx[k], smem, outv, sbb, ad);
         if (GRAD) {
             const f4 none[2] = {};
             lds_store<2, false, false, false, float>(p, tx, tyk, n, hw, 0u, outv, none);

@@ -263,6 +263,28 @@ def test_staged_and_generic_grad_flow_kernels_agree(shape, flow_sign, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stretch", [1.6, 2.5, 6.0])
+def test_staged_grad_flow_kernel_with_oversize_boxes(stretch, dev):
+    """The same comparison on a flow that stretches the sampled region: boxes beyond the LDS budget are staged in part (the rows
+    that fit) and the pixels with a tap below them read global memory -- the gradient must not notice."""
+    from oflibpytorch_amd import _native
+    n, c, h, w = 2, 3, 160, 224
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    f = torch.stack([-(xs - w / 2) * (stretch - 1.0) * 0.8, -(ys - h / 2) * (stretch - 1.0)])[None] + _smooth(n, h, w, 2.0, 5)
+    f = f.contiguous().to(dev)
+    g = torch.Generator().manual_seed(3)
+    src = torch.rand(n, c, h, w, generator=g).to(dev) * 10
+    gout = torch.randn(n, c, h, w, generator=g).to(dev)
+    try:
+        _native.set_warp_path(1)
+        _, ref = _native.warp_bwd_grad(f, src, gout, want_src=False, want_flow=True)
+    finally:
+        _native.set_warp_path(0)
+    _, got = _native.warp_bwd_grad(f, src, gout, want_src=False, want_flow=True)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.gpu
 def test_gradients_at_1080p_against_torch_cpu_autograd(dev):
     """gradient parity at the frame size of the benchmark (B = 2, 1080 x 1920, the sigma = 8 bench flow, so the
     gather splat behind the gradient wrt the warp's source crosses fold tiles): apply_flow 't' and 's' and switch_ref against

@@ -157,6 +157,49 @@ def _smooth(n, h, w, sigma, seed, dev):
     return torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous().to(dev)
 
 
+@pytest.mark.parametrize("c", [1, 2, 3])
+@pytest.mark.parametrize("stretch", [1.2, 1.6, 2.5, 6.0])
+def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, dev):
+    """A flow that stretches the sampled region makes a 32 x 16 tile's box larger than the LDS budget (26 KB = 1 663 pixel slots):
+    the four-tile column kernel of LARGE launches stages the rows that fit and only the pixels with a tap below them gather from
+    global memory (OFL_WARP_CLIP); the two-tile, one-tile and generic kernels do not.  All must agree bit for bit, and with the
+    oracle.  stretch 1.2: boxes fit; 1.6 / 2.5: oversize, most rows staged; 6.0: too few rows fit in places (whole-tile fallback).
+    The batch is large enough for the launcher to pick the column kernel (7 x 3 column groups per image: 7 056 >= 6 912)."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    n, h, w = 336, 160, 224
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    # sample position = pixel - flow: x - u = cx + (x - cx) * stretch, likewise y (plus a smooth wobble, another per image)
+    u = -(xs - w / 2) * (stretch - 1.0) * 0.8
+    v = -(ys - h / 2) * (stretch - 1.0)
+    flow = (torch.stack([u, v])[None] + _smooth(n, h, w, 2.0, 23, torch.device('cpu'))).contiguous().to(dev)
+    g = torch.Generator().manual_seed(9)
+    src = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    fmk = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    for kw in (dict(src_mask=sm, flow_mask=fmk, want_valid=True), dict()):
+        outs = []
+        for path in (0, 1, 3, 4):               # auto (= columns of four here), generic, two tiles per block, one tile per block
+            _native.set_warp_path(path)
+            try:
+                outs.append(_native.warp_bwd(flow, src, **kw))
+            finally:
+                _native.set_warp_path(0)
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b)
+        k = 3                                    # (the oracle on the first images only: it is the checker, not the thing timed)
+        s = src[:k].cpu().numpy()
+        if kw.get("want_valid"):
+            s = np.concatenate([s, sm[:k].cpu().numpy().astype(np.float32)[:, None]], 1)
+        gref = oracle.G(flow[:k].cpu().numpy(), s)
+        assert np.array_equal(outs[0][0][:k].cpu().numpy(), gref[:, :c], equal_nan=True)
+        if kw.get("want_valid"):
+            assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > 0.99999) & fmk[:k].cpu().numpy())
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260),
                                    (2, 3, 37, 50), (2, 2, 33, 47), (1, 1, 19, 6), (1, 3, 70, 129), (2, 2, 40, 5),    # widths that are not multiples of 4
                                    (2, 4, 40, 64), (1, 7, 33, 45), (2, 6, 20, 36)])                               # more than 3 channels: groups of 3
