@@ -157,17 +157,21 @@ def _smooth(n, h, w, sigma, seed, dev):
     return torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True).contiguous().to(dev)
 
 
-@pytest.mark.parametrize("c", [1, 2, 3])
-@pytest.mark.parametrize("stretch", [1.2, 1.6, 2.5, 6.0])
-def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, dev):
+@pytest.mark.parametrize("c,stretch,frame", [(1, 1.2, (160, 224)), (2, 1.2, (160, 224)), (3, 1.2, (160, 224)),
+                                             (1, 1.6, (160, 224)), (2, 1.6, (160, 224)), (3, 1.6, (160, 224)),
+                                             (1, 2.5, (160, 224)), (2, 2.5, (160, 224)), (3, 2.5, (160, 224)),
+                                             (1, 6.0, (160, 224)), (2, 6.0, (160, 224)), (3, 6.0, (160, 224)),
+                                             (3, 2.5, (150, 218)), (2, 1.6, (147, 221)), (3, 3.5, (100, 330))])   # widths that are not multiples of 4, ragged last tiles
+def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, frame, dev):
     """A flow that stretches the sampled region makes a 32 x 16 tile's box larger than the LDS budget (26 KB = 1 663 pixel slots):
     the four-tile column kernel of LARGE launches stages the rows that fit and only the pixels with a tap below them gather from
     global memory (OFL_WARP_CLIP); the two-tile, one-tile and generic kernels do not.  All must agree bit for bit, and with the
     oracle.  stretch 1.2: boxes fit; 1.6 / 2.5: oversize, most rows staged; 6.0: too few rows fit in places (whole-tile fallback).
-    The batch is large enough for the launcher to pick the column kernel (7 x 3 column groups per image: 7 056 >= 6 912)."""
+    The batch is large enough for the launcher to pick the column kernel (>= 6 912 column groups)."""
     from oflibpytorch_amd import _native
     from oracle import oracle
-    n, h, w = 336, 160, 224
+    h, w = frame
+    n = 6912 // (((w + 31) // 32) * ((h + 63) // 64)) + 1          # enough column groups (of 4 tiles) for the launcher to pick the column kernel
     ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
     # sample position = pixel - flow: x - u = cx + (x - cx) * stretch, likewise y (plus a smooth wobble, another per image)
     u = -(xs - w / 2) * (stretch - 1.0) * 0.8
