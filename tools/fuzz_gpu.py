@@ -25,8 +25,14 @@ from oracle import oracle
 
 
 def rand_flow(rng, g, n, h, w, dev):
-    kind = rng.choice(["smooth", "rough", "huge", "shear", "zero", "const"])
-    if kind == "zero":
+    kind = rng.choice(["smooth", "rough", "huge", "shear", "zero", "const", "stretch"])
+    if kind == "stretch":                                   # the sampled region is a scaled copy of the frame: boxes beyond the LDS budget
+        xs = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w) - w / 2
+        ys = torch.arange(h, dtype=torch.float32).view(1, 1, h, 1) - h / 2
+        lo = torch.randn(n, 2, max(h // 12, 2), max(w // 12, 2), generator=g) * rng.uniform(0.2, 4)
+        f = torch.nn.functional.interpolate(lo, size=(h, w), mode='bicubic', align_corners=True)
+        f = f + torch.cat([-rng.uniform(0, 3) * xs.expand(n, 1, h, w), -rng.uniform(0, 4) * ys.expand(n, 1, h, w)], 1)
+    elif kind == "zero":
         f = torch.zeros(n, 2, h, w)
     elif kind == "const":
         f = torch.zeros(n, 2, h, w) + torch.tensor([rng.uniform(-9, 9), rng.uniform(-9, 9)]).view(1, 2, 1, 1)
@@ -127,6 +133,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--big", action="store_true", help="frames up to 1100 x 2000 (fewer cases)")
+    ap.add_argument("--column", action="store_true", help="warp only, batches large enough for the launcher to pick the four-tile column kernel "
+                    "(>= 6 912 column groups): auto == generic == two tiles per block == one tile per block, bit for bit")
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     rng = np.random.default_rng(a.seed)
@@ -138,6 +146,9 @@ def main():
         h, w = (int(rng.integers(200, 1100)), int(rng.integers(300, 2000))) if a.big else (int(rng.integers(2, 180)), int(rng.integers(4, 300)))
         if a.big:
             n, c = int(rng.integers(1, 3)), int(rng.integers(1, 5))
+        if a.column:
+            h, w, c = int(rng.integers(40, 200)), int(rng.integers(64, 300)), int(rng.integers(1, 4))
+            n = 6912 // (((w + 31) // 32) * ((h + 63) // 64)) + int(rng.integers(1, 9))
         kind, flow = rand_flow(rng, g, n, h, w, dev)
         src = (torch.rand(n, c, h, w, generator=g) * 300 - 100).to(dev)
         sm = (torch.rand(n, h, w, generator=g) > rng.uniform(0, 0.4)).to(dev)
@@ -154,7 +165,7 @@ def main():
         if rng.random() < 0.3:
             kw.update(want_flags=True, want_src_flags=(c == 2))
         outs = []
-        for path in (0, 1):
+        for path in ((0, 1, 3, 4) if a.column else (0, 1)):
             _native.set_warp_path(path)
             try:
                 outs.append(_native.warp_bwd(flow, src, **kw))
@@ -163,13 +174,16 @@ def main():
         if c == 2 and kw.get("want_valid") and not kw.get("round_mode"):
             rf = _native.warp_bwd(flow, src, want_dst_flags=True, **kw)
             assert rf[4].cpu().tolist() == _native.flow_flags(rf[0], rf[1]).cpu().tolist(), "warp dst_flags %s %s" % ((n, c, h, w), kind)
-        for x, y in zip(*outs):
-            assert (x is None) == (y is None)
-            if x is not None and not torch.equal(x, y):
-                bad = (x != y) & ~(torch.isnan(x.float()) & torch.isnan(y.float()))
-                if bad.any():
-                    raise SystemExit("WARP MISMATCH shape %s kind %s kw %s: %d values" % ((n, c, h, w), kind, {k: (v if not torch.is_tensor(v) else 'T') for k, v in kw.items()}, int(bad.sum())))
+        for other in outs[1:]:
+            for x, y in zip(outs[0], other):
+                assert (x is None) == (y is None)
+                if x is not None and not torch.equal(x, y):
+                    bad = (x != y) & ~(torch.isnan(x.float()) & torch.isnan(y.float()))
+                    if bad.any():
+                        raise SystemExit("WARP MISMATCH shape %s kind %s kw %s: %d values" % ((n, c, h, w), kind, {k: (v if not torch.is_tensor(v) else 'T') for k, v in kw.items()}, int(bad.sum())))
         nw += 1
+        if a.column:
+            continue
         # ---- splat
         data = src
         skw = dict(weight_mask=sm if rng.random() < 0.6 else None, occlude=bool(rng.random() < 0.6), want_density=True, want_warped=True,
