@@ -2490,9 +2490,10 @@ void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, 
     if (fhp) fh = *fhp;
     if (vec) {
         // about 512 blocks in all: every wave ends with a look at (and maybe an atomic on) its image's shared word, and
-        // few long-running blocks stream better than many short ones (B=64 1080p: 3.1 -> 5.8 TB/s; B=16: 2.5 -> 5.4)
+        // few long-running blocks stream better than many short ones (B=64 1080p: 3.1 -> 5.8 TB/s; B=16: 2.5 -> 5.4);
+        // 256 for a batch of 8 or fewer (1080p wait, 512 / 256 blocks: B = 8 42.1 / 38.3 us, B = 4 31.8 / 28.9 us; B = 16 59.7 / 65.8 us)
         int64_t bx = (hw / 4 + 1023) / 1024;               // 4 groups of 4 pixels per thread and step
-        int64_t cap = OFL_FLAGS_BLOCKS / n;
+        int64_t cap = (n <= 8 ? OFL_FLAGS_BLOCKS / 2 : OFL_FLAGS_BLOCKS) / n;
         cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
         if (bx > cap) bx = cap;
         fh.total_blocks = (int32_t)(bx * n);
