@@ -233,6 +233,10 @@ int64_t ofl_splat_tiled_pass_images(int32_t n, int32_t h, int32_t w);   /* image
 /* images `accum_fallback` must hold, for `planes` = 1 + min(C, 3) + (with_mask_chan ? 1 : 0) planes per image: the pass, capped
  * at 1 GiB (>= 1) -- accum_fallback is fp32 [that many, planes, H, W] */
 int64_t ofl_splat_tiled_fallback_images(int32_t n, int32_t planes, int32_t h, int32_t w);
+/* the geometry this build of the gather splat works with (what the stats words of a call count in, and what a caller that wants
+ * to provoke / predict the fallbacks has to know): destination tile width and height in pixels, and the number of 16 x 2 source
+ * subtiles one destination tile can list before its IMAGE takes the two-pass path.  Any pointer may be NULL; returns OFL_OK. */
+int ofl_splat_tile_geometry(int32_t* tile_w, int32_t* tile_h, int32_t* list_capacity);
 int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
                         const float* xs, const float* ys, int64_t xy_bs,
                         const float* data, int64_t data_bs, float data_sign,

@@ -18,7 +18,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 28              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 29              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -26,7 +26,7 @@ _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
             "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
-            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32", "ofl_resize_bilinear_f32")
+            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32", "ofl_resize_bilinear_f32", "ofl_splat_tile_geometry")
 _lib = None
 
 
@@ -77,6 +77,7 @@ def load_library(path: str = None):
     lib.ofl_splat_tiled_workspace_ints.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_pass_images.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_fallback_images.argtypes = [i32, i32, i32, i32]
+    lib.ofl_splat_tile_geometry.argtypes = [p, p, p]
     lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                         p, p, i64, p, i32, i32, i32, i32, i32, p]
     lib.ofl_warp_bwd_grad_f32.argtypes = [p, i64, f32, p, i64, p, f32, p, i64, p, i32, i32, i32, i32, p]
@@ -561,6 +562,13 @@ def _fallback_accum(lib, n, c, mch, h, w, dev):
     pass, capped at 1 GiB by the library -- flagged images beyond that are served in rounds."""
     planes = 1 + min(c, 3) + mch
     return torch.empty((int(lib.ofl_splat_tiled_fallback_images(n, planes, h, w)), planes, h, w), dtype=torch.float32, device=dev)
+
+
+def splat_tile_geometry() -> tuple:
+    """(tile width, tile height, list capacity in 16 x 2 source subtiles) of the gather splat of the loaded library."""
+    tw, th, cap = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _check(load_library().ofl_splat_tile_geometry(ctypes.byref(tw), ctypes.byref(th), ctypes.byref(cap)), "ofl_splat_tile_geometry")
+    return tw.value, th.value, cap.value
 
 
 def set_splat_fallback_slots(k: int):

@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(256) void splat_fallback_kernel(const SplatParams p
 //  the device, per image.
 // ------------------------------------------------------------------------------------------------
 #ifndef OFL_SP_TW
-#define OFL_SP_TW 32    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues)
+#define OFL_SP_TW 64    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues)
 #endif
 #ifndef OFL_SP_TH
 #define OFL_SP_TH 16
@@ -2584,7 +2584,7 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 28; }   // 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 29; }   // 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 4) { g_warp_path = value; return OFL_OK; }
@@ -2887,6 +2887,13 @@ static int64_t splat_fallback_slots(int32_t n, int32_t planes, int32_t h, int32_
 }
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_fallback_images(int32_t n, int32_t planes, int32_t h, int32_t w) {
     return splat_fallback_slots(n, planes, h, w);
+}
+
+__attribute__((visibility("default"))) int ofl_splat_tile_geometry(int32_t* tile_w, int32_t* tile_h, int32_t* list_capacity) {
+    if (tile_w) *tile_w = kSpTW;
+    if (tile_h) *tile_h = kSpTH;
+    if (list_capacity) *list_capacity = kBinCap;
+    return OFL_OK;
 }
 
 __attribute__((visibility("default"))) int64_t ofl_splat_tiled_workspace_ints(int32_t n, int32_t h, int32_t w) {

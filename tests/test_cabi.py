@@ -95,6 +95,10 @@ def test_round3_entry_points_reject_bad_arguments_without_a_gpu():
     # the fallback accumulator is bounded: the pass, capped at 1 GiB
     assert lib.ofl_splat_tiled_fallback_images(64, 5, 1080, 1920) == 25 and lib.ofl_splat_tiled_fallback_images(4, 5, 1080, 1920) == 4
     assert lib.ofl_splat_tiled_fallback_images(16, 4, 2160, 3840) == 8 and lib.ofl_splat_tiled_fallback_images(3, 5, 16384, 16384) == 1
+    tw, th, cap = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert lib.ofl_splat_tile_geometry(ctypes.byref(tw), ctypes.byref(th), ctypes.byref(cap)) == 0
+    assert (tw.value, th.value) in ((32, 16), (64, 16)) and cap.value == 256 * (tw.value // 32)
+    assert lib.ofl_splat_tile_geometry(None, None, None) == 0
     assert lib.ofl_set_option(5, -1) == -3 and lib.ofl_set_option(5, 0) == 0
 
 

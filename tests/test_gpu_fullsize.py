@@ -75,9 +75,10 @@ def test_apply_s_full_frame(frames, dev):
     got = warped.cpu().numpy()
     assert np.array_equal(valid.cpu().numpy(), expv)
     np.testing.assert_allclose(got, exp, rtol=2e-5, atol=2e-5 * 255)
-    tiles = (2 * ((H + 15) // 16) * ((W + 31) // 32))
+    tw, th, _ = _native.splat_tile_geometry()
+    tiles = (2 * ((H + th - 1) // th) * ((W + tw - 1) // tw))
     differing = np.argwhere((got != exp).any(axis=1))                    # (n, y, x) of pixels that are not bit-identical
-    touched = {(int(a), int(y) // 16, int(x) // 32) for a, y, x in differing}
+    touched = {(int(a), int(y) // th, int(x) // tw) for a, y, x in differing}
     assert len(touched) <= st[1], "only tiles that left the exact path may differ (%d differ, %d fell back of %d)" % (len(touched), st[1], tiles)
 
 
