@@ -199,7 +199,7 @@ int ofl_splat_finalize_f32(const float* accum,
 
 /*
  * Forward splat, single fused call (the fast path of the two passes above, same arguments) -- an in-order GATHER:
- * a bin kernel appends the id of every 16 x 2 source subtile to the list of each 32 x 16 destination tile its end points
+ * a bin kernel appends the id of every 16 x 2 source subtile to the list of each destination tile (64 x 16: ofl_splat_tile_geometry) its end points
  * touch; a gather kernel (one block per destination tile) re-reads the listed source pixels, keeps those that land in
  * the tile as LDS records per unit cell, puts every cell in raster order of its source pixels and sums each destination
  * pixel's contributions in registers, per corner class in that order and ((c0 + c1) + c2) + c3 across the classes -- the

@@ -1232,11 +1232,11 @@ __global__ __launch_bounds__(256) void splat_fallback_kernel(const SplatParams p
 //                 the box overlaps (fixed capacity; ranks from LDS atomics per 64 x 16 source region, one device-scope
 //                 atomic per (region, destination tile)).  Reads the flow and the weight mask only (9 B/px), writes
 //                 ~0.2 B/px.  A tile lists 28 - 32 subtiles on the bench flows.
-//  gather kernel: one block per 32 x 16 DESTINATION tile.
+//  gather kernel: one block per DESTINATION tile (64 x 16 since the end of round 4: OFL_SP_TW; 32 x 16 before).
 //     A  walks its list, 64 subtiles per step in two half steps of 32 (the second skipped when empty): flow, mask and data
 //        of the listed source pixels straight from the operand tensors (16-byte row-coalesced loads, served by L2 for the
 //        ~2 tiles that share a subtile), end points in the reference's order (utils.py:1056-1057); the pixels whose unit
-//        cell lies in the tile's 33 x 17 cells become RECORDS IN LDS ONLY (four corner weights, data, raster key +
+//        cell lies in the tile's (TW + 1) x 17 cells become RECORDS IN LDS ONLY (four corner weights, data, raster key +
 //        mask-channel bit): ballot + popcount ranks, one LDS atomic per wave and half step; every record joins its CELL
 //        (four 16-bit slots, later ones on a chain);
 //     S  cells with one or two records need no order (a + b = b + a); the others are collected and handled one per lane:
@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(256) void splat_fallback_kernel(const SplatParams p
 //  the device, per image.
 // ------------------------------------------------------------------------------------------------
 #ifndef OFL_SP_TW
-#define OFL_SP_TW 64    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues)
+#define OFL_SP_TW 64    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues; round 3: 32 by 1 %, round 4 after the long cells left the critical path: 64 by 4 % at sigma 8, 30 % at B = 1)
 #endif
 #ifndef OFL_SP_TH
 #define OFL_SP_TH 16
