@@ -18,6 +18,9 @@
 
 #pragma clang fp contract(off)
 
+// the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
+int ofl_wide_launch_column(const void* params, int nc, int valid, void* stream);
+
 namespace {
 
 constexpr float kValidThr = 0.99999f;  // flow_class.py:922
@@ -251,12 +254,24 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 #ifndef OFL_WARP_CLIP
 #define OFL_WARP_CLIP 8      // 0: an oversize box gathers the whole tile from global memory; n: stage its first rows if at least n fit
 #endif
-constexpr int kLdsNT = 128, kLdsTWQ = 8, kLdsTH = kLdsNT / kLdsTWQ, kLdsIters = 3;
+// Tile shape of the staged kernels: 128 threads x 4 pixels = 32 x 16 output pixels, 26 KB of LDS (6 blocks = 12 waves per CU).
+// ofl_warp_wide.hip compiles this file a second time with 256 threads = 64 x 16 tiles and 52 KB (3 blocks = the same 12 waves)
+// for the four-tile column kernel of large plain warps only: -1.9 % there, +5 % on the pair kernel of mode 3
+// (profiles/r4_warp_16waves.txt), so the shape is chosen per kernel -- by translation unit, not by templating every helper.
+#ifndef OFL_LDS_NT
+#define OFL_LDS_NT 128
+#define OFL_LDS_TWQ 8
+#define OFL_LDS_BYTES 26624
+#endif
+constexpr int kLdsNT = OFL_LDS_NT, kLdsTWQ = OFL_LDS_TWQ, kLdsTH = kLdsNT / kLdsTWQ, kLdsIters = 3;
+#ifndef OFL_WARP_WIDE
+#define OFL_WARP_WIDE 1
+#endif
 #ifndef OFL_WARP_T
 #define OFL_WARP_T 4
 #endif
 constexpr int kLdsT = OFL_WARP_T;    // tiles per block of the column kernel (warp_bwd_lds_column_kernel); 2: the pair kernel only
-constexpr int kLdsBytes = 26624;   // 6 blocks (12 waves) per CU
+constexpr int kLdsBytes = OFL_LDS_BYTES;   // 6 blocks (12 waves) per CU
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -2408,6 +2423,28 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
     return (unsigned)(p.per_xcd * kXcds);
 }
 
+#ifdef OFL_WIDE_TU
+}  // namespace
+
+// This translation unit (ofl_warp_wide.hip) provides ONE thing: the column kernel of a large plain warp on 64 x 16 tiles.
+int ofl_wide_launch_column(const void* params, int nc, int valid, void* stream) {
+    WarpParams q = *static_cast<const WarpParams*>(params);
+    q.lds_bytes = kLdsBytes;
+    const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int TT = kLdsT > 2 ? kLdsT : 3;
+#define OFL_WIDE_CASE(NC)                                                                                                                   \
+    if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);           \
+    else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+    switch (nc) {
+        case 1: OFL_WIDE_CASE(1) break;
+        case 2: OFL_WIDE_CASE(2) break;
+        default: OFL_WIDE_CASE(3) break;
+    }
+#undef OFL_WIDE_CASE
+    return (int)hipGetLastError();
+}
+#else
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
@@ -2455,6 +2492,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     WarpParams q = p;
     const unsigned g = (kLdsT > 2 && !add && !p.flow_flags) ? warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) : 0u;
     if (g >= kColumnMinGroups && g_warp_path != 3) {
+        if (OFL_WARP_WIDE) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, (void*)st);    // 64 x 16 tiles: -1.9 % (see kLdsNT)
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
@@ -3176,3 +3214,4 @@ __attribute__((visibility("default"))) int ofl_host_words_alloc(int64_t ints, vo
 __attribute__((visibility("default"))) int ofl_host_words_free(void* ptr) { return ptr ? (int)hipHostFree(ptr) : OFL_OK; }
 
 }  // extern "C"
+#endif  // OFL_WIDE_TU
