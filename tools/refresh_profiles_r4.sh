@@ -30,7 +30,7 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_INSTS_VALU SQ_INSTS_SAL
 done
 python3 tools/pmc_summary.py $O splat_ > $O/splat_pmc_summary.txt 2>&1
 # roughness sweep of the warp, the validation wait, the step's timeline at B = 8
-for s in 0.5 2 4 8 12 16; do python tools/ab_warp.py --sigma $s --reps 1 --only 1 2>/dev/null | grep "shear on" | sed "s/^/sigma $s  /"; done > $O/sigma_sweep.txt
+for s in 0.5 2 4 8 12 16; do python tools/ab_warp.py --sigma $s --reps 2 --only 1 2>/dev/null | grep "shear on" | tail -1 | sed "s/^/sigma $s  /"; done > $O/sigma_sweep.txt
 python tools/ab_flags.py > $O/flags.txt 2>/dev/null
 python tools/step_timeline.py > $O/timeline.txt 2>/dev/null; python tools/step_timeline.py --batch 64 >> $O/timeline.txt 2>/dev/null
 ls $O
