@@ -22,7 +22,8 @@ for sigma in [float(v) for v in os.environ.get("STAMP_SIGMAS", "8,2").split(",")
     fn = lambda: A.apply(img, target_mask=tm, return_valid_area=True)
     fn(); torch.cuda.synchronize()
     import numpy as np
-    blocks = ((n * 60 * 68 + 7) // 8) * 8
+    tw, th, _ = _native.splat_tile_geometry()
+    blocks = ((n * ((w + tw - 1) // tw) * ((h + th - 1) // th) + 7) // 8) * 8
     buf = np.zeros(blocks * 16, dtype=np.uint32)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()
