@@ -147,7 +147,7 @@ def main():
         if a.big:
             n, c = int(rng.integers(1, 3)), int(rng.integers(1, 5))
         if a.column:
-            h, w, c = int(rng.integers(40, 200)), int(rng.integers(64, 300)), int(rng.integers(1, 4))
+            h, w, c = int(rng.integers(2, 200)), int(rng.integers(4, 300)), int(rng.integers(1, 4))
             n = 6912 // (((w + 31) // 32) * ((h + 63) // 64)) + int(rng.integers(1, 9))
         kind, flow = rand_flow(rng, g, n, h, w, dev)
         src = (torch.rand(n, c, h, w, generator=g) * 300 - 100).to(dev)
