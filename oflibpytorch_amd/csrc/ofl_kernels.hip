@@ -1569,6 +1569,9 @@ __device__ __forceinline__ void sp_use_presum(const f4* rec4, uint32_t ia, uint3
 #ifndef OFL_SP_LANEMAX
 #define OFL_SP_LANEMAX 12
 #endif
+#ifndef OFL_SP_NET8
+#define OFL_SP_NET8 1     // cells of five to N records are ordered by a sorting network in registers (1: N by channel count; 6 / 8: forced; 0: insertion sort up to OFL_SP_LANEMAX)
+#endif
 constexpr int kSpLaneMax = OFL_SP_LANEMAX;   // longest cell ONE lane puts in raster order (insertion on its chain); longer ones (up to kSpLong) are a wave's
 
 // A cell with kSpLaneMax < cn <= 64 records, ordered and summed by the 64 lanes of one wave (every lane of the wave calls this
@@ -1858,7 +1861,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     __shared__ uint16_t lq[kLongQ];
     __shared__ int lqn;
     // ... and, of those, the cells with more than kSpLaneMax records: a WAVE orders and sums each of them (below)
-    constexpr int kBigQ = kSpQ / (kSpLaneMax + 1) + 1;
+    // cells of five to kNet records: a sorting network in one lane's registers; longer ones: a wave (3 data channels: six, the
+    // eight-input network spills there and costs smooth flows 2 %; 2 channels: eight -- profiles/r4_splat_variants.txt section 8)
+    constexpr int kNet = OFL_SP_NET8 == 0 ? 0 : (OFL_SP_NET8 == 1 ? (NC == 3 ? 6 : 8) : OFL_SP_NET8), kLaneMax = kNet ? kNet : kSpLaneMax;
+    constexpr int kBigQ = kSpQ / (kLaneMax + 1) + 1;              // (every queued cell holds more than kLaneMax of the kSpQ records)
     __shared__ uint16_t bq[kBigQ];
     __shared__ int bqn;
     f4* rec4 = reinterpret_cast<f4*>(raw);                            // rec4[2 * i] weights, rec4[2 * i + 1] data | key
@@ -2027,7 +2033,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                 const int c = lq[qi];
                 const uint32_t cn = ccnt[c];
                 if (cn > (uint32_t)kSpLong) { toolong = true; continue; }   // the limit is on the LENGTH: the same in every run
-                if (cn > (uint32_t)kSpLaneMax) { bq[atomicAdd(&bqn, 1)] = (uint16_t)c; continue; }   // a wave's job (below)
+                if (cn > (uint32_t)kLaneMax) { bq[atomicAdd(&bqn, 1)] = (uint16_t)c; continue; }   // a wave's job (below)
                 const uint2 sl4 = slots[c];
                 uint32_t e[4] = {sl4.x & 0xffffu, sl4.x >> 16, sl4.y & 0xffffu, sl4.y >> 16};
                 // the class sums, in raster order: product rounded, then added (as sp_use does for the short cells)
@@ -2059,6 +2065,49 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
                     add(w0, d0); add(w1, d1); add(w2, d2);
                     if (four) add(w3, d3);
                     ia = e[0]; ib = e[1]; ic = e[2];
+                } else if (kNet != 0 && cn <= (uint32_t)kNet) {
+                    // five to eight records: the chain is walked ONCE (its links), the (key, index) pairs are ordered by a sorting
+                    // network in registers (19 comparators for eight, 12 for six) and the records fetched by index -- ~6 dependent
+                    // LDS round trips instead of the ~2 n^2 / 4 of the insertion sort below (n = 8: 32)
+                    constexpr int M = kNet ? kNet : 8;
+                    static_assert(M == 8 || M == 6, "sorting network size");
+                    uint32_t ix[M], ky[M];
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) ix[j4] = e[j4];
+                    uint32_t cur = ohead[c];
+#pragma unroll
+                    for (int j4 = 4; j4 < M; ++j4) {
+                        const bool on = (uint32_t)j4 < cn;
+                        ix[j4] = on ? cur : kEnd;
+                        if (on) cur = link[cur];
+                    }
+#pragma unroll
+                    for (int j4 = 0; j4 < M; ++j4) ky[j4] = ix[j4] != kEnd ? rwords[8 * ix[j4] + 7] : 0xffffffffu;
+#define OFL_CSWAP8(a_, b_) { const bool sw = ky[a_] > ky[b_]; const uint32_t tk = sw ? ky[b_] : ky[a_], te = sw ? ix[b_] : ix[a_]; \
+                             ky[b_] = sw ? ky[a_] : ky[b_]; ix[b_] = sw ? ix[a_] : ix[b_]; ky[a_] = tk; ix[a_] = te; }
+                    if (M == 8) {
+                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5) OFL_CSWAP8(M - 2, M - 1)
+                        OFL_CSWAP8(0, 2) OFL_CSWAP8(1, 3) OFL_CSWAP8(4, M - 2) OFL_CSWAP8(5, M - 1)
+                        OFL_CSWAP8(1, 2) OFL_CSWAP8(5, M - 2) OFL_CSWAP8(0, 4) OFL_CSWAP8(3, M - 1)
+                        OFL_CSWAP8(1, 5) OFL_CSWAP8(2, M - 2)
+                        OFL_CSWAP8(1, 4) OFL_CSWAP8(3, M - 2)
+                        OFL_CSWAP8(2, 4) OFL_CSWAP8(3, 5)
+                        OFL_CSWAP8(3, 4)
+                    } else {
+                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
+                        OFL_CSWAP8(0, 2) OFL_CSWAP8(3, 5) OFL_CSWAP8(1, 4)
+                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
+                        OFL_CSWAP8(1, 2) OFL_CSWAP8(3, 4)
+                        OFL_CSWAP8(2, 3)
+                    }
+#undef OFL_CSWAP8
+                    // (unused slots carry the largest key: they sort last; five records at least are real)
+#pragma unroll
+                    for (int r = 0; r < M; ++r) {
+                        if (r < 5 || (uint32_t)r < cn) add(rec4[2 * ix[r]], rec4[2 * ix[r] + 1]);
+                        if (r == 3) asm volatile("" ::: "memory");     // (two batches of loads)
+                    }
+                    ia = ix[0]; ib = ix[1]; ic = ix[2];
                 } else {
                     uint32_t cur = ohead[c];
 #pragma unroll

@@ -416,6 +416,36 @@ def test_compressing_flows_stay_exact(patch, dev):
     assert np.array_equal(out[3].cpu().numpy(), rwarped)
 
 
+@pytest.mark.parametrize("c,squeeze,cols", [(3, 7.2, 40), (2, 9.2, 31), (3, 5.3, 52), (2, 7.6, 38)])
+def test_many_medium_cells_in_one_tile_stay_exact(c, squeeze, cols, dev):
+    """A strip of the frame squeezed horizontally: `cols` destination columns in which EVERY cell holds `squeeze` records, and
+    nothing else contributes (the weight mask is off outside the strip) -- as many cells per band as the record store allows that
+    are too long for one lane's sorting network (more than six records with three data channels, more than eight with two) and go
+    to the waves' queue, or just short enough for the network.  The queue holds one entry per such cell (fuzz seed 31 found it
+    sized for cells beyond 12 records when the threshold had moved to 6): bit-identical to the oracle, no tile leaves the exact path."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    _native.collect_splat_stats = True
+    n, h, w = 2, 64, 512
+    xs = torch.arange(w, dtype=torch.float32)
+    x0, d0, wide = 40.0, 256.0, cols * squeeze                        # the strip's destination columns start on a tile boundary
+    inside = (xs >= x0) & (xs < x0 + wide)
+    dest = torch.where(inside, d0 + (xs - x0) / squeeze, xs)
+    flow = torch.zeros(n, 2, h, w)
+    flow[:, 0] = (dest - xs).view(1, 1, w)
+    flow = (flow + _smooth(n, h, w, 0.02, 3, torch.device('cpu'))).contiguous().to(dev)
+    g = torch.Generator().manual_seed(11)
+    data = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    wm = inside.view(1, 1, w).expand(n, h, w).contiguous().to(dev)
+    out = _native.splat_fwd(flow, data, weight_mask=wm, want_density=True, want_warped=True, occlude=False)
+    assert _native._last_splat_stats.cpu().tolist()[:2] == [0, 0]
+    ref, rwarped, rden = oracle.apply_s_flow(flow.cpu().numpy(), data.cpu().numpy(), wm.cpu().numpy(), False, return_density=True)
+    assert (rden > squeeze - 1.5).sum() > 0.8 * n * h * cols   # the strip: long cells in every row
+    assert np.array_equal(out[0].cpu().numpy(), ref[:, :c])
+    assert np.array_equal(out[2].cpu().numpy(), rden)
+    assert np.array_equal(out[3].cpu().numpy(), rwarped)
+
+
 @pytest.mark.parametrize("shape", [(3, 70, 132), (2, 37, 50), (1, 9, 3), (2, 64, 96)])
 def test_flows_stored_in_fp16_are_converted_and_validated_in_one_pass(shape, dev):
     """ofl_flow_from_f16 (Flow(fp16 tensor) on a HIP device): the fp32 vectors are exactly `.float()`, the flag words those
