@@ -248,6 +248,9 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_WARP_UNCOND_STORE
+#define OFL_WARP_UNCOND_STORE 1
+#endif
 #ifndef OFL_WARP_CLIP_COLUMN
 #define OFL_WARP_CLIP_COLUMN 1
 #endif
@@ -642,7 +645,12 @@ __device__ __forceinline__ void lds_store(const WP& p, int tx, int ty, int n, ui
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const int w = p.w, h = p.h;
     const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
-    const bool inb = (x4 < w) && (y < h);
+    // OFL_WARP_UNCOND_STORE: lanes past the frame's right / bottom edge have computed the CLAMPED pixel group (same flow, same
+    // coordinates, same taps as its owner) and store it again -- identical duplicate stores, as for the group that straddles a
+    // row end.  What it buys is not the branch: with the stores in straight-line code the compiler can COUNT them, so the next
+    // tile's wait for its flow / staged box becomes s_waitcnt vmcnt(4) instead of vmcnt(0), which also waited for these stores'
+    // acknowledgements (the vmcnt queue is in order) -- once per tile, with nothing else of the block in flight.
+    const bool inb = OFL_WARP_UNCOND_STORE || ((x4 < w) && (y < h));
     const uint32_t pix = (uint32_t)(min(y, h - 1) * w + min(x4, w - 4));
     if (inb) {
         uint32_t vo = 0x01010101u;
