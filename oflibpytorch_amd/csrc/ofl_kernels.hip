@@ -19,7 +19,7 @@
 #pragma clang fp contract(off)
 
 // the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
-int ofl_wide_launch_column(const void* params, int nc, int valid, void* stream);
+int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void* stream);
 
 namespace {
 
@@ -132,7 +132,7 @@ typedef const WarpParams __attribute__((address_space(4))) WarpParamsK;
 #define OFL_WARP_KARG 1
 #endif
 #ifndef OFL_WARP_COL_ADD
-#define OFL_WARP_COL_ADD 0
+#define OFL_WARP_COL_ADD 1
 #endif
 
 constexpr int kTileW = 64;   // one wavefront spans 64 consecutive x: 256-byte rows per instruction
@@ -248,6 +248,12 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_WARP_MERGE_BARRIER
+#define OFL_WARP_MERGE_BARRIER 1
+#endif
+#ifndef OFL_WARP_UNCOND_ROUNDS
+#define OFL_WARP_UNCOND_ROUNDS 1
+#endif
 #ifndef OFL_WARP_UNCOND_STORE
 #define OFL_WARP_UNCOND_STORE 1
 #endif
@@ -368,9 +374,13 @@ __device__ __forceinline__ int lds_slope_row(const WP& p, const float* __restric
 template <int NC> struct LdsStage { int slot[kLdsIters]; f4 q[kLdsIters][NC]; uint32_t mq[kLdsIters]; };
 
 // steps 1-2 for one tile
-template <bool BOX = true, bool CLIP = false, typename WP>
-__device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
-                                               LdsCoords& T, LdsBox& B, int (*red)[4]) {
+// Two halves: _a = coordinates, per-wave box, the wave's (lo, hi) words into `red`; _b = the other waves' words (after a block
+// barrier -- the caller's: in the pipelines it is the barrier that publishes the previous tile's staged box anyway) and the
+// staging geometry.  lds_coords_box is the two with a barrier of its own between them.
+struct LdsBoxWords { int lo, hi; };
+template <bool BOX = true, typename WP>
+__device__ __forceinline__ LdsBoxWords lds_coords_box_a(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
+                                                        LdsCoords& T, int (*red)[4]) {
     constexpr int NW = kLdsNT / 64;
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const int w = p.w, h = p.h;
@@ -429,16 +439,26 @@ __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, cons
             miny = min(miny, yi - max(s0, s1)); maxy = max(maxy, yi + 1 - min(s0, s1));
         }
     }
-    if (!BOX) return;
+    if (!BOX) return LdsBoxWords{0, 0};
     // block-wide box: columns and (sheared) rows fit 16 bits (checked on the host), so (x, y) pairs reduce together
     int lo = (int)(((uint32_t)minx & 0xffffu) | ((uint32_t)miny << 16)), hi = (int)(((uint32_t)maxx & 0xffffu) | ((uint32_t)maxy << 16));
     lo = wave_pk_min_dpp(lo); hi = wave_pk_max_dpp(hi);
     if (NW > 1) {
         if ((tid & 63) == 0) { red[tid >> 6][0] = lo; red[tid >> 6][1] = hi; }
-        lds_barrier();
+    }
+    return LdsBoxWords{lo, hi};
+}
+
+template <bool CLIP = false, typename WP>
+__device__ __forceinline__ void lds_coords_box_b(const WP& p, int sq, LdsBoxWords wds, LdsBox& B, int (*red)[4]) {
+    constexpr int NW = kLdsNT / 64;
+    const int w = p.w, h = p.h;
+    int lo = wds.lo, hi = wds.hi;
+    if (NW > 1) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) { lo = pk_min16(lo, red[i][0]); hi = pk_max16(hi, red[i][1]); }
     }
+    int minx, miny, maxx, maxy;
     minx = (int)(short)(lo & 0xffff); miny = lo >> 16; maxx = (int)(short)(hi & 0xffff); maxy = hi >> 16;
     // touched columns [minx, maxx + 1] clipped to the image; sheared rows [miny, maxy] as they are (a staged row that falls
     // outside the image is skipped and never read back)   (wave-uniform)
@@ -465,6 +485,15 @@ __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, cons
     B.interior = B.fits && !B.clipped && xin && (miny + min(sa, sb_) >= 0) && (maxy + max(sa, sb_) <= h - 1);
 }
 
+template <bool BOX = true, bool CLIP = false, typename WP>
+__device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
+                                               LdsCoords& T, LdsBox& B, int (*red)[4]) {
+    const LdsBoxWords wds = lds_coords_box_a<BOX>(p, tx, ty, u4, v4, sq, T, red);
+    if (!BOX) return;
+    if (kLdsNT > 64) lds_barrier();
+    lds_coords_box_b<CLIP>(p, sq, wds, B, red);
+}
+
 // step 3a: issue the staging loads of a tile into registers (nothing waits here)
 template <int NC, bool VALID, bool SUB = false, typename TS = float, typename WP = WarpParams>
 __device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
@@ -475,12 +504,15 @@ __device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb
 #pragma unroll
     for (int it = 0; it < kLdsIters; ++it) {
         S.slot[it] = -1;
-        if (it < rounds) {
+        // the first OFL_WARP_UNCOND_ROUNDS rounds are issued whatever the box (lanes past its last chunk re-read chunk 0 and
+        // write nothing to the LDS): loads in straight-line code are loads the compiler can COUNT, so the wait for the next
+        // tile's flow (older than these loads) no longer waits for them too -- its coordinates are computed while they fly
+        if (it < OFL_WARP_UNCOND_ROUNDS || it < rounds) {
             const uint32_t i = (uint32_t)tid + it * kLdsNT;
             // 24-bit multiplies (full rate): i < 2^9, inv <= 2^20, rows and columns < 2^13, h * w < 2^24
             const uint32_t r = __umul24(i, inv) >> 20, c4 = i - __umul24(r, (uint32_t)B.cw);
             const int y = B.miny + (int)r + lds_shear(B.cbase + (int)c4, B.sq);
-            const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h);
+            const bool on = (i < (uint32_t)B.nch) && ((uint32_t)y < (uint32_t)p.h) && (OFL_WARP_UNCOND_ROUNDS == 0 || it < rounds);
             const uint32_t g = on ? (uint32_t)(__mul24(y, p.w) + B.bx0) + c4 * 4u : 0u;
             S.slot[it] = on ? 1 + (int)(__umul24(r, (uint32_t)B.Pp) + c4) : -1;
             // the last chunk of a row of an image whose width is not a multiple of 4 would read past the row end (and past
@@ -493,7 +525,9 @@ __device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb
                 S.q[it][c] = ld4(sb + c * hw + ge);
                 if (SUB) S.q[it][c] = S.q[it][c] - ld4(sbb + c * hw + ge);     // (mode 1 't': the warped field is flow - self)
             }
-            S.mq[it] = (VALID && sm) ? ld32(sm + ge) : 0x01010101u;
+            // (OFL_WARP_UNCOND_ROUNDS, no target mask: the load reads the first plane's bytes and lds_write discards them -- still one countable load)
+            if (OFL_WARP_UNCOND_ROUNDS && VALID) S.mq[it] = ld32(sm ? sm + ge : reinterpret_cast<const uint8_t*>(sb) + ge);
+            else S.mq[it] = (VALID && sm) ? ld32(sm + ge) : 0x01010101u;
             if (wrem != 0) {
                 if (edge) {
 #pragma unroll
@@ -507,17 +541,18 @@ __device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb
 
 // step 3b: registers -> interleaved LDS slots
 template <int NC, bool VALID>
-__device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsStage<NC>& S) {
+__device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsStage<NC>& S, bool has_sm = true) {
     if (threadIdx.x == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < kLdsIters; ++it) {
         if (S.slot[it] >= 0) {
+            const uint32_t mq = (OFL_WARP_UNCOND_ROUNDS && VALID && !has_sm) ? 0x01010101u : S.mq[it];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f4 sl = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < NC; ++c) sl[c] = S.q[it][c][k];
-                if (VALID) sl[3] = fminf((float)((S.mq[it] >> (8 * k)) & 0xffu), 1.0f);   // non-zero byte -> 1 (v_cvt_f32_ubyteK + v_min)
+                if (VALID) sl[3] = fminf((float)((mq >> (8 * k)) & 0xffu), 1.0f);   // non-zero byte -> 1 (v_cvt_f32_ubyteK + v_min)
                 lds[S.slot[it] + k * B.cw] = sl;
             }
         }
@@ -726,9 +761,18 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     const int sq = p.shear ? lds_slope(p, fu, hw, tx, ty2) : 0;
     lds_coords_box(p, tx, tyA, uA, vA, sq, TA, BA, red[0]);
     lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, BA, S, sbb);   // staging loads of A fly ...
-    lds_coords_box(p, tx, tyB, uB, vB, sq, TB, BB, red[1]);     // ... while B's coordinates are computed
-    lds_write<NC, VALID>(lds, BA, S);
+    // ... while B's coordinates are computed; the block-wide half of B's box waits for the barrier that publishes A's staged box
+    // (OFL_WARP_MERGE_BARRIER: one barrier per tile fewer)
+#if OFL_WARP_MERGE_BARRIER
+    const LdsBoxWords wB = lds_coords_box_a(p, tx, tyB, uB, vB, sq, TB, red[1]);
+#else
+    lds_coords_box(p, tx, tyB, uB, vB, sq, TB, BB, red[1]);
+#endif
+    lds_write<NC, VALID>(lds, BA, S, sm != nullptr);
     lds_barrier();
+#if OFL_WARP_MERGE_BARRIER
+    lds_coords_box_b(p, sq, wB, BB, red[1]);
+#endif
     // the vmcnt queue is in order: the addend (an L2 hit when it is the flow itself) is fetched BEFORE B's staging loads /
     // A's stores, so that waiting for it never waits for them
     // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
@@ -747,7 +791,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
         return;
     }
     lds_barrier();
-    lds_write<NC, VALID>(lds, BB, S);
+    lds_write<NC, VALID>(lds, BB, S, sm != nullptr);
     lds_barrier();
     lds_gather<NC, VALID, SUB, TS>(p, hw, sb, sm, TB, BB, smem, outv, sbb);
     if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyB, n, hw, aB);
@@ -797,12 +841,15 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         const uint32_t pix = (uint32_t)(min((tyg * T + k) * kLdsTH + ly, h - 1) * w + xq);
         uu[k] = ld4nt(fu + pix); vv[k] = ld4nt(fu + hw + pix);
         fmk[k] = 0x01010101u;
-        if ((VALID || p.flow_flags) && fm) fmk[k] = ld32(fm + pix);
+        // (OFL_WARP_UNCOND_ROUNDS: countable, as the staging loads: no flow mask -> a read of the flow's bytes, discarded where the word is used)
+        if (OFL_WARP_UNCOND_ROUNDS && VALID) fmk[k] = ld32(fm ? fm + pix : reinterpret_cast<const uint8_t*>(fu) + pix);
+        else if ((VALID || p.flow_flags) && fm) fmk[k] = ld32(fm + pix);
     };
+    auto fmw = [&](int k) -> uint32_t { return (OFL_WARP_UNCOND_ROUNDS && VALID && !fm) ? 0x01010101u : fmk[k]; };
     auto note_flags = [&](int k) {       // finiteness / zero tests of the flow operand as a by-product (wave-uniform branch)
         if (p.flow_flags && (x4 < w) && ((tyg * T + k) * kLdsTH + ly < h)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) fflags |= flag_bits(uu[k][q], vv[k][q], ((fmk[k] >> (8 * q)) & 0xffu) != 0u);
+            for (int q = 0; q < 4; ++q) fflags |= flag_bits(uu[k][q], vv[k][q], ((fmw(k) >> (8 * q)) & 0xffu) != 0u);
         }
     };
     load_flow(0);
@@ -830,12 +877,22 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         OFL_WARP_PHASE();
         const int tyk = tyg * T + k;
         const bool more = (k + 1 < T) && ((tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
+        LdsBoxWords wn = {0, 0};
         if (k + 1 < T) {
-            if (more) { note_flags(k + 1); lds_coords_box<true, kClip>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }   // ... while the next tile's coordinates are computed
+            // ... while the next tile's coordinates are computed (OFL_WARP_MERGE_BARRIER: the block-wide half of its box behind the
+            // barrier that publishes this tile's staged box -- one barrier per tile fewer)
+#if OFL_WARP_MERGE_BARRIER
+            if (more) { note_flags(k + 1); wn = lds_coords_box_a(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], red[(k + 1) & 1]); }
+#else
+            if (more) { note_flags(k + 1); lds_coords_box<true, kClip>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }
+#endif
         }
         if (k + 2 < T) load_flow(k + 2);
-        lds_write<NC, VALID>(lds, Bx[k], S);
+        lds_write<NC, VALID>(lds, Bx[k], S, sm != nullptr);
         lds_barrier();
+#if OFL_WARP_MERGE_BARRIER
+        if (k + 1 < T) { if (more) lds_coords_box_b<kClip>(p, sq[k + 1], wn, Bx[k + 1], red[(k + 1) & 1]); }
+#endif
         f4 outv[4], ad[NC];
         if (EARLY) { if (reuse) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; } else lds_load_addend<NC>(p, tx, tyk, n, hw, ad); }
         if (GRAD) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);              // the upstream gradient of the tile, ahead of the younger loads
@@ -851,7 +908,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
             continue;
         }
         if (ADD && !EARLY) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
-        lds_store<NC, VALID, ADD, DF, TD>(p, tx, tyk, n, hw, fmk[k], outv, ad, &dflags);
+        lds_store<NC, VALID, ADD, DF, TD>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
         if (!more) break;
         lds_barrier();
     }
@@ -2484,12 +2541,19 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 }  // namespace
 
 // This translation unit (ofl_warp_wide.hip) provides ONE thing: the column kernel of a large plain warp on 64 x 16 tiles.
-int ofl_wide_launch_column(const void* params, int nc, int valid, void* stream) {
+int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
     const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
     hipStream_t st = (hipStream_t)stream;
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
+#if OFL_WARP_COL_ADD >= 2
+    if (add) {                                     // (the fused composition: 2 channels)
+        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        return (int)hipGetLastError();
+    }
+#endif
 #define OFL_WIDE_CASE(NC)                                                                                                                   \
     if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);           \
     else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
@@ -2523,6 +2587,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     if (OFL_WARP_COL_ADD && kLdsT > 2 && add && NC == 2 && !p.flow_flags) {
         WarpParams q = p;
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+        if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, (void*)st);
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
@@ -2549,7 +2614,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     WarpParams q = p;
     const unsigned g = (kLdsT > 2 && !add && !p.flow_flags) ? warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) : 0u;
     if (g >= kColumnMinGroups && g_warp_path != 3) {
-        if (OFL_WARP_WIDE) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, (void*)st);    // 64 x 16 tiles: -1.9 % (see kLdsNT)
+        if (OFL_WARP_WIDE) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 0, (void*)st);    // 64 x 16 tiles: -1.9 % (see kLdsNT)
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
