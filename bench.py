@@ -278,6 +278,10 @@ def main():
                     help="(the sharded probe's child) run the batch-sharded validation route on a communicator of ONE rank")
     ap.add_argument("--flag-route", choices=("host", "comm"), default="host",
                     help="batch sharding: flag words cross the ranks through shared memory (one node) or through the communicator")
+    ap.add_argument("--shared-image", action="store_true",
+                    help="the reference's 1 <-> N broadcast (utils.py:527-537): ONE B = 1 image + target mask owned by rank 0, sent to "
+                         "every rank with distributed.broadcast_operand (RCCL broadcast over xGMI) once per timed block, INSIDE the "
+                         "timed region, and warped by every rank's shard of the flows through the stride-0 batch broadcast")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass")
     args = ap.parse_args()
@@ -323,6 +327,25 @@ def main():
         inclusive and on cached objects; then HIP events round every launch of max(steps, 100) more steps.
         -> per-block seconds (both flavours) and the per-launch kernel times in ms"""
         f1, f2, img, m1, m2, tm = make_inputs(nb, h, w, dev, seed=seed)
+        bcast_ev = []
+        if args.shared_image:
+            # ONE image and ONE target mask for the whole job: rank 0 owns them, the other ranks hold empty buffers of the same shape
+            g = torch.Generator(device='cpu').manual_seed(2000)
+            own_img = (torch.rand(1, 3, h, w, generator=g) * 255).to(dev)
+            own_tm = hole_mask(1, h, w, dev).flip(1)
+            img = own_img.clone() if rank == 0 else torch.zeros_like(own_img)
+            tm = own_tm.clone() if rank == 0 else torch.zeros_like(own_tm)
+
+        def share():
+            """the shared operand's trip: one broadcast of the image (24.9 MB at 1080p) and one of its mask (2.1 MB), timed by HIP events"""
+            if not args.shared_image:
+                return
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ofd.broadcast_operand(img, src=0)
+            ofd.broadcast_operand(tm.view(torch.uint8), src=0)          # (bool bytes travel as uint8)
+            e1.record()
+            bcast_ev.append((e0, e1))
 
         def step_streaming():
             a, b = ofl.Flow(f1, 't', m1), ofl.Flow(f2, 't', m2)        # validation: one fused flag reduction + read-back each
@@ -331,9 +354,14 @@ def main():
         for _ in range(warmup):
             step_streaming()
         stream_s = []
+        share()
+        if args.shared_image and rank != 0:
+            torch.cuda.synchronize()
+            assert torch.equal(img, own_img) and torch.equal(tm, own_tm), "broadcast_operand did not deliver rank 0's operand"
         for _ in range(blocks):
             barrier()
             t0 = time.perf_counter()
+            share()                                                     # (inside the timed region, once per block)
             for _ in range(steps):                                      # EXACTLY `steps` timed steps per block
                 step_streaming()
             barrier()
@@ -367,7 +395,8 @@ def main():
         barrier()
         ta = sorted(e[0].elapsed_time(e[1]) for e in ev)
         tc = sorted(e[1].elapsed_time(e[2]) for e in ev)
-        return {"stream_s": stream_s, "cached_s": cached_s, "launches": k,
+        bms = sorted(e0.elapsed_time(e1) for e0, e1 in bcast_ev[1:]) if len(bcast_ev) > 1 else []
+        return {"stream_s": stream_s, "cached_s": cached_s, "launches": k, "broadcast_ms": (bms[len(bms) // 2] if bms else None),
                 "apply_ms": sum(ta) / k, "comb_ms": sum(tc) / k, "apply_ms_median": ta[k // 2], "comb_ms_median": tc[k // 2],
                 "apply_ms_min": ta[0], "comb_ms_min": tc[0]}
 
@@ -385,7 +414,7 @@ def main():
     elapsed, el_cached = med(stream_blocks), med(cached_blocks)          # the median block is the reported one
 
     probe = None
-    if world == 1 and not args.no_probe and (n, h, w) == (64, 1080, 1920):
+    if world == 1 and not args.no_probe and not args.shared_image and (n, h, w) == (64, 1080, 1920):
         # BASELINE.json configs[3] on 8 GPUs leaves 8 elements per GPU: the same step at B = 8 on this GPU
         k8 = max(args.steps, 100)
         p8 = measure(8, k8, 5, 11, 5)
@@ -430,7 +459,7 @@ def main():
 
     if rank == 0:
         traffic_source = "--traffic-bytes" if args.traffic_bytes is not None else None
-        if args.traffic_bytes is None and (n, h, w) == (64, 1080, 1920):
+        if args.traffic_bytes is None and not args.shared_image and (n, h, w) == (64, 1080, 1920):
             for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # PMC passes are separate runs (tools/refresh_profiles_r4.sh)
                 tj = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tj):
@@ -442,7 +471,9 @@ def main():
         px = n * h * w
         gpx = global_batch * h * w
         ms_step = elapsed / args.steps * 1e3
-        ach = BYTES_APPLY * px / (t_apply * 1e-3) / 1e9
+        # --shared-image: the B = 1 image + target mask (13 B/px) are read once per launch, not once per batch element
+        bytes_apply = (BYTES_APPLY - 13) + 13.0 / max(n, 1) if args.shared_image else BYTES_APPLY
+        ach = bytes_apply * px / (t_apply * 1e-3) / 1e9
         per_step = sorted(b / args.steps * 1e3 for b in stream_blocks)
         out = {
             "metric": "Mpix/s warped+composed (Flow(...) x2 from raw tensors, Flow.apply 't' C=3 + valid area, then "
@@ -456,9 +487,11 @@ def main():
             "config": {"workload": "B=%d/GPU %dx%d fp32: Flow(f,'t',mask) x2 (validation), Flow.apply('t', C=3 image, "
                                    "target+flow masks, valid area) + combine_with(mode=3, 't', masks)" % (n, h, w),
                        "batch_per_gpu": n, "global_batch": global_batch, "height": h, "width": w,
-                       "parallelism": "batch-sharded x%d (no data-path collective)" % world,
+                       "parallelism": ("batch-sharded x%d; shared B=1 image + target mask: RCCL broadcast from rank 0 once per block "
+                                       "(distributed.broadcast_operand), stride-0 batch broadcast in the warp" % world) if args.shared_image
+                       else "batch-sharded x%d (no data-path collective)" % world,
                        "launcher": "torch.distributed (nccl)" if dist.is_initialized() else "single process",
-                       "bytes_per_px": BYTES_APPLY + BYTES_COMBINE},
+                       "bytes_per_px": round(bytes_apply + BYTES_COMBINE, 3)},
             "timing": {"blocks": len(stream_blocks), "steps_per_block": args.steps, "reported": "median block",
                        "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
                        "ms_per_step_max": round(per_step[-1], 4),
@@ -468,7 +501,7 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": args.traffic_bytes,
                          "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": BYTES_APPLY * px,
+                         "algorithmic_bytes_per_launch": int(bytes_apply * px),
                          "avg_launch_ms": round(t_apply, 4), "median_launch_ms": round(r["apply_ms_median"], 4),
                          "min_launch_ms": round(r["apply_ms_min"], 4), "launches_timed": r["launches"],
                          "device_copy_GBs": round(copy_gbs, 1), "frac_of_device_copy": round(ach / copy_gbs, 4)},
@@ -479,6 +512,10 @@ def main():
                         "validation_ms_per_step": round(ms_step - el_cached / args.steps * 1e3, 4)},
             "value_cached_flow_objects": round(gpx / (el_cached / args.steps) / 1e6, 1),
         }
+        if args.shared_image:
+            out["broadcast_ms"] = None if r["broadcast_ms"] is None else round(r["broadcast_ms"], 4)
+            out["broadcast_note"] = ("median HIP-event time of the two broadcasts (image 3 x H x W fp32 + mask H x W bytes) per timed block; "
+                                     "at one rank without --force-collectives there is nobody to send to and the call returns at once")
         if secondary is not None:
             out["secondary"] = secondary
         if probe is not None:

@@ -248,6 +248,9 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_WARP_ALWAYS_T
+#define OFL_WARP_ALWAYS_T 1
+#endif
 #ifndef OFL_WARP_MERGE_BARRIER
 #define OFL_WARP_MERGE_BARRIER 1
 #endif
@@ -876,7 +879,12 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     for (int k = 0; k < T; ++k) {
         OFL_WARP_PHASE();
         const int tyk = tyg * T + k;
-        const bool more = (k + 1 < T) && ((tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
+        // OFL_WARP_ALWAYS_T: a block runs all T tiles of its column whatever the frame's height -- a tile past the bottom edge
+        // recomputes and re-stores the frame's last row (clamped loads, identical duplicate stores), at most T - 1 tiles of
+        // the last row of groups.  No run-time branch round the staging loads or the stores is left, so the compiler counts
+        // every one of them in its vmcnt waits (see lds_store).
+        // (not with the ADD epilogue: its re-used flow registers leave no room for the longer live ranges -- 36 B of scratch, -13 %)
+        const bool more = (k + 1 < T) && ((OFL_WARP_ALWAYS_T && !ADD) || (tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
         LdsBoxWords wn = {0, 0};
         if (k + 1 < T) {
             // ... while the next tile's coordinates are computed (OFL_WARP_MERGE_BARRIER: the block-wide half of its box behind the
@@ -2691,6 +2699,30 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
 }
 
 
+// How many 256-thread blocks of a fallback-kernel instantiation the current device holds AT ONCE, halved (the grid barrier of
+// splat_fallback_kernel spins: a block that cannot be scheduled would hang every resident one).  Occupancy query x CU count, per
+// device and instantiation, cached; one block per CU fewer than the API says where it says more than one (the API is one high
+// for some register counts: MI355X_MICROARCH.md, residency); never above kFallbackBlocks, never below 1.
+inline unsigned fallback_resident_blocks(const void* kernel, int which) {
+    static int cache[64][5];                                  // 0 = not asked yet (a benign race: every asker stores the same number)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int v = cache[dev][which];
+    if (v == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
+        if (per_cu > 1) per_cu -= 1;
+        if (per_cu < 1) per_cu = 1;
+        int64_t b = ((int64_t)per_cu * cus) / 2;
+        if (b > (int64_t)kFallbackBlocks) b = kFallbackBlocks;
+        if (b < 1) b = 1;
+        v = (int)b;
+        cache[dev][which] = v;
+    }
+    return (unsigned)v;
+}
+
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
@@ -3182,7 +3214,14 @@ static int splat_tiled_impl(
             const int planes = 1 + cg + (fb.with_mask_chan ? 1 : 0);
             unsigned g2;
             tile_grid((int32_t)nn, h, w, fb.tiles_x, fb.tiles_y, fb.total_tiles, fb.per_xcd, g2);
-            if (g2 > kFallbackBlocks) g2 = kFallbackBlocks;   // (strided: the kernel walks the tiles of the flagged images; resident as a whole -- its passes meet at grid barriers)
+            // (strided: the kernel walks the tiles of the flagged images; its passes meet at grid barriers, so the grid must be
+            // RESIDENT AS A WHOLE: bounded by what the device -- a CPX partition, a CU-masked stream's device -- can hold, with
+            // half of it left to whatever else runs, a second call's fallback kernel on another stream included)
+            const int which = half_in ? (elem == 2 ? 3 : 4) : (cg == 1 ? 0 : (cg == 2 ? 1 : 2));
+            const void* kfn = half_in ? (elem == 2 ? (const void*)splat_fallback_kernel<2, _Float16, _Float16> : (const void*)splat_fallback_kernel<2, _Float16, float>)
+                                      : (cg == 1 ? (const void*)splat_fallback_kernel<1> : (cg == 2 ? (const void*)splat_fallback_kernel<2> : (const void*)splat_fallback_kernel<3>));
+            const unsigned resident = fallback_resident_blocks(kfn, which);
+            if (g2 > resident) g2 = resident;
             for (int64_t r0 = 0; r0 < nn; r0 += fb.fb_slots) {
                 fb.fb_round = (int32_t)(r0 / fb.fb_slots);
                 int32_t* arrivals = gp.stats + 4;           // two words, zeroed with the statistics words at the start of the call and left zero by every launch

@@ -10,6 +10,7 @@ one tiny all-reduce, cached per tensor version like the local flags.  A shared B
 1<->N broadcast) is distributed with `broadcast_operand`; `all_gather_batch` reassembles results when asked.
 """
 import atexit
+import threading
 import time
 
 import numpy as np
@@ -21,7 +22,8 @@ _enabled = False
 _force_collectives = False   # tests only: run the collectives on a communicator of ONE rank too (tests/test_gpu_validation.py)
 _exchange = None             # _HostExchange of the group when every rank lives on this host (the 8 GPUs of one node), else None
 USE_HOST_EXCHANGE = True     # False: the flag words always travel through the communicator (RCCL / gloo), as in rounds 1-3
-EXCHANGE_TIMEOUT_SECONDS = 120.0
+EXCHANGE_TIMEOUT_SECONDS = None   # how long a rank waits for a peer's flag word; None: the process group's own timeout (RCCL /
+#                                   gloo tolerate that much skew between ranks -- a rank that checkpoints or compiles -- and so must this)
 
 
 class _HostExchange(object):
@@ -41,16 +43,23 @@ class _HostExchange(object):
         from multiprocessing import shared_memory
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.seq = 0
+        self.lock = threading.Lock()          # or_reduce from two threads of one rank: `seq` and the slot store are one step
+        self.timeout = _exchange_timeout(group)
         size = self.world * self.RING * 8
         name = [None]
         self.shm = None
         if self.rank == 0:
-            self.shm = shared_memory.SharedMemory(create=True, size=size)
-            np.ndarray((self.world * self.RING,), dtype=np.int64, buffer=self.shm.buf)[:] = 0
-            name[0] = self.shm.name
+            # a failure here (no /dev/shm, no room) must not leave the other ranks in the broadcast below: rank 0 sends
+            # name = None and EVERY rank falls back to the communicator route together
+            try:
+                self.shm = shared_memory.SharedMemory(create=True, size=size)
+                np.ndarray((self.world * self.RING,), dtype=np.int64, buffer=self.shm.buf)[:] = 0
+                name[0] = self.shm.name
+            except Exception:  # noqa: BLE001
+                self.shm = None
         dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ok = 1
-        if self.rank != 0:
+        ok = 1 if name[0] is not None else 0
+        if self.rank != 0 and ok:
             try:
                 self.shm = shared_memory.SharedMemory(name=name[0])
                 # (the segment belongs to rank 0: this process must not unlink it at exit)
@@ -67,6 +76,15 @@ class _HostExchange(object):
         self.slots = None if self.shm is None else np.ndarray((self.world, self.RING), dtype=np.int64, buffer=self.shm.buf)
 
     def or_reduce(self, bits: int) -> int:
+        # Memory-ordering assumption: the word is ONE aligned 8-byte store of a NumPy int64 and the readers'
+        # loads are aligned 8-byte loads -- single-copy atomic on x86-64 and AArch64, and the word carries its own sequence
+        # number, so no ordering BETWEEN words is relied upon.  Thread safety: the lock makes (seq, slot store, reads) one step
+        # per rank -- two threads of one rank take two consecutive sequence numbers; as with any collective, all ranks must
+        # then make their calls in the same order.
+        with self.lock:
+            return self._or_reduce_locked(bits)
+
+    def _or_reduce_locked(self, bits: int) -> int:
         self.seq += 1
         k, e = self.seq, self.seq % self.RING
         self.slots[self.rank, e] = (k << 8) | (bits & 0xff)          # one aligned 8-byte store: sequence number and bits arrive together
@@ -83,7 +101,7 @@ class _HostExchange(object):
                 if looks & 0x3ff == 0:
                     now = time.perf_counter()
                     t0 = now if t0 is None else t0
-                    if now - t0 > EXCHANGE_TIMEOUT_SECONDS:
+                    if now - t0 > self.timeout:
                         raise RuntimeError("oflibpytorch_amd.distributed: rank %d did not post flag exchange %d (ranks must make "
                                            "the same sequence of calls)" % (r, k))
                     if now - t0 > 1e-3:
@@ -99,6 +117,22 @@ class _HostExchange(object):
                     shm.unlink()
             except Exception:  # noqa: BLE001
                 pass
+
+
+def _exchange_timeout(group) -> float:
+    """Seconds a rank waits for a peer's flag word: EXCHANGE_TIMEOUT_SECONDS when set, else the timeout of the process group's
+    own backend (torch's defaults: 10 min for RCCL, 30 min for gloo), else 30 min."""
+    if EXCHANGE_TIMEOUT_SECONDS is not None:
+        return float(EXCHANGE_TIMEOUT_SECONDS)
+    try:
+        pg = group if group is not None else dist.group.WORLD
+        return float(pg._get_backend(_collective_device(group)).options._timeout.total_seconds())
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        return float(dist.distributed_c10d._get_default_timeout(dist.get_backend(group)).total_seconds())
+    except Exception:  # noqa: BLE001
+        return 1800.0
 
 
 def _collective_device(group):
@@ -188,11 +222,13 @@ def split_global_or(host: list) -> tuple:
 
 
 def shard_bounds(n: int, rank: int = None, world: int = None) -> tuple:
-    """Contiguous batch chunk [lo, hi) of rank `rank` (ragged tail allowed)."""
+    """Contiguous batch chunk [lo, hi) of rank `rank`.  A batch that does not divide is BALANCED: the first n % world ranks hold
+    one element more (60 over 8: 8, 8, 8, 8, 7, 7, 7, 7; 2 over 4: 1, 1, 0, 0 -- empty shards are allowed)."""
     rank = dist.get_rank(_group) if rank is None else rank
     world = dist.get_world_size(_group) if world is None else world
-    per = (n + world - 1) // world
-    return min(rank * per, n), min((rank + 1) * per, n)
+    per, extra = divmod(n, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
 
 
 def broadcast_operand(t: torch.Tensor, src: int = 0) -> torch.Tensor:

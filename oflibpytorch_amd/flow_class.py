@@ -285,6 +285,9 @@ class Flow(object):
     def vecs(self, input_vecs):
         v = get_valid_vecs(input_vecs, error_string="Error setting flow vectors: ", _check_finite=False)
         old = self._vecs
+        # the caller's tensor may be stored as it is (an fp32 tensor on the device passes through get_valid_vecs): a flow
+        # that was private to its object is not any more, so an inference tensor's key must stop matching
+        self._release_private()
         self._vecs, self._flag_cache, self._pending_flags = v, None, None
         try:
             self._require_finite("Error setting flow vectors: ")
@@ -295,6 +298,7 @@ class Flow(object):
     @property
     def vecs_numpy(self) -> np.ndarray:
         """N-H-W-2 float32 numpy view of the vectors (flow_class.py:95-110)"""
+        self._release_private()               # (a CPU-resident flow hands out shared memory here)
         return np.moveaxis(self._vecs.detach().cpu().numpy(), 1, -1)
 
     @property
@@ -324,6 +328,7 @@ class Flow(object):
 
     @mask.setter
     def mask(self, input_mask=None):
+        self._release_private()               # (the caller's mask may be stored as it is: see the vecs setter)
         if input_mask is None:
             self._mask = None
         else:
@@ -345,6 +350,8 @@ class Flow(object):
     def device(self, input_device=None):
         device = self._fv.device if input_device is None else get_valid_device(input_device)
         self._device = device
+        if self._fv.device != device or (self._mask is not None and self._mask.device != device):
+            self._release_private()           # storage is replaced: the privacy of the old tensors says nothing about the new ones
         if self._fv.device != device:
             self._vecs = self._fv.to(device) if device.type == 'cuda' else self._vecs.to(device)
             self._flag_cache = None if self._flag_cache is None else \

@@ -169,3 +169,7 @@ def test_from_matrix_contract():
     back = ofl.from_matrix(torch.linalg.inv(shift), (6, 8), 't', matrix_is_inverse=True)
     assert torch.allclose(back, ofl.from_matrix(shift, (6, 8), 't'), atol=1e-5)
     assert Flow.from_matrix(shift, (6, 8), 's').shape == (1, 6, 8)
+    # the public helper with a 2-D 3 x 3 matrix is ONE matrix (its first dimension is not a batch size)
+    from oflibpytorch_amd import utils
+    one = utils.flow_from_matrix(shift, [1, 6, 8])
+    assert one.shape == (1, 2, 6, 8) and torch.equal(one, utils.flow_from_matrix(shift.unsqueeze(0), [1, 6, 8]))

@@ -77,6 +77,27 @@ def _worker(rank, world, port, q):
         assert float(ofd.broadcast_operand(shared, src=0).sum()) == 7.0 * 48
         gathered = ofd.all_gather_batch(out.vecs)
         assert np.array_equal(gathered.numpy(), ev)
+        # 3b. the reference's 1 <-> N broadcast (utils.py:527-537; flow_class.py:896-897) END TO END under sharding: ONE image and ONE
+        # target mask live on rank 0, travel with `broadcast_operand` (the only data-path collective the path has), and every rank
+        # warps it with its own shard of the flows through the stride-0 batch broadcast -- equal to the unsharded oracle
+        one_img = torch.rand(1, 3, h, w, generator=g)
+        one_tm = torch.rand(1, h, w, generator=g) > 0.2
+        mine_img = ofd.broadcast_operand(one_img.clone() if rank == 0 else torch.zeros(1, 3, h, w), src=0)
+        mine_tm = ofd.broadcast_operand((one_tm.clone() if rank == 0 else torch.zeros(1, h, w, dtype=torch.bool)).to(torch.uint8), src=0).bool()
+        assert torch.equal(mine_img, one_img) and torch.equal(mine_tm, one_tm)
+        sw, sv = ofl.Flow(f2[lo:hi], 't', m2[lo:hi]).apply(mine_img, target_mask=mine_tm, return_valid_area=True)
+        ew, evalid = oracle.flow_apply(f2.numpy(), 't', m2.numpy(), one_img.expand(4, -1, -1, -1).numpy(), one_tm.expand(4, -1, -1).numpy())
+        assert sw.shape == (2, 3, h, w) and np.array_equal(sw.numpy(), ew[lo:hi]) and np.array_equal(sv.numpy(), evalid[lo:hi])
+        # ... and the other way round: ONE flow (rank 0's) warps every rank's shard of a batch of images
+        one_flow = ofd.broadcast_operand(f2[0:1].clone() if rank == 0 else torch.zeros(1, 2, h, w), src=0)
+        bw = ofl.Flow(one_flow, 't').apply(img[lo:hi])
+        eb, _ = oracle.flow_apply(f2[0:1].expand(4, -1, -1, -1).numpy(), 't', np.ones((4, h, w), bool), img.numpy())
+        assert np.array_equal(bw.numpy(), eb[lo:hi])
+        # ragged strong scaling (bench.py --scaling strong --batch 3 on 2 ranks: 2 + 1): unequal shards, same batch-global decisions
+        r0, r1 = ofd.shard_bounds(3, rank, world)
+        assert (r1 - r0) == (2 if rank == 0 else 1)
+        rg = ofl.Flow(f1[1:4][r0:r1], 't', m1[1:4][r0:r1]).combine_with(ofl.Flow(f2[1:4][r0:r1], 't', m2[1:4][r0:r1]), 3)
+        assert rg.vecs.shape[0] == r1 - r0 and np.array_equal(ofd.all_gather_batch(rg.vecs).numpy(), ev[1:4])
         # ragged shards (3 elements over 2 ranks: 2 + 1; 1 element: 1 + 0) gather in order
         for total in (3, 1):
             a0, a1 = ofd.shard_bounds(total, rank, world)
@@ -106,6 +127,37 @@ def _worker(rank, world, port, q):
             ofl.Flow(bad[lo:hi], 't')
         ofd.disable_batch_sharding()
         ofd.USE_HOST_EXCHANGE = True
+        # 5. ADVICE r4: (a) or_reduce from two threads of one rank -- the lock makes (sequence number, slot store, reads) one step
+        ofd.enable_batch_sharding()
+        assert ofd.host_exchange_active()
+        import threading
+        got = []
+
+        def many():
+            for _ in range(100):
+                got.append(ofd.reduce_flags(1 << rank, torch.device('cpu')))
+        ths = [threading.Thread(target=many) for _ in range(2)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert got == [0b11] * 200
+        assert ofd._exchange.timeout >= 600.0       # the process group's own timeout (gloo: 30 min), not a private 120 s
+        ofd.disable_batch_sharding()
+        # (b) rank 0 cannot create the segment: EVERY rank falls back to the communicator route together (nobody is left in a collective)
+        from multiprocessing import shared_memory
+        real_shm = shared_memory.SharedMemory
+
+        def failing(*a, **k):
+            if k.get("create"):
+                raise OSError("no shared memory here")
+            return real_shm(*a, **k)
+        shared_memory.SharedMemory = failing if rank == 0 else real_shm
+        try:
+            ofd.enable_batch_sharding()
+            assert ofd.is_enabled() and not ofd.host_exchange_active()
+            assert ofd.reduce_flags(1 << rank, torch.device('cpu')) == 0b11
+            ofd.disable_batch_sharding()
+        finally:
+            shared_memory.SharedMemory = real_shm
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -129,5 +181,9 @@ def test_batch_sharding_world_size_2():
 
 def test_shard_bounds_ragged():
     from oflibpytorch_amd import distributed as ofd
-    assert [ofd.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
-    assert ofd.shard_bounds(2, 3, 4) == (2, 2)
+    assert [ofd.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert ofd.shard_bounds(2, 3, 4) == (2, 2) and ofd.shard_bounds(2, 1, 4) == (1, 2)
+    # BASELINE configs[3] with a batch that does not divide (bench.py --scaling strong --batch 60 on 8 GPUs): 8, 8, 8, 8, 7, 7, 7, 7
+    b = [ofd.shard_bounds(60, r, 8) for r in range(8)]
+    assert [hi - lo for lo, hi in b] == [8, 8, 8, 8, 7, 7, 7, 7] and b[0][0] == 0 and b[-1][1] == 60
+    assert all(b[i][1] == b[i + 1][0] for i in range(7))

@@ -142,10 +142,23 @@ def test_resize_on_the_device_equals_atens_cpu_kernels_bit_for_bit(shape, dev):
             continue
         ref = F.interpolate(x, scale_factor=[float(sf[0]), float(sf[1])], mode='bilinear', align_corners=False)
         got = _native.resize_bilinear(x.to(dev), sf)
-        assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (shape, sf)
+        # bit for bit against ATen's CPU kernels on the torch version they were probed on (kernel selection and FMA
+        # contraction are properties of a build); on any other version within 1e-6 of the scale -- and always exactly the oracle
+        from oflibpytorch_amd import utils as _u
+        if torch.__version__.startswith(_u.RESIZE_PROBED_TORCH):
+            assert got.shape == ref.shape and torch.equal(got.cpu(), ref), (shape, sf)
+        else:
+            assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), (shape, sf)
         assert np.array_equal(got.cpu().numpy(), oracle.resize_bilinear(x.numpy(), sf))
     if shape[1] == 2:
         out = ofl.resize_flow(x.to(dev), [1.5, 0.7])
         assert out.device.type == 'cuda' and np.array_equal(out.cpu().numpy(), oracle.resize_flow(x.numpy(), [1.5, 0.7]))
-        assert torch.equal(out.cpu(), ofl.resize_flow(x, [1.5, 0.7]))           # the host route (ATen's CPU kernel itself)
+        if torch.__version__.startswith(_u.RESIZE_PROBED_TORCH):
+            assert torch.equal(out.cpu(), ofl.resize_flow(x, [1.5, 0.7]))       # the host route (ATen's CPU kernel itself)
+        _u.RESIZE_MATCHES_ATEN_CPU = False                                      # the reference's own route on a HIP device: ATen's GPU kernel
+        try:
+            aten = ofl.resize_flow(x.to(dev), [1.5, 0.7])
+        finally:
+            _u.RESIZE_MATCHES_ATEN_CPU = True
+        assert aten.device.type == 'cuda' and float((aten.cpu() - out.cpu()).abs().max()) <= 1e-5 * float(out.abs().max())
 

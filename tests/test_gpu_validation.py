@@ -297,6 +297,24 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank(dev):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["launcher"] == "torch.distributed (nccl)"
 
 
+def test_bench_shared_image_and_ragged_strong_scaling_under_torch_distributed_run(dev):
+    """`bench.py --shared-image` drives the reference's 1 <-> N broadcast case (utils.py:527-537; flow_class.py:896-897)
+    through the only data-path collective the path has -- a B = 1 image + target mask broadcast from rank 0 (RCCL, forced on at one
+    rank) inside the timed region, warped through the stride-0 batch broadcast -- and `--scaling strong --batch 5` takes a batch that
+    does not divide.  World size 2 runs in the gloo tier (tests/test_distributed_gloo.py, section 3b)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "5",
+           "--scaling", "strong", "--shared-image", "--force-collectives", "--no-cpu-baseline", "--no-probe", "--no-secondary", "--blocks", "3"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    import json
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "strong" and out["config"]["global_batch"] == 5
+    assert "broadcast" in out["config"]["parallelism"] and out["broadcast_ms"] is not None and out["broadcast_ms"] > 0
+    assert abs(out["config"]["bytes_per_px"] - (22 + 13 / 5 + 27)) < 1e-2
+
+
 def test_kernel_outputs_keep_their_flag_words_under_inference_mode(dev, monkeypatch):
     """under torch.inference_mode() tensors carry no version counter, so the flag cache of a flow never matched and
     every use re-ran the reduction and waited for it -- also for kernel OUTPUTS nobody else holds.  Those are now `private`:
@@ -347,4 +365,24 @@ def test_kernel_outputs_keep_their_flag_words_under_inference_mode(dev, monkeypa
         c4 = a.combine_with(b, 3)
         _ = c4.invert()                             # an internal temporary over c4's tensors does not end it
         assert c4._private
+        # the public setters store the caller's tensor as it is -- privacy must end, so that an in-place edit of
+        # that tensor is seen by the next use
+        c5 = a.combine_with(b, 3)
+        assert c5._private
+        v = torch.zeros(2, 2, 40, 56, device=dev)
+        c5.vecs = v
+        assert not c5._private
+        assert c5.combine_with(b, 3) is b           # the zero flow: the second operand comes back
+        v += 3.0
+        shifted = c5.combine_with(b, 3)
+        assert shifted is not b
+        assert torch.equal(shifted.vecs, ofl.Flow(v.clone(), 't').combine_with(b, 3).vecs)
+        c6 = a.combine_with(b, 3)
+        m = torch.zeros(2, 40, 56, dtype=torch.bool, device=dev)
+        c6.mask = m
+        assert not c6._private
+        k0 = c6._flags()
+        m.fill_(True)
+        assert not c6._flags_known()                # the edit of the caller's mask invalidates the word
+        assert c6._flags() != k0                    # (masked bits: none under an all-False mask, set under an all-True one)
     assert per_use <= 2.0
