@@ -225,6 +225,17 @@ def secondary_lines(ofl, dev):
          _event_ms(lambda: fs2.apply(img, target_mask=tm, return_valid_area=True), 50, 3))
     line("switch_ref 's'->'t' B=16 1080x1920 fp32 (sigma 8)", 16 * h * w, 18, _event_ms(lambda: fs.switch_ref(), 50, 3))
     del f1, f2, img, m1, m2, tm, fs, fs2, fl
+    # many channels: Flow.apply 't' of an N-C-H-W feature tensor, B = 8, C = 64 -- ONE launch that walks the channels
+    # inside the block (warp_bwd_lds_chan_kernel); algorithmic bytes: flow 8 + flow mask 1 + every plane read once and written once
+    torch.cuda.empty_cache()
+    cf = ofl.Flow(smooth_flow(8, h, w, 8.0, 1003, dev), 't', hole_mask(8, h, w, dev))
+    feat = torch.rand(8, 64, h, w, device=dev)
+    line("many channels: B=8 1080x1920 C=64 fp32 Flow.apply 't' (feature tensor, flow mask; one launch, channel loop in the block; sigma 8)",
+         8 * h * w, 8 + 8 * 64 + 1, _event_ms(lambda: cf.apply(feat), 20, 3),
+         {"note": "bound by memory-side traffic, not by the bytes counted here: halo lines of a tile's box are re-fetched per channel group "
+                  "(profiles/r5_chan_pmc.txt: 2.26 x the algorithmic reads at sigma 8, 1.48 x at sigma 2, ~6.4 TB/s of fabric traffic either way)"})
+    del cf, feat
+    torch.cuda.empty_cache()
     # config 5: B = 16 (the per-GPU share of B = 128 on 8 GPUs) 2160x3840, flows STORED in fp16: switch_ref s->t, then mode 1
     h, w = 2160, 3840
     g1 = smooth_flow(16, h, w, 8.0, 1005, dev).half()

@@ -52,12 +52,14 @@ extern "C" {
 int ofl_version(void);
 
 /* Process-wide options (testing / benchmarking aids; defaults are what production uses).
- *   OFL_OPT_WARP_PATH: 0 = auto (LDS-staged kernel when the launch is eligible: W >= 4, H >= 2; > 3 channels in groups of 3;
+ *   OFL_OPT_WARP_PATH: 0 = auto (LDS-staged kernel when the launch is eligible: W >= 4, H >= 2; > 3 channels in ONE launch that loops over them;
  *                          generic direct-gather kernel otherwise -- both restate the same arithmetic),
  *                      1 = generic direct-gather kernel only,
  *                      3 / 4 = like auto, but the staged kernel with two tiles / one tile per block whatever the launch size
  *                          (auto picks by size: one tile per block for tiny launches, two for small ones, columns of four
- *                          from ~B = 8 at 1080p; all three run the same device code per tile -- tests compare them). */
+ *                          from ~B = 8 at 1080p; all three run the same device code per tile -- tests compare them),
+ *                      5 = like auto, but a warp of more than 3 channels runs as separate launches of 3 channels instead of the
+ *                          channel-loop kernel (one launch that walks the channels in groups of 4 inside the block; W % 4 == 0). */
 #define OFL_OPT_WARP_PATH 1
 /*   OFL_OPT_WARP_SHEAR: 1 = the LDS-staged warp kernel stages a y-sheared box (default), 0 = plain bounding box
  *   (speed only; the results are identical). */

@@ -133,7 +133,8 @@ def set_splat_pass_images(k: int):
 
 def set_warp_path(mode: int):
     """0 = auto (LDS-staged kernel when eligible), 1 = generic direct-gather kernel only, 3 / 4 = staged with two tiles / one tile
-    per block whatever the launch size (tests compare them all)."""
+    per block whatever the launch size, 5 = auto but more than 3 channels as separate launches of 3 instead of the channel-loop
+    kernel (tests compare them all)."""
     _check(load_library().ofl_set_option(1, int(mode)), "ofl_set_option")
 
 

@@ -20,6 +20,7 @@
 
 // the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
 int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void* stream);
+int ofl_wide_launch_chan(const void* params, int valid, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles
 
 namespace {
 
@@ -248,6 +249,12 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_WARP_CHAN
+#define OFL_WARP_CHAN 1
+#endif
+#ifndef OFL_WARP_CHAN_WIDE
+#define OFL_WARP_CHAN_WIDE 1
+#endif
 #ifndef OFL_WARP_ALWAYS_T
 #define OFL_WARP_ALWAYS_T 1
 #endif
@@ -383,9 +390,9 @@ template <int NC> struct LdsStage { int slot[kLdsIters]; f4 q[kLdsIters][NC]; ui
 struct LdsBoxWords { int lo, hi; };
 template <bool BOX = true, typename WP>
 __device__ __forceinline__ LdsBoxWords lds_coords_box_a(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
-                                                        LdsCoords& T, int (*red)[4]) {
+                                                        LdsCoords& T, int (*red)[4], int row = -1) {
     constexpr int NW = kLdsNT / 64;
-    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = row >= 0 ? row : tid / kLdsTWQ;   // (row: the tile row this lane works on, when it is not its own -- chan_tile's row parts)
     const int w = p.w, h = p.h;
     const int xc = min(tx * (kLdsTWQ * 4) + lx * 4, w - 4), yc = min(ty * kLdsTH + ly, h - 1);
     // ((x - s*u) * 2) / (w - 1) - 1, then (g + 1) * ((w - 1) / 2)   (utils.py:462-465, 549)
@@ -490,8 +497,8 @@ __device__ __forceinline__ void lds_coords_box_b(const WP& p, int sq, LdsBoxWord
 
 template <bool BOX = true, bool CLIP = false, typename WP>
 __device__ __forceinline__ void lds_coords_box(const WP& p, int tx, int ty, const f4& u4, const f4& v4, int sq,
-                                               LdsCoords& T, LdsBox& B, int (*red)[4]) {
-    const LdsBoxWords wds = lds_coords_box_a<BOX>(p, tx, ty, u4, v4, sq, T, red);
+                                               LdsCoords& T, LdsBox& B, int (*red)[4], int row = -1) {
+    const LdsBoxWords wds = lds_coords_box_a<BOX>(p, tx, ty, u4, v4, sq, T, red, row);
     if (!BOX) return;
     if (kLdsNT > 64) lds_barrier();
     lds_coords_box_b<CLIP>(p, sq, wds, B, red);
@@ -679,7 +686,7 @@ __device__ __forceinline__ void lds_load_addend(const WP& p, int tx, int ty, int
 // step 4b: valid mask, epilogue (a_sign * addend + g_sign * G, rounding), 16-byte stores
 template <int NC, bool VALID, bool ADD, bool DF = false, typename TD = float, typename WP = WarpParams>
 __device__ __forceinline__ void lds_store(const WP& p, int tx, int ty, int n, uint32_t hw, uint32_t fmask4,
-                                          const f4 (&outv)[4], const f4 (&addend)[NC], int* dflags = nullptr) {
+                                          const f4 (&outv)[4], const f4 (&addend)[NC], int* dflags = nullptr, int64_t choff = 0) {
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const int w = p.w, h = p.h;
     const int x4 = tx * (kLdsTWQ * 4) + lx * 4, y = ty * kLdsTH + ly;
@@ -699,7 +706,7 @@ __device__ __forceinline__ void lds_store(const WP& p, int tx, int ty, int n, ui
                 vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmask4 >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
             st32o(p.valid + (int64_t)n * hw + pix, vo);
         }
-        TD* __restrict__ db = reinterpret_cast<TD*>(p.dst) + (int64_t)n * p.dst_bs;
+        TD* __restrict__ db = reinterpret_cast<TD*>(p.dst) + (int64_t)n * p.dst_bs + choff;   // (choff: first plane of a channel group, warp_bwd_lds_chan_kernel)
         f4 o01[2];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -929,6 +936,293 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
 #if OFL_WARP_KARG
 #undef p
 #endif
+}
+
+// MANY CHANNELS (C >= 4; Flow.apply of an N-C-H-W feature tensor, utils.py:469-555): ONE launch for all of them.  A block owns one
+// output tile: flow, coordinates, bounding box, the byte addresses of the 16 taps of a lane's 4 pixels in the staged box and their
+// 16 weights, and the staging geometry are formed ONCE; then the block walks the channels in groups of 4 -- one 16-byte LDS slot
+// per source pixel -- as a pipeline ALONG C: the staging loads of group g + 1 fly while group g is gathered and stored.  Per group a
+// lane issues its staging loads, 16 ds_read_b128, 32 packed FMAs and 4 stores -- no coordinate, no address arithmetic.  With the
+// valid area wanted (VALID) the first group is channels 0 .. 2 plus the target mask as its fourth plane, and writes the mask.
+// (Groups of 3 as separate launches re-read the flow and its mask and redid every coordinate per group: 9 B/px + ~100 VALU per pixel
+// of pure repetition, +37 % traffic at C = 64.)  A channel count that is not a multiple of 4 makes the LAST group start at C - 4: it
+// recomputes up to three planes (identical values, duplicate stores).  The first pipelined group is peeled so that, at the loop
+// head, the staged group is 4 stores old on BOTH incoming paths: the compiler's vmcnt wait for it then leaves the previous group's
+// stores in flight (see lds_store).  Same expressions, same FMA chain as lds_gather_impl: bit-identical to the launches of 3.
+template <typename WP>
+__device__ __forceinline__ void lds_taps(const WP& p, const LdsCoords& T, const LdsBox& B, int (&si)[16], float (&wg)[16]) {
+    const int w = p.w, h = p.h;
+    const int cw16 = B.cw * 16, P16 = B.Pp * 16;
+    const float wf = (float)w, hf = (float)h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float fx = floorf(T.sx[k]), fy = floorf(T.sy[k]);
+        const float ww = T.sx[k] - fx, e = 1.0f - ww, nn = T.sy[k] - fy, s_ = 1.0f - nn;
+        wg[4 * k + 0] = s_ * e; wg[4 * k + 1] = s_ * ww; wg[4 * k + 2] = nn * e; wg[4 * k + 3] = nn * ww;
+        const int xi = (int)__builtin_amdgcn_fmed3f(fx, -2.0f, wf), yi = (int)__builtin_amdgcn_fmed3f(fy, -2.0f, hf);
+        const bool x0 = (uint32_t)xi < (uint32_t)w, x1 = (uint32_t)(xi + 1) < (uint32_t)w;
+        const bool y0 = (uint32_t)yi < (uint32_t)h, y1 = (uint32_t)(yi + 1) < (uint32_t)h;
+        const int yr = yi - B.miny;
+        const int ra = yr - lds_shear(xi >> 2, B.sq), rb = yr - lds_shear((xi + 1) >> 2, B.sq);
+        const int xl0 = xi - B.bx0, xl1 = xl0 + 1;
+        const int cp0 = __mul24(xl0 & 3, cw16) + ((xl0 & ~3) << 2), cp1 = __mul24(xl1 & 3, cw16) + ((xl1 & ~3) << 2);
+        const int r0 = 16 + __mul24(ra, P16), r1 = 16 + __mul24(rb, P16);
+        si[4 * k + 0] = (x0 && y0) ? r0 + cp0 : 0; si[4 * k + 1] = (x1 && y0) ? r1 + cp1 : 0;
+        si[4 * k + 2] = (x0 && y1) ? r0 + P16 + cp0 : 0; si[4 * k + 3] = (x1 && y1) ? r1 + P16 + cp1 : 0;
+    }
+}
+
+// A tile whose box does not fit the LDS even in part (fewer than OFL_WARP_CLIP rows of it would: an extreme stretch): every group
+// gathers from global memory with the arithmetic of lds_gather_impl.  A real call: cold, its registers must not weigh on the pipeline's.
+template <bool VALID>
+__device__ __attribute__((noinline)) void chan_tile_from_global(WarpParamsK* pp, LdsCoords Tc, int tx, int ty, int n, uint32_t fmk) {
+#define p (*pp)
+    const int C = p.c;
+    const uint32_t hw = (uint32_t)(p.h * p.w);
+    const float* __restrict__ sb0 = p.src + n * p.src_bs;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    LdsBox Bx = {};
+    Bx.fits = false; Bx.interior = false; Bx.clipped = false;
+    int g = 0;
+    if (VALID) {
+        f4 outv[4];
+        const f4 none[3] = {};
+        lds_gather_impl<3, true, false>(p, hw, sb0, sm, Tc, Bx, nullptr, outv);
+        lds_store<3, true, false>(p, tx, ty, n, hw, fmk, outv, none);
+        g = 3;
+    }
+    const f4 none4[4] = {};
+    for (bool last = false; !last; g += 4) {
+        const int mine = min(g, C - 4);
+        last = g + 4 >= C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(Tc.sx[k])); asm volatile("" : "+v"(Tc.sy[k])); }   // (nothing hoisted out of the loop)
+        f4 outv[4];
+        lds_gather_impl<4, false, false>(p, hw, sb0 + (int64_t)mine * hw, nullptr, Tc, Bx, nullptr, outv);
+        lds_store<4, false, false>(p, tx, ty, n, hw, 0u, outv, none4, nullptr, (int64_t)mine * hw);
+    }
+#undef p
+}
+
+// OVERSIZE box staged in part (lds_coords_box<.., CLIP>: the rows that fit): the pixels of this lane with a tap below the staged rows
+// (bit k of `below`) take their 4 planes from global memory instead -- flow re-read (an L2 hit), coordinates re-formed, the
+// arithmetic of lds_gather_impl -- so that nothing of it is kept in registers across the channel loop.  Cold (a wave with no such
+// lane skips it), and a real call for the same reason as above.
+struct Out4 { f4 v[4]; };
+template <int NCH, bool MASK3>
+__device__ __attribute__((noinline)) Out4 chan_pixels_from_global(WarpParamsK* pp, const float* sb, uint32_t pix, uint32_t below, Out4 cur) {
+#define p (*pp)
+    const int w = p.w, h = p.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    int tx, ty, n;
+    decode_tile(p, tx, ty, n);
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    const f4 uu = ld4nt(fu + pix), vv = ld4nt(fu + hw + pix);
+    LdsCoords Tc;
+    int dummy[1][4];
+    lds_coords_box_a<false>(p, tx, ty, uu, vv, 0, Tc, dummy);
+    LdsBox Bx = {};
+    Bx.fits = false; Bx.interior = false; Bx.clipped = false;
+    f4 got[4];
+    lds_gather_impl<NCH, MASK3, false>(p, hw, sb, MASK3 ? sm : nullptr, Tc, Bx, nullptr, got);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((below >> k) & 1u) cur.v[k] = got[k];
+    return cur;
+#undef p
+}
+
+template <bool VALID>
+__global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const WarpParams p_by_value) {
+    WarpParamsK* pp = (WarpParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*pp)
+    constexpr int NW = kLdsNT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int red[NW][4];
+    int tx, ty, n;
+    if (!decode_tile(p, tx, ty, n)) return;
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h, C = p.c;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const float* __restrict__ sb0 = p.src + n * p.src_bs;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
+    const int x4 = tx * (kLdsTWQ * 4) + lx * 4, xq = min(x4, w - 4);
+    uint32_t pix = (uint32_t)(min(ty * kLdsTH + ly, h - 1) * w + xq);
+    const f4 uu = ld4nt(fu + pix), vv = ld4nt(fu + hw + pix);
+    uint32_t fmk = 0x01010101u;
+    if ((VALID || p.flow_flags) && fm) fmk = ld32(fm + pix);
+    if (p.flow_flags) {                      // finiteness / zero tests of the flow operand as a by-product (wave-uniform branch)
+        int f = 0;
+        if ((x4 < w) && (ty * kLdsTH + ly < h)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f |= flag_bits(uu[q], vv[q], ((fmk >> (8 * q)) & 0xffu) != 0u);
+        }
+        f = wave_or_flags(f);
+        if ((tid & 63) == 0) flag_or(&p.flow_flags[n], f);
+    }
+    f4* lds = reinterpret_cast<f4*>(smem);
+    LdsCoords Tc;
+    LdsBox Bx;
+    const int sq = p.shear ? lds_slope_row(p, fu, hw, tx, ty * kLdsTH + kLdsTH / 2) : 0;
+    lds_coords_box<true, true>(p, tx, ty, uu, vv, sq, Tc, Bx, red);
+    if (__builtin_expect(!Bx.fits, 0)) {     // (block-uniform, cold)
+        chan_tile_from_global<VALID>(pp, Tc, tx, ty, n, fmk);
+        return;
+    }
+    // --- per-tile invariants: taps, weights, staging geometry -------------------------------------------------------------
+    int si[16];
+    float wg[16];
+    uint32_t below = 0u;                                     // pixels of this lane with a tap below the staged rows of a clipped box
+    lds_taps(p, Tc, Bx, si, wg);
+    if (__builtin_expect(Bx.clipped, 0)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                        // (lds_gather_impl's test, on the row of the lower taps)
+            const int xi = (int)__builtin_amdgcn_fmed3f(floorf(Tc.sx[k]), -2.0f, (float)w), yi = (int)__builtin_amdgcn_fmed3f(floorf(Tc.sy[k]), -2.0f, (float)h);
+            const int yr = yi - Bx.miny;
+            const int ra = yr - lds_shear(xi >> 2, Bx.sq), rb = yr - lds_shear((xi + 1) >> 2, Bx.sq);
+            if (!(max(ra, rb) + 1 < Bx.bh)) {
+                below |= 1u << k;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) si[4 * k + j] = 0;   // (its LDS reads go to the zero slot; the result is replaced)
+            }
+        }
+    }
+    const bool any_below = Bx.clipped && __any(below != 0u);  // wave-uniform
+    const int rounds = (Bx.nch + kLdsNT - 1) / kLdsNT;       // 1 .. kLdsIters, block-uniform
+    uint32_t goff[kLdsIters];                                // (widths that are multiples of 4 only: no chunk straddles a row end)
+    int slot[kLdsIters];
+    {
+        const uint32_t inv = inv20((uint32_t)Bx.cw);
+#pragma unroll
+        for (int it = 0; it < kLdsIters; ++it) {             // (lds_issue's arithmetic)
+            const uint32_t i = (uint32_t)tid + it * kLdsNT;
+            const uint32_t r = __umul24(i, inv) >> 20, c4 = i - __umul24(r, (uint32_t)Bx.cw);
+            const int y = Bx.miny + (int)r + lds_shear(Bx.cbase + (int)c4, Bx.sq);
+            const bool on = (i < (uint32_t)Bx.nch) && ((uint32_t)y < (uint32_t)h) && it < rounds;
+            goff[it] = on ? (uint32_t)(__mul24(y, w) + Bx.bx0) + c4 * 4u : 0u;
+            slot[it] = on ? 16 * (1 + (int)(__umul24(r, (uint32_t)Bx.Pp) + c4)) : -1;      // byte address of the chunk's first slot
+        }
+    }
+    const int cw16 = Bx.cw * 16;
+    // nothing above is to be recomputed, and nothing else hoisted, inside the channel loop
+    uint32_t sp[8];                                          // two 16-bit LDS byte addresses per register
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sp[i] = (uint32_t)si[2 * i] | ((uint32_t)si[2 * i + 1] << 16);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(sp[i]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(wg[i]));
+#pragma unroll
+    for (int it = 0; it < kLdsIters; ++it) { asm volatile("" : "+v"(goff[it])); asm volatile("" : "+v"(slot[it])); }
+    asm volatile("" : "+v"(pix));
+
+    f4 q[kLdsIters][4];                                      // the staged group: [round][plane] = 4 pixels of one plane
+    // staging loads of the 4 planes at `sb` (mask3: the fourth plane is the target mask's bytes, as 0 / 1 floats)
+    auto issue = [&](const float* __restrict__ sb, bool mask3) {
+#pragma unroll
+        for (int it = 0; it < kLdsIters; ++it) {
+            if (it == 0 || it < rounds) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[it][c] = ld4(sb + c * hw + goff[it]);
+                if (VALID && mask3) {
+                    const uint32_t mb = sm ? ld32(sm + goff[it]) : 0x01010101u;
+                    q[it][3] = (f4){fminf((float)(mb & 0xffu), 1.0f), fminf((float)((mb >> 8) & 0xffu), 1.0f),
+                                    fminf((float)((mb >> 16) & 0xffu), 1.0f), fminf((float)(mb >> 24), 1.0f)};
+                } else q[it][3] = ld4(sb + 3 * hw + goff[it]);
+            }
+        }
+    };
+    auto publish = [&]() {                                   // registers -> interleaved LDS slots (lds_write's layout)
+        if (tid == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < kLdsIters; ++it) {
+            if (slot[it] >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<f4*>(smem + slot[it] + k * cw16) = (f4){q[it][0][k], q[it][1][k], q[it][2][k], q[it][3][k]};
+            }
+        }
+        lds_barrier();
+    };
+    auto gather = [&](f4 (&outv)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f4 tv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + ((j & 1) ? (sp[2 * k + (j >> 1)] >> 16) : (sp[2 * k + (j >> 1)] & 0xffffu)));
+            f4 r = tv[0] * wg[4 * k];
+            r = __builtin_elementwise_fma(tv[1], (f4){wg[4 * k + 1], wg[4 * k + 1], wg[4 * k + 1], wg[4 * k + 1]}, r);
+            r = __builtin_elementwise_fma(tv[2], (f4){wg[4 * k + 2], wg[4 * k + 2], wg[4 * k + 2], wg[4 * k + 2]}, r);
+            r = __builtin_elementwise_fma(tv[3], (f4){wg[4 * k + 3], wg[4 * k + 3], wg[4 * k + 3], wg[4 * k + 3]}, r);
+            outv[k] = r;
+        }
+    };
+    float* __restrict__ db = p.dst + (int64_t)n * p.dst_bs;
+    auto store = [&](const f4 (&outv)[4], int first, int planes) {   // planes `first` .. of dst (unconditional: see lds_store)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < planes) {
+                f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
+                if (p.round_mode != OFL_ROUND_NONE) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], p.round_mode);
+                }
+                st4o(db + (int64_t)(first + c) * hw + pix, o);
+            }
+        }
+    };
+    int g = 0;                               // first channel the groups of 4 have still to do
+    if (VALID) {
+        issue(sb0, true);
+        publish();
+        f4 outv[4];
+        gather(outv);
+        if (__builtin_expect(any_below, 0)) {
+            if (below != 0u) {
+                const Out4 fixed = chan_pixels_from_global<3, true>(pp, sb0, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
+#pragma unroll
+                for (int k = 0; k < 4; ++k) outv[k] = fixed.v[k];
+            }
+        }
+        uint32_t vo = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vo |= (uint32_t)((outv[k][3] > kValidThr) && (((fmk >> (8 * k)) & 0xffu) != 0u)) << (8 * k);
+        st32o(p.valid + (int64_t)n * hw + pix, vo);
+        store(outv, 0, 3);
+        lds_barrier();
+        g = 3;
+    }
+    const int groups = (C - g + 3) >> 2;     // >= 1 (the host sends C >= 4)
+    int cur = min(g, C - 4);
+    issue(sb0 + (int64_t)cur * hw, false);
+    auto group = [&](bool next) {            // publish the staged group, start the next one's loads, gather, store
+        publish();
+        const int mine = cur;
+        if (next) {
+            g += 4;
+            cur = min(g, C - 4);
+            issue(sb0 + (int64_t)cur * hw, false);
+        }
+        f4 outv[4];
+        gather(outv);
+        if (__builtin_expect(any_below, 0)) {
+            if (below != 0u) {
+                const Out4 fixed = chan_pixels_from_global<4, false>(pp, sb0 + (int64_t)mine * hw, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
+#pragma unroll
+                for (int k = 0; k < 4; ++k) outv[k] = fixed.v[k];
+            }
+        }
+        store(outv, mine, 4);
+        if (next) lds_barrier();
+    };
+    if (groups > 1) {
+        group(true);                                           // (peeled: see above)
+        for (int k = 1; k + 1 < groups; ++k) group(true);
+    }
+    group(false);
+#undef p
 }
 
 // CT = compile-time channel count (0: run-time p.c)
@@ -2573,8 +2867,17 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void*
 #undef OFL_WIDE_CASE
     return (int)hipGetLastError();
 }
+
+int ofl_wide_launch_chan(const void* params, int valid, void* stream) {
+    WarpParams q = *static_cast<const WarpParams*>(params);
+    q.lds_bytes = kLdsBytes;
+    const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
+    if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+    return (int)hipGetLastError();
+}
 #else
-int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests)
+int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests), 5 = auto but more than 3 channels as separate launches of 3 (tests: the channel-loop kernel against them)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
@@ -2779,7 +3082,7 @@ extern "C" {
 __attribute__((visibility("default"))) int ofl_version(void) { return 29; }   // 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
-    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 4) { g_warp_path = value; return OFL_OK; }
+    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 5) { g_warp_path = value; return OFL_OK; }
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }
@@ -2836,7 +3139,17 @@ static int warp_bwd_impl(
         }
         p.dst_flags = dst_flags;                                             // a by-product of the staged kernel (c == 2: one group)
         const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
-        // more than 3 channels: groups of 3 (the staged box holds 3 channels + the mask channel); the valid mask and the
+        // more than 3 channels of a plain warp: ONE launch that walks the channels inside the block (warp_bwd_lds_chan_kernel)
+        // (with the valid area wanted the first group is 3 channels + the mask plane: below 7 channels two launches of 3 are as good or better)
+        if (OFL_WARP_CHAN && c >= (valid ? 7 : 4) && (w & 3) == 0 && !addend && !src_b && !dst_flags && g_warp_path != 5) {
+            WarpParams q = p;
+            const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
+            if (OFL_WARP_CHAN_WIDE && g1 >= 2 * 6912u) return ofl_wide_launch_chan(&p, p.valid ? 1 : 0, (void*)st);
+            if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+            else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+            return (int)hipGetLastError();
+        }
+        // otherwise groups of 3 (the staged box holds 3 channels + the mask channel); the valid mask and the
         // flow flags come out of the first group
         for (int32_t c0 = 0; c0 < c; c0 += 3) {
             const int32_t nc = (c - c0) < 3 ? (c - c0) : 3;

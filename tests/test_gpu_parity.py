@@ -206,7 +206,8 @@ def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, frame, dev):
 
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260),
                                    (2, 3, 37, 50), (2, 2, 33, 47), (1, 1, 19, 6), (1, 3, 70, 129), (2, 2, 40, 5),    # widths that are not multiples of 4
-                                   (2, 4, 40, 64), (1, 7, 33, 45), (2, 6, 20, 36)])                               # more than 3 channels: groups of 3
+                                   (2, 4, 40, 64), (1, 7, 33, 45), (2, 6, 20, 36),                               # more than 3 channels: the channel-loop kernel (W % 4 == 0) / groups of 3
+                                   (1, 5, 64, 96), (2, 9, 70, 128), (1, 16, 130, 260), (1, 64, 48, 64)])
 @pytest.mark.parametrize("sigma", [0.0005, 3.0, 40.0])
 def test_lds_and_generic_paths_agree(shape, sigma, dev):
     import sys
@@ -225,7 +226,9 @@ def test_lds_and_generic_paths_agree(shape, sigma, dev):
                dict(flow_sign=-1.0, src_mask=sm, want_valid=True, addend=add, a_sign=1.0, g_sign=-1.0),
                dict(round_mode=2), dict(flow_mask=fmk, want_valid=True, want_flags=True, want_src_flags=(c == 2))):
         outs = []
-        for path in (0, 1, 3, 4):               # auto, generic, staged two tiles per block, staged one tile per block
+        for path in (0, 1, 3, 4, 5):            # auto, generic, staged two tiles per block, staged one tile per block, > 3 channels as launches of 3
+            if path == 5 and c <= 3:
+                continue
             _native.set_warp_path(path)
             try:
                 outs.append(_native.warp_bwd(flow, src, **kw))
