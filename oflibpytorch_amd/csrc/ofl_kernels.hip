@@ -249,6 +249,9 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_WARP_REUSE
+#define OFL_WARP_REUSE 1
+#endif
 #ifndef OFL_WARP_CHAN
 #define OFL_WARP_CHAN 1
 #endif
@@ -816,8 +819,13 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
 // pixels with the same registers and the same LDS -- flow two tiles ahead, staging loads one tile ahead, stores behind.
 // GRAD: the same column pipeline computing the gradient with respect to the flow (`addend` = the upstream gradient [N,NC,H,W],
 // `dst` = [N,2,H,W]; see lds_gather_impl) -- the forward's staged boxes instead of 4 * NC scalar gathers per pixel.
-template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false>
+// REUSE (the fused composition proper: ADD with the addend being the flow operand itself, 2 channels): the flow registers of a tile
+// ARE its addend and stay live until its store, so the tile's sample positions are not kept from the box phase to the gather (8
+// VGPRs per tile, two tiles live) but re-formed from those registers at gather time -- ~40 VALU per tile for the ~16 registers that
+// were the kernel's scratch traffic.
+template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false, bool REUSE = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p_by_value) {
+    static_assert(!REUSE || (ADD && NC == 2 && !GRAD), "REUSE: the fused composition");
 #if OFL_WARP_KARG
     // parameters through the kernarg segment (see OFL_OPAQUE_S at the gather splat): the ~250 bytes of WarpParams are not
     // held in SGPRs (and spilled to VGPR lanes) across the whole column, each phase s_loads what it needs
@@ -865,7 +873,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     load_flow(0);
     if (T > 1) load_flow(1);
     f4* lds = reinterpret_cast<f4*>(smem);
-    LdsCoords Tc[T];
+    LdsCoords Tc[REUSE ? 1 : T];
     LdsBox Bx[T];
     LdsStage<NC> S;
     // the shear slope is estimated per tile (a column is too tall for one estimate); all of them up front: the scalar loads
@@ -880,7 +888,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     // loads / this tile's stores, so that waiting for it never waits for them
     // (flows only: with three channels the extra registers would spill, and nothing on the host adds to an image)
     constexpr bool EARLY = ADD && NC <= 2;
-    const bool reuse = EARLY && NC == 2 && p.add_is_flow;                 // block-uniform
+    const bool reuse = REUSE || (EARLY && NC == 2 && p.add_is_flow);      // block-uniform
     int dflags = 0;
 #pragma unroll
     for (int k = 0; k < T; ++k) {
@@ -891,15 +899,15 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         // the last row of groups.  No run-time branch round the staging loads or the stores is left, so the compiler counts
         // every one of them in its vmcnt waits (see lds_store).
         // (not with the ADD epilogue: its re-used flow registers leave no room for the longer live ranges -- 36 B of scratch, -13 %)
-        const bool more = (k + 1 < T) && ((OFL_WARP_ALWAYS_T && !ADD) || (tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
+        const bool more = (k + 1 < T) && ((OFL_WARP_ALWAYS_T && (!ADD || (REUSE && OFL_WARP_ALWAYS_T >= 2))) || (tyk + 1) * kLdsTH < h);        // block-uniform: a tile follows
         LdsBoxWords wn = {0, 0};
         if (k + 1 < T) {
             // ... while the next tile's coordinates are computed (OFL_WARP_MERGE_BARRIER: the block-wide half of its box behind the
             // barrier that publishes this tile's staged box -- one barrier per tile fewer)
 #if OFL_WARP_MERGE_BARRIER
-            if (more) { note_flags(k + 1); wn = lds_coords_box_a(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], red[(k + 1) & 1]); }
+            if (more) { note_flags(k + 1); wn = lds_coords_box_a(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[REUSE ? 0 : k + 1], red[(k + 1) & 1]); }
 #else
-            if (more) { note_flags(k + 1); lds_coords_box<true, kClip>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[k + 1], Bx[k + 1], red[(k + 1) & 1]); }
+            if (more) { note_flags(k + 1); lds_coords_box<true, kClip>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], sq[k + 1], Tc[REUSE ? 0 : k + 1], Bx[k + 1], red[(k + 1) & 1]); }
 #endif
         }
         if (k + 2 < T) load_flow(k + 2);
@@ -914,7 +922,8 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         if (k + 1 < T) {
             if (more) lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[k + 1], S, sbb);   // the next tile's staging loads fly while this one is gathered and stored
         }
-        lds_gather<NC, VALID, SUB, TS, GRAD, kClip>(p, hw, sb, sm, Tc[k], Bx[k], smem, outv, sbb, ad);
+        if (REUSE) lds_coords_box_a<false>(p, tx, tyk, uu[k], vv[k], 0, Tc[0], red[0]);   // (the positions again, from the registers that are the addend)
+        lds_gather<NC, VALID, SUB, TS, GRAD, kClip>(p, hw, sb, sm, Tc[REUSE ? 0 : k], Bx[k], smem, outv, sbb, ad);
         if (GRAD) {
             const f4 none[2] = {};
             lds_store<2, false, false, false, float>(p, tx, tyk, n, hw, 0u, outv, none);
@@ -2850,6 +2859,11 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void*
     hipStream_t st = (hipStream_t)stream;
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
 #if OFL_WARP_COL_ADD >= 2
+    if (add && OFL_WARP_REUSE && q.add_is_flow) {
+        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        return (int)hipGetLastError();
+    }
     if (add) {                                     // (the fused composition: 2 channels)
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
@@ -2899,6 +2913,11 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         WarpParams q = p;
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
         if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, (void*)st);
+        if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
+            if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            return (int)hipGetLastError();
+        }
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
