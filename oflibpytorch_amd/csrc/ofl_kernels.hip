@@ -737,7 +737,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
     int tx, ty2, n;                      // the grid counts tile PAIRS: tiles_y = ceil(h / (2 * kLdsTH))
     if (!decode_tile(p, tx, ty2, n)) return;
     const int tyA = 2 * ty2, tyB = tyA + 1;
-    const bool haveB = tyB * kLdsTH < p.h;
+    // (OFL_WARP_ALWAYS_T: the second tile is run whatever the frame's height -- past the bottom edge it recomputes and re-stores the
+    // last row, see the column kernel -- so that its staging loads and both tiles' stores are straight-line code the compiler counts)
+    const bool haveB = OFL_WARP_ALWAYS_T || tyB * kLdsTH < p.h;
     const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
     const int w = p.w, h = p.h;
     const uint32_t hw = (uint32_t)(h * w);
@@ -1648,6 +1650,9 @@ __global__ __launch_bounds__(256) void splat_fallback_kernel(const SplatParams p
 //  subtiles spread over > 256 destination tiles takes the two-pass global-atomics path inside the same call, decided on
 //  the device, per image.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_SP_ISSUE_FIRST
+#define OFL_SP_ISSUE_FIRST 1
+#endif
 #ifndef OFL_SP_TW
 #define OFL_SP_TW 64    // width of a destination tile (32: 256-thread blocks, 4 per CU; 64: 512-thread blocks, 2 per CU -- fewer source pixels scanned per output pixel and half the per-tile prologues; round 3: 32 by 1 %, round 4 after the long cells left the critical path: 64 by 4 % at sigma 8, 30 % at B = 1)
 #endif
@@ -1763,6 +1768,55 @@ __device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy,
             if (edge) { a = rot4(a, 4 - wrem); b = rot4(b, 4 - wrem); wm4 >>= 8 * (4 - wrem); }
         }
     }
+    sp_finish_src(s, sx4, sy, inimg, a, b, wm4, q);
+}
+
+// The same in two halves, for the gather kernel's scan: _issue only LOADS (flow or positions, weight mask), _done rotates a row-end
+// group and forms the end points.  The scan issues the loads of BOTH half steps and of their data (sp_issue_data) before anything is
+// consumed: written as sp_load_src + sp_load_data the compiler waited for the flow before it issued the data loads -- the divergent
+// `if (inimg)` blocks keep it from moving loads across the first use -- and a step was THREE dependent round trips (list, flow,
+// data) instead of two (round 5: -8 % on apply 's', -9 % on switch_ref at sigma 8).
+struct SpRaw { f4 a, b; uint32_t wm4; int rot; };
+template <typename TF = float, typename SP>
+__device__ __forceinline__ void sp_issue_src(const SP& s, int n, int sx4, int sy, bool inimg, uint32_t pix, uint32_t hw, SpRaw& r) {
+    const TF* __restrict__ flw = reinterpret_cast<const TF*>(s.flow);
+    r.a = (f4){0.f, 0.f, 0.f, 0.f}; r.b = (f4){0.f, 0.f, 0.f, 0.f};
+    r.wm4 = 0x01010101u;
+    const int wrem = s.w & 3;
+    const bool edge = wrem != 0 && inimg && sx4 > s.w - 4;
+    const uint32_t pe = edge ? pix - (uint32_t)(4 - wrem) : pix;
+    r.rot = edge ? 4 - wrem : 0;
+    if (inimg && s.fw != 0) {
+        // padded apply: per-pixel loads with replicate addressing (not a hot path); the weight mask is False outside the window
+        const uint32_t fhw = (uint32_t)(s.fh * s.fw);
+        r.wm4 = 0u; r.rot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bool inside;
+            const uint32_t off = sp_win(s, min(sx4 + k, s.w - 1), sy, inside);
+            r.a[k] = ld1(flw + n * s.flow_bs + off); r.b[k] = ld1(flw + n * s.flow_bs + fhw + off);
+            const bool m = s.weight_mask ? (inside && s.weight_mask[n * s.weight_mask_bs + off] != 0) : true;
+            r.wm4 |= (uint32_t)m << (8 * k);
+        }
+    } else if (inimg) {
+        if (s.flow) {
+            r.a = ld4(flw + n * s.flow_bs + pe);
+            r.b = ld4(flw + n * s.flow_bs + hw + pe);
+        } else {
+            r.a = ld4(s.xs + n * s.xy_bs + pe);
+            r.b = ld4(s.ys + n * s.xy_bs + pe);
+        }
+        if (s.weight_mask) r.wm4 = ld32(s.weight_mask + n * s.weight_mask_bs + pe);
+    }
+}
+template <typename SP>
+__device__ __forceinline__ void sp_src_done(const SP& s, int sx4, int sy, bool inimg, SpRaw& r, SpSrc& q) {
+    // (locals, not in-place edits of `r`: the in-place form of sp_data_done's rotation was MISCOMPILED by ROCm 7.2 -- planes 1 and 2 of
+    // a row-end group came out unrotated; tests/test_gpu_parity.py::test_tiled_splat_matches_two_pass_and_oracle[0.0-shape4] caught it)
+    const int rot = ((s.w & 3) != 0) ? r.rot : 0;             // (block-uniform test first)
+    f4 a = r.a, b = r.b;
+    uint32_t wm4 = r.wm4;
+    if (rot != 0) { a = rot4(a, rot); b = rot4(b, rot); wm4 >>= 8 * rot; }
     sp_finish_src(s, sx4, sy, inimg, a, b, wm4, q);
 }
 
@@ -2206,6 +2260,54 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
     mc4 = nz_bytes(ma) & nz_bytes(mb);
 }
 
+// sp_load_data in two halves (see sp_issue_src): _issue only loads -- the data planes, the subtrahend planes of modes 1-2, the two
+// mask-channel operands --, _done rotates a row-end group, subtracts and forms the mask-channel bits.
+template <int NC> struct SpRawData { f4 dat[NC], sub[NC <= 2 ? NC : 1]; uint32_t ma, mb; int rot; };   // (only flows -- 2 channels -- have a subtrahend)
+template <int NC, bool MCH, typename TF = float, typename SP>
+__device__ __forceinline__ void sp_issue_data(const SP& s, int n, int sx4, int sy, uint32_t hw, SpRawData<NC>& r) {
+    const int w = s.w;
+    const TF* __restrict__ db = reinterpret_cast<const TF*>(s.data) + n * s.data_bs;
+    const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
+    const int wrem = w & 3;
+    const bool edge = wrem != 0 && sx4 > w - 4;                   // row-end group: last whole group, rotated
+    const uint32_t px = (uint32_t)(sy * w + sx4) - (edge ? (uint32_t)(4 - wrem) : 0u);
+    r.rot = edge ? 4 - wrem : 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) r.dat[c] = ld4(db + c * hw + px);
+    if (NC <= 2 && dbb) {                                          // (block-uniform)
+#pragma unroll
+        for (int c = 0; c < (NC <= 2 ? NC : 1); ++c) r.sub[c] = ld4(dbb + c * hw + px);
+    }
+    r.ma = 0x01010101u; r.mb = 0x01010101u;
+    if (MCH) {
+        if (s.chan_mask_a) r.ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + px);
+        if (s.fw != 0) {                                            // padded apply: chan_mask_b lives in the flow window, False outside
+            r.mb = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bool inside;
+                const uint32_t off = sp_win(s, min((int)(px % (uint32_t)w) + k, w - 1), sy, inside);
+                const bool m = inside && (s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + off] != 0 : true);
+                r.mb |= (uint32_t)m << (8 * k);
+            }
+        } else if (s.chan_mask_b) r.mb = ld32(s.chan_mask_b + n * s.chan_mask_b_bs + px);
+    }
+}
+template <int NC, typename SP>
+__device__ __forceinline__ void sp_data_done(const SP& s, SpRawData<NC>& r, f4 (&dat)[NC], uint32_t& mc4) {
+    const int rot = ((s.w & 3) != 0) ? r.rot : 0;             // (block-uniform test first: widths that are multiples of 4 skip it all)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        f4 v = r.dat[c];
+        if (NC <= 2 && s.data_b) v = v - r.sub[NC <= 2 ? c : 0];
+        if (rot != 0) v = rot4(v, rot);
+        dat[c] = v;
+    }
+    uint32_t ma = r.ma, mb = r.mb;
+    if (rot != 0) { ma >>= 8 * rot; mb >>= 8 * rot; }
+    mc4 = nz_bytes(ma) & nz_bytes(mb);
+}
+
 template <int NC, bool MCH, typename TF, typename TO, typename GP, typename SP>
 __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float* acc, const uint32_t* __restrict__ lst, int nlist,
                                                 const SpTile& t, int n);
@@ -2334,6 +2436,32 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             int sx4[2], sy[2];
             bool inb[2];
             const bool two = base + kHalf < nlist;             // block-uniform: the second half step has entries
+#if OFL_SP_ISSUE_FIRST
+            // per half step: EVERY load first -- flow / positions, weight mask, data, mask-channel operands -- and only then the
+            // end points: one round trip instead of two (see sp_issue_src).  (Both half steps' loads at once would be one
+            // round trip for the rare tile with more than 64 listed subtiles too, but 70 live registers more: scratch.)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) continue;
+                const int e = base + u * kHalf + tid / kSubLanes;
+                const bool have = e < nlist;
+                const uint32_t sub = base == 0 ? pre[u] : (have ? lst[e] : 0u);
+                const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
+                sx4[u] = (int)subx * kSubW + sc4 * 4; sy[u] = (int)suby * kSubH + srow;
+                inb[u] = have && (sx4[u] < w) && (sy[u] < h);
+                SpRaw raw_src;
+                SpRawData<NC> raw_dat;
+                sp_issue_src<TF>(s, n, sx4[u], sy[u], inb[u], (uint32_t)(sy[u] * w + sx4[u]), hw, raw_src);
+                if (inb[u]) sp_issue_data<NC, MCH, TF>(s, n, sx4[u], sy[u], hw, raw_dat);
+                f4 dat[NC];
+                uint32_t mc4 = 0x01010101u;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dat[c] = (f4){0.f, 0.f, 0.f, 0.f};
+                sp_src_done(s, sx4[u], sy[u], inb[u], raw_src, q[u]);
+                if (inb[u]) sp_data_done<NC>(s, raw_dat, dat, mc4);
+                process(q[u], sx4[u], sy[u], dat, mc4, r0, r1);
+            }
+#else
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u == 1 && !two) { inb[1] = false; sx4[1] = sy[1] = 0; continue; }
@@ -2356,6 +2484,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
             }
             process(q[0], sx4[0], sy[0], dat[0], mc4[0], r0, r1);
             if (two) process(q[1], sx4[1], sy[1], dat[1], mc4[1], r0, r1);
+#endif
         }
     };
     using std::integral_constant;
