@@ -471,7 +471,7 @@ def main():
     if rank == 0:
         traffic_source = "--traffic-bytes" if args.traffic_bytes is not None else None
         if args.traffic_bytes is None and not args.shared_image and (n, h, w) == (64, 1080, 1920):
-            for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # PMC passes are separate runs (tools/refresh_profiles_r4.sh)
+            for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # PMC passes are separate runs (tools/refresh_profiles_r5.sh)
                 tj = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tj):
                     with open(tj) as fh:

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Copy the summaries of gpurun_out/r5final/ (tools/refresh_profiles_r5.sh, run on the GPU box) into profiles/r5_* and derive
+profiles/r5_traffic.json (HBM bytes per launch of the dominant kernel: 2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md gfx950
+correction) from the two PMC passes."""
+import json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r5final")
+DST = os.path.join(ROOT, "profiles")
+names = {"bench.json": "r5_bench.json", "bench_kernel_stats.csv": "r5_bench_kernel_stats.csv", "bench_pmc_summary.txt": "r5_bench_pmc_summary.txt",
+         "bench_ops.txt": "r5_bench_ops_B16.txt", "ops_kernel_stats.csv": "r5_bench_ops_kernel_stats.csv", "bench_grad.txt": "r5_bench_grad_B16.txt",
+         "splat_pmc_summary.txt": "r5_splat_gather_pmc_summary.txt",
+         "sigma_sweep.txt": "r5_sigma_sweep.txt", "bench_chan.txt": "r5_bench_chan.txt", "flags.txt": "r5_validation_wait.txt", "timeline.txt": "r5_step_timeline.txt"}
+for a, b in names.items():
+    p = os.path.join(SRC, a)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(DST, b))
+        print("profiles/" + b)
+summ = os.path.join(SRC, "bench_pmc_summary.txt")
+if os.path.exists(summ):
+    text = open(summ).read()
+    best = None
+    for block in re.split(r"\n(?=\S)", text):
+        if "warp_bwd_lds_column_kernel<4, 3, true, false" in block:
+            f = re.search(r"FETCH_SIZE\s+mean=([0-9.e+]+)", block)
+            w = re.search(r"WRITE_SIZE\s+mean=([0-9.e+]+)", block)
+            if f and w:
+                best = (float(f.group(1)), float(w.group(1)))
+    if best:
+        fetch_kib, write_kib = best
+        out = {"kernel": "warp_bwd_lds_column_kernel<4, 3, true, false, false, false, float, float, false>",
+               "workload": "B=64 1080x1920 Flow.apply 't' C=3 + valid", "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+               "fetch_correction": 2.0, "traffic_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024,
+               "algorithmic_bytes_per_launch": 35 * 64 * 1080 * 1920,
+               "source": "profiles/r5_bench_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, same bench command, "
+                         "tools/refresh_profiles_r5.sh; gfx950: FETCH_SIZE tallies 64 B per 128-B request for 16 B/lane streams -> doubled)"}
+        json.dump(out, open(os.path.join(DST, "r5_traffic.json"), "w"), indent=1)
+        print("profiles/r5_traffic.json", out["traffic_bytes_per_launch"] / out["algorithmic_bytes_per_launch"])

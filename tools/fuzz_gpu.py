@@ -142,7 +142,7 @@ def main():
     t0 = time.time()
     nw = ns = nx = 0
     while time.time() - t0 < a.seconds:
-        n, c = int(rng.integers(1, 4)), int(rng.integers(1, 8))
+        n, c = int(rng.integers(1, 4)), (int(rng.integers(1, 8)) if rng.random() < 0.8 else int(rng.integers(8, 20)))   # (C >= 4, W % 4 == 0, no addend: the channel-loop kernel)
         h, w = (int(rng.integers(200, 1100)), int(rng.integers(300, 2000))) if a.big else (int(rng.integers(2, 180)), int(rng.integers(4, 300)))
         if a.big:
             n, c = int(rng.integers(1, 3)), int(rng.integers(1, 5))
