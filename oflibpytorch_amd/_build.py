@@ -34,12 +34,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP kernels + C ABI into oflibpytorch_amd/libofl_hip.so (cross-compiles without a GPU)."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc_path()] + HIPCC_FLAGS + ["-I", os.path.join(_ROOT, "include"), "-o", LIB_PATH] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("oflibpytorch_amd: hipcc failed\n" + res.stdout + res.stderr)
+    # the three translation units are compiled side by side (ofl_kernels.hip alone is ~80 s of device code generation: the splat
+    # gather kernel has 16 instantiations), then linked
+    import tempfile
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="ofl_build_") as tmp:
+        objs, procs = [], []
+        for src in SOURCES:
+            obj = os.path.join(tmp, os.path.splitext(os.path.basename(src))[0] + ".o")
+            cmd = [hipcc_path()] + compile_flags + ["-I", os.path.join(_ROOT, "include"), "-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            objs.append(obj)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        for src, pr in procs:
+            out, err = pr.communicate()
+            if pr.returncode != 0:
+                raise RuntimeError("oflibpytorch_amd: hipcc failed on %s\n%s%s" % (src, out, err))
+        link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(link))
+        res = subprocess.run(link, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("oflibpytorch_amd: hipcc (link) failed\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 

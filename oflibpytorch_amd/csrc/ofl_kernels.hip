@@ -1379,7 +1379,19 @@ struct SplatParams {
     int32_t fb_round, fb_slots;  // (with run_if_set) the accumulator holds fb_slots images: this launch serves the flagged images ranked [fb_round * fb_slots, (fb_round + 1) * fb_slots) among the flagged ones, image of rank r in slot r % fb_slots
     int32_t* dst_flags;          // optional int32[N] (2-channel data only): flag word of the OUTPUT read as a flow under `valid`
     int32_t raw;                 // 1: the weighted sums themselves, not divided by the density (ofl_splat_sum_f32: the transpose of the backward warp)
+    static constexpr bool kLean = false;
 };
+// The COMMON CASE as a type: the same bytes read as SplatParamsLean promise the gather path that the call has a flow (not positions),
+// no flow window, a width that is a multiple of 4, no rounding and no raw sums -- `SP::kLean` folds those run-time switches (and the
+// scalar loads, compares and branches they cost per use) out of the lean instantiations of the bin and gather kernels.  The host
+// picks them when the promises hold (splat_tiled_impl): apply 's' -6.5 %, switch_ref -8.7 % (profiles/r5_splat_lean.txt).
+struct SplatParamsLean : SplatParams { static constexpr bool kLean = true; };
+// the switches, as the kernels' helpers read them (s: a SplatParams or SplatParamsLean, in any address space)
+#define OFL_SP_WINDOW(s_) (!std::remove_reference<decltype(s_)>::type::kLean && (s_).fw != 0)
+#define OFL_SP_WREM(s_) (std::remove_reference<decltype(s_)>::type::kLean ? 0 : ((s_).w & 3))
+#define OFL_SP_HAS_FLOW(s_) (std::remove_reference<decltype(s_)>::type::kLean || (s_).flow != nullptr)
+#define OFL_SP_RAW(s_) (!std::remove_reference<decltype(s_)>::type::kLean && (s_).raw != 0)
+#define OFL_SP_ROUND(s_) (std::remove_reference<decltype(s_)>::type::kLean ? (int32_t)OFL_ROUND_NONE : (s_).round_mode)
 
 // flow window (padded apply): offset of frame pixel (x, y) in a flow-geometry plane (clamped: replicate) and whether it is inside
 template <typename SP>
@@ -1650,6 +1662,9 @@ __global__ __launch_bounds__(256) void splat_fallback_kernel(const SplatParams p
 //  subtiles spread over > 256 destination tiles takes the two-pass global-atomics path inside the same call, decided on
 //  the device, per image.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_SP_LEAN
+#define OFL_SP_LEAN 1
+#endif
 #ifndef OFL_SP_ISSUE_FIRST
 #define OFL_SP_ISSUE_FIRST 1
 #endif
@@ -1720,7 +1735,7 @@ __device__ __forceinline__ void sp_finish_src(const SP& s, int sx4, int sy, bool
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         bool zero = false;
-        if (s.flow) {
+        if (OFL_SP_HAS_FLOW(s)) {
             // get_flow_endpoints utils.py:1056-1057.  flow_sign is +1 or -1: the product is exact, so ONE fma rounds exactly
             // as the reference's add does (the entry points reject any other sign)
             q.x[k] = __builtin_fmaf(s.flow_sign, a[k], (float)(sx4 + k));
@@ -1740,10 +1755,10 @@ __device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy,
     f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     uint32_t wm4 = 0x01010101u;
     // the last group of a row of an image whose width is not a multiple of 4: fetch the last whole group and rotate
-    const int wrem = s.w & 3;
+    const int wrem = OFL_SP_WREM(s);
     const bool edge = wrem != 0 && inimg && sx4 > s.w - 4;
     const uint32_t pe = edge ? pix - (uint32_t)(4 - wrem) : pix;
-    if (inimg && s.fw != 0) {
+    if (inimg && OFL_SP_WINDOW(s)) {
         // padded apply: per-pixel loads with replicate addressing (not a hot path); the weight mask is False outside the window
         const uint32_t fhw = (uint32_t)(s.fh * s.fw);
         wm4 = 0u;
@@ -1756,7 +1771,7 @@ __device__ __forceinline__ void sp_load_src(const SP& s, int n, int sx4, int sy,
             wm4 |= (uint32_t)m << (8 * k);
         }
     } else if (inimg) {
-        if (s.flow) {
+        if (OFL_SP_HAS_FLOW(s)) {
             a = ld4(flw + n * s.flow_bs + pe);
             b = ld4(flw + n * s.flow_bs + hw + pe);
         } else {
@@ -1782,11 +1797,11 @@ __device__ __forceinline__ void sp_issue_src(const SP& s, int n, int sx4, int sy
     const TF* __restrict__ flw = reinterpret_cast<const TF*>(s.flow);
     r.a = (f4){0.f, 0.f, 0.f, 0.f}; r.b = (f4){0.f, 0.f, 0.f, 0.f};
     r.wm4 = 0x01010101u;
-    const int wrem = s.w & 3;
+    const int wrem = OFL_SP_WREM(s);
     const bool edge = wrem != 0 && inimg && sx4 > s.w - 4;
     const uint32_t pe = edge ? pix - (uint32_t)(4 - wrem) : pix;
     r.rot = edge ? 4 - wrem : 0;
-    if (inimg && s.fw != 0) {
+    if (inimg && OFL_SP_WINDOW(s)) {
         // padded apply: per-pixel loads with replicate addressing (not a hot path); the weight mask is False outside the window
         const uint32_t fhw = (uint32_t)(s.fh * s.fw);
         r.wm4 = 0u; r.rot = 0;
@@ -1799,7 +1814,7 @@ __device__ __forceinline__ void sp_issue_src(const SP& s, int n, int sx4, int sy
             r.wm4 |= (uint32_t)m << (8 * k);
         }
     } else if (inimg) {
-        if (s.flow) {
+        if (OFL_SP_HAS_FLOW(s)) {
             r.a = ld4(flw + n * s.flow_bs + pe);
             r.b = ld4(flw + n * s.flow_bs + hw + pe);
         } else {
@@ -1813,7 +1828,7 @@ template <typename SP>
 __device__ __forceinline__ void sp_src_done(const SP& s, int sx4, int sy, bool inimg, SpRaw& r, SpSrc& q) {
     // (locals, not in-place edits of `r`: the in-place form of sp_data_done's rotation was MISCOMPILED by ROCm 7.2 -- planes 1 and 2 of
     // a row-end group came out unrotated; tests/test_gpu_parity.py::test_tiled_splat_matches_two_pass_and_oracle[0.0-shape4] caught it)
-    const int rot = ((s.w & 3) != 0) ? r.rot : 0;             // (block-uniform test first)
+    const int rot = (OFL_SP_WREM(s) != 0) ? r.rot : 0;             // (block-uniform test first)
     f4 a = r.a, b = r.b;
     uint32_t wm4 = r.wm4;
     if (rot != 0) { a = rot4(a, rot); b = rot4(b, rot); wm4 >>= 8 * rot; }
@@ -1838,13 +1853,14 @@ __device__ __forceinline__ void sp_flag_image(const GatherParams& p, int n) {
     if (atomicOr(&p.img_over[n], 1) == 0) { atomicOr(&p.stats[0], 1); atomicAdd(&p.stats[2], 1); }
 }
 
-template <typename TF>
+template <typename TF, bool LEAN = false>
 __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     __shared__ int red[4][2];
     __shared__ int lcount[kBinLocal], lbase[kBinLocal];
     int rx, ry, n;
     if (!decode3(p.rtotal, p.rper_xcd, p.regs_img, p.ri_m, p.ri_s, p.rx_m, p.rx_s, p.regs_x, rx, ry, n)) return;
-    const SplatParams& s = p.s;
+    const typename std::conditional<LEAN, SplatParamsLean, SplatParams>::type& s =
+        reinterpret_cast<const typename std::conditional<LEAN, SplatParamsLean, SplatParams>::type&>(p.s);   // (see SplatParamsLean)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane >> 4, r = (lane >> 2) & 3, c4 = lane & 3;       // subtile of the wave, row and 4-pixel group in it
     const int w = s.w, h = s.h;
@@ -2081,10 +2097,10 @@ __device__ __forceinline__ void sp_tile_setup(const SP& s, int tx, int ty, int n
     t.pix = (uint32_t)(min(y, h - 1) * w + x2);
     t.wide = t.dx0 + kSpTW <= w;
     t.fill_ok[0] = t.fill_ok[1] = false;
-    if (s.occlude && s.flow && t.inimg) {
+    if (s.occlude && OFL_SP_HAS_FLOW(s) && t.inimg) {
         f2 a, b;
         uint32_t wm2 = 0x0101u;
-        if (s.fw != 0) {                                            // padded apply (see sp_win)
+        if (OFL_SP_WINDOW(s)) {                                            // padded apply (see sp_win)
             const uint32_t fhw = (uint32_t)(s.fh * s.fw);
             wm2 = 0u;
 #pragma unroll
@@ -2127,18 +2143,18 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float den = tot[k][0];
-        const float dcl = s.raw ? 1.0f : (den < kDenMin ? kDenMin : den);          // clamp_min utils.py:1144 (raw sums: x / 1 = x)
+        const float dcl = OFL_SP_RAW(s) ? 1.0f : (den < kDenMin ? kDenMin : den);          // clamp_min utils.py:1144 (raw sums: x / 1 = x)
         const bool warped = den > 0.0f;                            // utils.py:1197
         fill[k] = t.fill_ok[k] && !warped && mine;
         den2[k] = den;
         warped2 |= (uint32_t)warped << (8 * k);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) out[c][k] = stored_as<TO>(apply_round(tot[k][1 + c] / dcl, s.round_mode));
+        for (int c = 0; c < NC; ++c) out[c][k] = stored_as<TO>(apply_round(tot[k][1 + c] / dcl, OFL_SP_ROUND(s)));
         if (MCH) {
             // every contributor valid: the mask channel's sums ARE the density's (the same additions of the same weights),
             // and x / x = 1 -- no division where the whole wave is in that case (all but the neighbourhood of mask holes)
             const float num = tot[k][1 + NC];
-            const bool unit = num == den && den >= kDenMin && !s.raw;
+            const bool unit = num == den && den >= kDenMin && !OFL_SP_RAW(s);
             mch2[k] = __all(unit) ? 1.0f : num / dcl;
         }
     }
@@ -2148,11 +2164,11 @@ __device__ __forceinline__ void sp_finalize(const SP& s, const SpTile& t, const 
             if (!fill[k]) continue;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                out[c][k] = stored_as<TO>(apply_round(s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)), s.round_mode));
+                out[c][k] = stored_as<TO>(apply_round(s.data_sign * ((NC <= 2 && dbb) ? ld1(db + c * hw + pix + k) - dbb[c * hw + pix + k] : ld1(db + c * hw + pix + k)), OFL_SP_ROUND(s)));
             if (MCH) {
                 const bool a = s.chan_mask_a ? s.chan_mask_a[n * s.chan_mask_a_bs + pix + k] != 0 : true;
                 bool b = s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + pix + k] != 0 : true;
-                if (s.fw != 0) {                                    // padded apply: chan_mask_b lives in the flow window, False outside
+                if (OFL_SP_WINDOW(s)) {                                    // padded apply: chan_mask_b lives in the flow window, False outside
                     bool inside;
                     const uint32_t off = sp_win(s, (int)((pix + k) % (uint32_t)s.w), (int)((pix + k) / (uint32_t)s.w), inside);
                     b = inside && (s.chan_mask_b ? s.chan_mask_b[n * s.chan_mask_b_bs + off] != 0 : true);
@@ -2228,7 +2244,7 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
     const int w = s.w;
     const TF* __restrict__ db = reinterpret_cast<const TF*>(s.data) + n * s.data_bs;
     const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
-    const int wrem = w & 3;
+    const int wrem = OFL_SP_WREM(s);
     const bool edge = wrem != 0 && sx4 > w - 4;                   // row-end group: last whole group, rotated
     const uint32_t px = (uint32_t)(sy * w + sx4) - (edge ? (uint32_t)(4 - wrem) : 0u);
 #pragma unroll
@@ -2239,7 +2255,7 @@ __device__ __forceinline__ void sp_load_data(const SP& s, int n, int sx4, int sy
     uint32_t ma = 0x01010101u, mb = 0x01010101u;
     if (MCH) {
         if (s.chan_mask_a) ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + px);
-        if (s.fw != 0) {                                            // padded apply: chan_mask_b lives in the flow window, False outside
+        if (OFL_SP_WINDOW(s)) {                                            // padded apply: chan_mask_b lives in the flow window, False outside
             mb = 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -2268,7 +2284,7 @@ __device__ __forceinline__ void sp_issue_data(const SP& s, int n, int sx4, int s
     const int w = s.w;
     const TF* __restrict__ db = reinterpret_cast<const TF*>(s.data) + n * s.data_bs;
     const float* __restrict__ dbb = s.data_b ? s.data_b + n * s.data_b_bs : nullptr;
-    const int wrem = w & 3;
+    const int wrem = OFL_SP_WREM(s);
     const bool edge = wrem != 0 && sx4 > w - 4;                   // row-end group: last whole group, rotated
     const uint32_t px = (uint32_t)(sy * w + sx4) - (edge ? (uint32_t)(4 - wrem) : 0u);
     r.rot = edge ? 4 - wrem : 0;
@@ -2281,7 +2297,7 @@ __device__ __forceinline__ void sp_issue_data(const SP& s, int n, int sx4, int s
     r.ma = 0x01010101u; r.mb = 0x01010101u;
     if (MCH) {
         if (s.chan_mask_a) r.ma = ld32(s.chan_mask_a + n * s.chan_mask_a_bs + px);
-        if (s.fw != 0) {                                            // padded apply: chan_mask_b lives in the flow window, False outside
+        if (OFL_SP_WINDOW(s)) {                                            // padded apply: chan_mask_b lives in the flow window, False outside
             r.mb = 0u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -2295,7 +2311,7 @@ __device__ __forceinline__ void sp_issue_data(const SP& s, int n, int sx4, int s
 }
 template <int NC, typename SP>
 __device__ __forceinline__ void sp_data_done(const SP& s, SpRawData<NC>& r, f4 (&dat)[NC], uint32_t& mc4) {
-    const int rot = ((s.w & 3) != 0) ? r.rot : 0;             // (block-uniform test first: widths that are multiples of 4 skip it all)
+    const int rot = (OFL_SP_WREM(s) != 0) ? r.rot : 0;             // (block-uniform test first: widths that are multiples of 4 skip it all)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         f4 v = r.dat[c];
@@ -2319,7 +2335,9 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
 // v_writelane (rocprofv3 SQ_INSTS_VALU with and without the sort / sum phases: profiles/r2_splat_gather_sq_*.txt).
 typedef const GatherParams __attribute__((address_space(4))) GatherParamsK;
 
-template <int NC, bool MCH, typename TF = float, typename TO = float>
+typedef const SplatParams __attribute__((address_space(4))) SplatParamsK;
+typedef const SplatParamsLean __attribute__((address_space(4))) SplatParamsLeanK;
+template <int NC, bool MCH, typename TF = float, typename TO = float, bool LEAN = false>
 __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const GatherParams p_by_value_unused) {
     GatherParamsK* pp = (GatherParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
@@ -2351,7 +2369,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
     uint2* slots = reinterpret_cast<uint2*>(ccnt + kCellsP);          // [kCellsP]: records 0 .. 3 of the cell (kEnd: none), raster order after phase S
     uint32_t* ohead = reinterpret_cast<uint32_t*>(slots + kCellsP);   // [kCellsP]: chain of the records beyond four / sorted list of a long cell
     uint16_t* link = reinterpret_cast<uint16_t*>(ohead + kCellsP);    // [kSpQ]: next record of the chain
-#define s (pp->s)
+#define s (*reinterpret_cast<typename std::conditional<LEAN, SplatParamsLeanK, SplatParamsK>::type*>(&pp->s))   /* (see SplatParamsLean) */
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
@@ -3174,9 +3192,14 @@ inline unsigned fallback_resident_blocks(const void* kernel, int which) {
     return (unsigned)v;
 }
 
+// the promises of SplatParamsLean hold for this call (the lean instantiations exist for 2 and 3 channels)
+inline bool splat_is_lean(const SplatParams& s) {
+    return OFL_SP_LEAN && s.flow != nullptr && s.fw == 0 && (s.w & 3) == 0 && s.raw == 0 && s.round_mode == OFL_ROUND_NONE;
+}
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    if (NC >= 2 && splat_is_lean(gp.s)) hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    else hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
     return (int)hipGetLastError();
 }
 
@@ -3642,8 +3665,11 @@ static int splat_tiled_impl(
         e = n0 == 0 ? hipMemsetAsync(gp.stats, 0, (8 + zwords) * sizeof(int32_t), st)      // statistics | flags | lengths: contiguous
                     : hipMemsetAsync(gp.img_over, 0, zwords * sizeof(int32_t), st);
         if (e != hipSuccess) return (int)e;
-        if (half_in) hipLaunchKernelGGL(splat_bin_kernel<_Float16>, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
-        else hipLaunchKernelGGL(splat_bin_kernel<float>, dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
+        const bool lean = splat_is_lean(gp.s);
+        if (half_in) { if (lean) hipLaunchKernelGGL((splat_bin_kernel<_Float16, true>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
+                       else hipLaunchKernelGGL((splat_bin_kernel<_Float16>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp); }
+        else { if (lean) hipLaunchKernelGGL((splat_bin_kernel<float, true>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
+               else hipLaunchKernelGGL((splat_bin_kernel<float>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp); }
         rc = (int)hipGetLastError();
         if (rc) return rc;
         // more than 3 channels: groups of 3 (a record holds 3 data channels); density and masks come out of the first group
