@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             obj = os.path.join(tmp, os.path.splitext(os.path.basename(src))[0] + ".o")
             cmd = [hipcc_path()] + compile_flags + ["-I", os.path.join(_ROOT, "include"), "-c", "-o", obj, src]
             if verbose:
-                print(" ".join(cmd))
+                print(" ".join(cmd), flush=True)
             objs.append(obj)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
         for src, pr in procs:
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 raise RuntimeError("oflibpytorch_amd: hipcc failed on %s\n%s%s" % (src, out, err))
         link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB_PATH] + objs
         if verbose:
-            print(" ".join(link))
+            print(" ".join(link), flush=True)
         res = subprocess.run(link, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("oflibpytorch_amd: hipcc (link) failed\n" + res.stdout + res.stderr)

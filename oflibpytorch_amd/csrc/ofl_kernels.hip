@@ -125,9 +125,21 @@ struct WarpParams {
     // flow_mask are fh x fw frames covering rows foy .., columns fox .. of the h x w frame; outside the window the flow is
     // zero (F.pad(mode='constant')) and the flow mask False
     int32_t fh, fw, foy, fox;
+    static constexpr bool kLean = false;
 };
 
+// The COMMON CASE as a type (as SplatParamsLean for the splat): the same bytes read as WarpParamsLean promise the staged kernels a width
+// that is a multiple of 4, no rounding, no flow-flag by-product and the sheared box -- `WP::kLean` folds those run-time switches (a scalar
+// load + compare + branch per use: per staging round, per stored plane, per tile) out of the lean instantiations.  The host picks them when
+// the promises hold: apply 't' -2 %, mode 3 -3 % (profiles/r5_warp_lean.txt).
+struct WarpParamsLean : WarpParams { static constexpr bool kLean = true; };
+#define OFL_WP_LEAN_OF(p_) (std::remove_reference<decltype(p_)>::type::kLean)
+#define OFL_WP_WREM(p_) (OFL_WP_LEAN_OF(p_) ? 0 : ((p_).w & 3))
+#define OFL_WP_ROUND(p_) (OFL_WP_LEAN_OF(p_) ? (int32_t)OFL_ROUND_NONE : (p_).round_mode)
+#define OFL_WP_FLOW_FLAGS(p_) (OFL_WP_LEAN_OF(p_) ? (int32_t*)nullptr : (p_).flow_flags)
+#define OFL_WP_SHEAR(p_) (OFL_WP_LEAN_OF(p_) || (p_).shear != 0)
 typedef const WarpParams __attribute__((address_space(4))) WarpParamsK;
+typedef const WarpParamsLean __attribute__((address_space(4))) WarpParamsLeanK;
 #define OFL_OPAQUE_S(ptr_) asm volatile("" : "+s"(ptr_))
 #ifndef OFL_WARP_KARG
 #define OFL_WARP_KARG 1
@@ -249,6 +261,9 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 // A tile whose box does not fit the LDS budget gathers straight from global memory (same arithmetic).
 // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): global loads and stores stay in flight across them.
 // ------------------------------------------------------------------------------------------------
+#ifndef OFL_WARP_LEAN
+#define OFL_WARP_LEAN 1
+#endif
 #ifndef OFL_WARP_REUSE
 #define OFL_WARP_REUSE 1
 #endif
@@ -530,7 +545,7 @@ __device__ __forceinline__ void lds_issue(const WP& p, const TS* __restrict__ sb
             S.slot[it] = on ? 1 + (int)(__umul24(r, (uint32_t)B.Pp) + c4) : -1;
             // the last chunk of a row of an image whose width is not a multiple of 4 would read past the row end (and past
             // the buffer on the last row): fetch the last whole group instead and rotate (block-uniform branch)
-            const int wrem = p.w & 3;
+            const int wrem = OFL_WP_WREM(p);
             const bool edge = wrem != 0 && on && (int)(B.bx0 + (int)c4 * 4) > p.w - 4;
             const uint32_t ge = edge ? g - (uint32_t)(4 - wrem) : g;
 #pragma unroll
@@ -715,9 +730,9 @@ __device__ __forceinline__ void lds_store(const WP& p, int tx, int ty, int n, ui
         for (int c = 0; c < NC; ++c) {
             f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
             if (ADD) o = addend[c] * p.a_sign + o * p.g_sign;
-            if (p.round_mode != OFL_ROUND_NONE) {
+            if (OFL_WP_ROUND(p) != OFL_ROUND_NONE) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], p.round_mode);
+                for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], OFL_WP_ROUND(p));
             }
             st4o(db + c * hw + pix, o);
             if (DF && c < 2) o01[c] = o;
@@ -825,13 +840,14 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_kernel(const WarpParam
 // ARE its addend and stay live until its store, so the tile's sample positions are not kept from the box phase to the gather (8
 // VGPRs per tile, two tiles live) but re-formed from those registers at gather time -- ~40 VALU per tile for the ~16 registers that
 // were the kernel's scratch traffic.
-template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false, bool REUSE = false>
+template <int T, int NC, bool VALID, bool ADD, bool DF = false, bool SUB = false, typename TS = float, typename TD = float, bool GRAD = false, bool REUSE = false, bool LEAN = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const WarpParams p_by_value) {
     static_assert(!REUSE || (ADD && NC == 2 && !GRAD), "REUSE: the fused composition");
 #if OFL_WARP_KARG
     // parameters through the kernarg segment (see OFL_OPAQUE_S at the gather splat): the ~250 bytes of WarpParams are not
     // held in SGPRs (and spilled to VGPR lanes) across the whole column, each phase s_loads what it needs
-    WarpParamsK* pp = (WarpParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef typename std::conditional<LEAN, WarpParamsLeanK, WarpParamsK>::type WPK;       // (LEAN: see WarpParamsLean)
+    WPK* pp = (WPK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
 #define OFL_WARP_PHASE() OFL_OPAQUE_S(pp)
 #else
@@ -863,11 +879,11 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         fmk[k] = 0x01010101u;
         // (OFL_WARP_UNCOND_ROUNDS: countable, as the staging loads: no flow mask -> a read of the flow's bytes, discarded where the word is used)
         if (OFL_WARP_UNCOND_ROUNDS && VALID) fmk[k] = ld32(fm ? fm + pix : reinterpret_cast<const uint8_t*>(fu) + pix);
-        else if ((VALID || p.flow_flags) && fm) fmk[k] = ld32(fm + pix);
+        else if ((VALID || OFL_WP_FLOW_FLAGS(p)) && fm) fmk[k] = ld32(fm + pix);
     };
     auto fmw = [&](int k) -> uint32_t { return (OFL_WARP_UNCOND_ROUNDS && VALID && !fm) ? 0x01010101u : fmk[k]; };
     auto note_flags = [&](int k) {       // finiteness / zero tests of the flow operand as a by-product (wave-uniform branch)
-        if (p.flow_flags && (x4 < w) && ((tyg * T + k) * kLdsTH + ly < h)) {
+        if (OFL_WP_FLOW_FLAGS(p) && (x4 < w) && ((tyg * T + k) * kLdsTH + ly < h)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) fflags |= flag_bits(uu[k][q], vv[k][q], ((fmw(k) >> (8 * q)) & 0xffu) != 0u);
         }
@@ -882,7 +898,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
     // must not sit between a tile's flow and its box
     int sq[T];
 #pragma unroll
-    for (int k = 0; k < T; ++k) sq[k] = p.shear ? lds_slope_row(p, fu, hw, tx, (tyg * T + k) * kLdsTH + kLdsTH / 2) : 0;
+    for (int k = 0; k < T; ++k) sq[k] = OFL_WP_SHEAR(p) ? lds_slope_row(p, fu, hw, tx, (tyg * T + k) * kLdsTH + kLdsTH / 2) : 0;
     note_flags(0);
     lds_coords_box<true, kClip>(p, tx, tyg * T, uu[0], vv[0], sq[0], Tc[0], Bx[0], red[0]);
     lds_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Bx[0], S, sbb);          // staging loads of tile 0 fly ...
@@ -938,7 +954,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
         if (!more) break;
         lds_barrier();
     }
-    if (p.flow_flags) {
+    if (OFL_WP_FLOW_FLAGS(p)) {
         fflags = wave_or_flags(fflags);
         if ((tid & 63) == 0) flag_or(&p.flow_flags[n], fflags);
     }
@@ -1043,9 +1059,10 @@ __device__ __attribute__((noinline)) Out4 chan_pixels_from_global(WarpParamsK* p
 #undef p
 }
 
-template <bool VALID>
+template <bool VALID, bool LEAN = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const WarpParams p_by_value) {
-    WarpParamsK* pp = (WarpParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef typename std::conditional<LEAN, WarpParamsLeanK, WarpParamsK>::type WPK;       // (LEAN: see WarpParamsLean)
+    WPK* pp = (WPK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
     constexpr int NW = kLdsNT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1063,8 +1080,8 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
     uint32_t pix = (uint32_t)(min(ty * kLdsTH + ly, h - 1) * w + xq);
     const f4 uu = ld4nt(fu + pix), vv = ld4nt(fu + hw + pix);
     uint32_t fmk = 0x01010101u;
-    if ((VALID || p.flow_flags) && fm) fmk = ld32(fm + pix);
-    if (p.flow_flags) {                      // finiteness / zero tests of the flow operand as a by-product (wave-uniform branch)
+    if ((VALID || OFL_WP_FLOW_FLAGS(p)) && fm) fmk = ld32(fm + pix);
+    if (OFL_WP_FLOW_FLAGS(p)) {                      // finiteness / zero tests of the flow operand as a by-product (wave-uniform branch)
         int f = 0;
         if ((x4 < w) && (ty * kLdsTH + ly < h)) {
 #pragma unroll
@@ -1076,10 +1093,10 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
     f4* lds = reinterpret_cast<f4*>(smem);
     LdsCoords Tc;
     LdsBox Bx;
-    const int sq = p.shear ? lds_slope_row(p, fu, hw, tx, ty * kLdsTH + kLdsTH / 2) : 0;
+    const int sq = OFL_WP_SHEAR(p) ? lds_slope_row(p, fu, hw, tx, ty * kLdsTH + kLdsTH / 2) : 0;
     lds_coords_box<true, true>(p, tx, ty, uu, vv, sq, Tc, Bx, red);
     if (__builtin_expect(!Bx.fits, 0)) {     // (block-uniform, cold)
-        chan_tile_from_global<VALID>(pp, Tc, tx, ty, n, fmk);
+        chan_tile_from_global<VALID>(reinterpret_cast<WarpParamsK*>(pp), Tc, tx, ty, n, fmk);
         return;
     }
     // --- per-tile invariants: taps, weights, staging geometry -------------------------------------------------------------
@@ -1176,9 +1193,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
         for (int c = 0; c < 4; ++c) {
             if (c < planes) {
                 f4 o = {outv[0][c], outv[1][c], outv[2][c], outv[3][c]};
-                if (p.round_mode != OFL_ROUND_NONE) {
+                if (OFL_WP_ROUND(p) != OFL_ROUND_NONE) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], p.round_mode);
+                    for (int k = 0; k < 4; ++k) o[k] = apply_round(o[k], OFL_WP_ROUND(p));
                 }
                 st4o(db + (int64_t)(first + c) * hw + pix, o);
             }
@@ -1192,7 +1209,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
         gather(outv);
         if (__builtin_expect(any_below, 0)) {
             if (below != 0u) {
-                const Out4 fixed = chan_pixels_from_global<3, true>(pp, sb0, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
+                const Out4 fixed = chan_pixels_from_global<3, true>(reinterpret_cast<WarpParamsK*>(pp), sb0, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
 #pragma unroll
                 for (int k = 0; k < 4; ++k) outv[k] = fixed.v[k];
             }
@@ -1220,7 +1237,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
         gather(outv);
         if (__builtin_expect(any_below, 0)) {
             if (below != 0u) {
-                const Out4 fixed = chan_pixels_from_global<4, false>(pp, sb0 + (int64_t)mine * hw, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
+                const Out4 fixed = chan_pixels_from_global<4, false>(reinterpret_cast<WarpParamsK*>(pp), sb0 + (int64_t)mine * hw, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
 #pragma unroll
                 for (int k = 0; k < 4; ++k) outv[k] = fixed.v[k];
             }
@@ -2984,6 +3001,11 @@ inline void magic_u32(uint32_t d, uint32_t& m, uint32_t& s) {   // d >= 1; see f
     s = ((l ? 1u : 0u) << 16) | (l ? l - 1 : 0);
 }
 
+// the promises of WarpParamsLean hold for this launch
+inline bool warp_is_lean(const WarpParams& p) {
+    return OFL_WARP_LEAN && (p.w & 3) == 0 && p.round_mode == OFL_ROUND_NONE && p.flow_flags == nullptr && p.shear != 0;
+}
+
 inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
     p.tiles_x = (p.w + tile_w - 1) / tile_w;
     p.tiles_y = (p.h + tile_h - 1) / tile_h;
@@ -3005,6 +3027,7 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void*
     const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
     hipStream_t st = (hipStream_t)stream;
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
+    const bool lean = warp_is_lean(q);
 #if OFL_WARP_COL_ADD >= 2
     if (add && OFL_WARP_REUSE && q.add_is_flow) {
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
@@ -3018,7 +3041,10 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void*
     }
 #endif
 #define OFL_WIDE_CASE(NC)                                                                                                                   \
-    if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);           \
+    if (lean) {                                                                                                                              \
+        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);   \
+        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);        \
+    } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);      \
     else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
     switch (nc) {
         case 1: OFL_WIDE_CASE(1) break;
@@ -3033,7 +3059,10 @@ int ofl_wide_launch_chan(const void* params, int valid, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
     const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
-    if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+    if (warp_is_lean(q)) {
+        if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+    } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
     else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
@@ -3061,7 +3090,10 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
         if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, (void*)st);
         if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
-            if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            if (warp_is_lean(q)) {
+                if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+                else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
             else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
             return (int)hipGetLastError();
         }
@@ -3316,7 +3348,10 @@ static int warp_bwd_impl(
             WarpParams q = p;
             const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
             if (OFL_WARP_CHAN_WIDE && g1 >= 2 * 6912u) return ofl_wide_launch_chan(&p, p.valid ? 1 : 0, (void*)st);
-            if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+            if (warp_is_lean(q)) {
+                if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+                else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+            } else if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
             else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
             return (int)hipGetLastError();
         }
