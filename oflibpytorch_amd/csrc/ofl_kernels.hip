@@ -3113,6 +3113,11 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         WarpParams q1 = p;
         const unsigned g1 = warp_geometry(q1, kLdsTWQ * 4, kLdsTH);
         if (g_warp_path == 4 || (g_warp_path != 3 && g1 < kColumnMinGroups)) {
+            if (warp_is_lean(q1) && valid) {            // (the lean twins of the two instantiations with a valid mask: BASELINE configs[1] is one of them)
+                if (add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, true, false, false, float, float, false, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+                else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, false, false, false, float, float, false, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+                return (int)hipGetLastError();
+            }
             if (valid && add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
             else if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
             else if (add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
