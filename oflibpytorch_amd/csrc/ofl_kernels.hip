@@ -1135,6 +1135,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
     }
     const int cw16 = Bx.cw * 16;
     // nothing above is to be recomputed, and nothing else hoisted, inside the channel loop
+    static_assert(kLdsBytes <= 65536, "tap addresses are packed as 16-bit LDS byte addresses");
     uint32_t sp[8];                                          // two 16-bit LDS byte addresses per register
 #pragma unroll
     for (int i = 0; i < 8; ++i) sp[i] = (uint32_t)si[2 * i] | ((uint32_t)si[2 * i + 1] << 16);
