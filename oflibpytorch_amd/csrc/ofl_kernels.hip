@@ -3098,6 +3098,11 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
             else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
             return (int)hipGetLastError();
         }
+        if (warp_is_lean(q)) {                     // (the addend is another flow: the outer `flow - (...)` of modes 1-2, Flow.combine's cells)
+            if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            return (int)hipGetLastError();
+        }
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
