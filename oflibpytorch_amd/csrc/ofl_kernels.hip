@@ -3077,6 +3077,16 @@ template <int NC>
 int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     const bool valid = p.valid != nullptr, add = p.addend != nullptr;
     if (NC == 2 && p.src_b) {                              // (host: 2 channels, valid mask, no addend, no output flags)
+        if (kLdsT > 2 && g_warp_path != 3 && g_warp_path != 4) {   // large launches: columns of four tiles, lean when the promises hold
+            WarpParams q = p;
+            const unsigned gc = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+            constexpr int TT = kLdsT > 2 ? kLdsT : 3;
+            if (gc >= 6912u) {
+                if (warp_is_lean(q)) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2, float, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                return (int)hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         return (int)hipGetLastError();
     }
@@ -3495,8 +3505,22 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_h_f32(
     p.lds_bytes = kLdsBytes;
     p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;
     p.dst_bs = (int64_t)2 * h * w;
-    const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
     hipStream_t st = (hipStream_t)stream;
+    // large launches: columns of four tiles (round 5: every wait of that pipeline is counted, see lds_store), lean when the promises hold
+    if (kLdsT > 2 && g_warp_path != 3 && g_warp_path != 4) {
+        WarpParams q = p;
+        const unsigned gc = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
+        constexpr int TT = kLdsT > 2 ? kLdsT : 3;
+        if (gc >= 6912u) {
+            const bool lean = warp_is_lean(q);
+            if (src_b) { if (lean) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
+            else { if (lean) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                   else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
+            return (int)hipGetLastError();
+        }
+    }
+    const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
     if (src_b) hipLaunchKernelGGL((warp_bwd_lds_kernel<2, true, false, false, true, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
     else hipLaunchKernelGGL((warp_bwd_lds_kernel<2, true, false, false, false, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
     return (int)hipGetLastError();
