@@ -3303,7 +3303,7 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 29; }   // 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 30; }   // 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 5) { g_warp_path = value; return OFL_OK; }
