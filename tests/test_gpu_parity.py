@@ -181,7 +181,15 @@ def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, frame, dev):
     src = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
     sm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
     fmk = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
-    for kw in (dict(src_mask=sm, flow_mask=fmk, want_valid=True), dict()):
+    add = torch.randn(n, c, h, w, generator=g).to(dev)
+    kws = [dict(src_mask=sm, flow_mask=fmk, want_valid=True), dict()]
+    if c == 2:
+        # round 5: the fused composition -- the ADD epilogue -- runs on the column kernel too, oversize boxes staged in
+        # part: once with the flow itself as the addend (mode 3 proper: the REUSE instantiation re-forms the positions from the
+        # flow registers), once with another field
+        kws += [dict(src_mask=sm, flow_mask=fmk, want_valid=True, addend=flow, a_sign=1.0, g_sign=1.0),
+                dict(flow_mask=fmk, want_valid=True, addend=add, a_sign=-1.0, g_sign=1.0)]
+    for kw in kws:
         outs = []
         for path in (0, 1, 3, 4):               # auto (= columns of four here), generic, two tiles per block, one tile per block
             _native.set_warp_path(path)
@@ -197,9 +205,13 @@ def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, frame, dev):
         k = 3                                    # (the oracle on the first images only: it is the checker, not the thing timed)
         s = src[:k].cpu().numpy()
         if kw.get("want_valid"):
-            s = np.concatenate([s, sm[:k].cpu().numpy().astype(np.float32)[:, None]], 1)
+            m = sm[:k].cpu().numpy().astype(np.float32) if "src_mask" in kw else np.ones((k, h, w), np.float32)
+            s = np.concatenate([s, m[:, None]], 1)
         gref = oracle.G(flow[:k].cpu().numpy(), s)
-        assert np.array_equal(outs[0][0][:k].cpu().numpy(), gref[:, :c], equal_nan=True)
+        exp = gref[:, :c]
+        if "addend" in kw:
+            exp = np.float32(kw["a_sign"]) * kw["addend"][:k].cpu().numpy() + np.float32(kw["g_sign"]) * exp
+        assert np.array_equal(outs[0][0][:k].cpu().numpy(), exp, equal_nan=True)
         if kw.get("want_valid"):
             assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > 0.99999) & fmk[:k].cpu().numpy())
 
