@@ -273,6 +273,9 @@ __device__ __forceinline__ f4 rot4(f4 v, int d) { return d == 1 ? (f4){v[1], v[2
 #ifndef OFL_WARP_CHAN_WIDE
 #define OFL_WARP_CHAN_WIDE 1
 #endif
+#ifndef OFL_WARP_CHAN_SUBS
+#define OFL_WARP_CHAN_SUBS 1       // tiles side by side per block of the 64 x 16 channel-loop kernel.  3 (one 768-thread block per CU, its three tiles in lockstep so that they share their x-halo lines) was built and measured: bit-identical, 40 % SLOWER (profiles/r5_chan_pmc.txt) -- the lockstep that shares the lines also makes the whole CU wait together
+#endif
 #ifndef OFL_WARP_ALWAYS_T
 #define OFL_WARP_ALWAYS_T 1
 #endif
@@ -472,7 +475,7 @@ __device__ __forceinline__ LdsBoxWords lds_coords_box_a(const WP& p, int tx, int
     int lo = (int)(((uint32_t)minx & 0xffffu) | ((uint32_t)miny << 16)), hi = (int)(((uint32_t)maxx & 0xffffu) | ((uint32_t)maxy << 16));
     lo = wave_pk_min_dpp(lo); hi = wave_pk_max_dpp(hi);
     if (NW > 1) {
-        if ((tid & 63) == 0) { red[tid >> 6][0] = lo; red[tid >> 6][1] = hi; }
+        if ((tid & 63) == 0) { red[(tid >> 6) & (NW - 1)][0] = lo; red[(tid >> 6) & (NW - 1)][1] = hi; }   // (& (NW - 1): a block of several sub-tiles, warp_bwd_lds_chan_kernel<.., SUBS>)
     }
     return LdsBoxWords{lo, hi};
 }
@@ -999,56 +1002,23 @@ __device__ __forceinline__ void lds_taps(const WP& p, const LdsCoords& T, const 
     }
 }
 
-// A tile whose box does not fit the LDS even in part (fewer than OFL_WARP_CLIP rows of it would: an extreme stretch): every group
-// gathers from global memory with the arithmetic of lds_gather_impl.  A real call: cold, its registers must not weigh on the pipeline's.
-template <bool VALID>
-__device__ __attribute__((noinline)) void chan_tile_from_global(WarpParamsK* pp, LdsCoords Tc, int tx, int ty, int n, uint32_t fmk) {
-#define p (*pp)
-    const int C = p.c;
-    const uint32_t hw = (uint32_t)(p.h * p.w);
-    const float* __restrict__ sb0 = p.src + n * p.src_bs;
-    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
-    LdsBox Bx = {};
-    Bx.fits = false; Bx.interior = false; Bx.clipped = false;
-    int g = 0;
-    if (VALID) {
-        f4 outv[4];
-        const f4 none[3] = {};
-        lds_gather_impl<3, true, false>(p, hw, sb0, sm, Tc, Bx, nullptr, outv);
-        lds_store<3, true, false>(p, tx, ty, n, hw, fmk, outv, none);
-        g = 3;
-    }
-    const f4 none4[4] = {};
-    for (bool last = false; !last; g += 4) {
-        const int mine = min(g, C - 4);
-        last = g + 4 >= C;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(Tc.sx[k])); asm volatile("" : "+v"(Tc.sy[k])); }   // (nothing hoisted out of the loop)
-        f4 outv[4];
-        lds_gather_impl<4, false, false>(p, hw, sb0 + (int64_t)mine * hw, nullptr, Tc, Bx, nullptr, outv);
-        lds_store<4, false, false>(p, tx, ty, n, hw, 0u, outv, none4, nullptr, (int64_t)mine * hw);
-    }
-#undef p
-}
-
-// OVERSIZE box staged in part (lds_coords_box<.., CLIP>: the rows that fit): the pixels of this lane with a tap below the staged rows
-// (bit k of `below`) take their 4 planes from global memory instead -- flow re-read (an L2 hit), coordinates re-formed, the
+// OVERSIZE box staged in part (lds_coords_box<.., CLIP>: the rows that fit; none at all when not even OFL_WARP_CLIP rows would): the
+// pixels of this lane with a tap below the staged rows (bit k of `below`) take their 4 planes from global memory instead -- flow re-read (an L2 hit), coordinates re-formed, the
 // arithmetic of lds_gather_impl -- so that nothing of it is kept in registers across the channel loop.  Cold (a wave with no such
 // lane skips it), and a real call for the same reason as above.
 struct Out4 { f4 v[4]; };
 template <int NCH, bool MASK3>
-__device__ __attribute__((noinline)) Out4 chan_pixels_from_global(WarpParamsK* pp, const float* sb, uint32_t pix, uint32_t below, Out4 cur) {
+__device__ __attribute__((noinline)) Out4 chan_pixels_from_global(WarpParamsK* pp, const float* sb, uint32_t pix, uint32_t below, Out4 cur,
+                                                                  int tx, int ty, int n, int row) {
 #define p (*pp)
     const int w = p.w, h = p.h;
     const uint32_t hw = (uint32_t)(h * w);
-    int tx, ty, n;
-    decode_tile(p, tx, ty, n);
     const float* __restrict__ fu = p.flow + n * p.flow_bs;
     const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
     const f4 uu = ld4nt(fu + pix), vv = ld4nt(fu + hw + pix);
     LdsCoords Tc;
     int dummy[1][4];
-    lds_coords_box_a<false>(p, tx, ty, uu, vv, 0, Tc, dummy);
+    lds_coords_box_a<false>(p, tx, ty, uu, vv, 0, Tc, dummy, row);
     LdsBox Bx = {};
     Bx.fits = false; Bx.interior = false; Bx.clipped = false;
     f4 got[4];
@@ -1059,17 +1029,26 @@ __device__ __attribute__((noinline)) Out4 chan_pixels_from_global(WarpParamsK* p
 #undef p
 }
 
-template <bool VALID, bool LEAN = false>
-__global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const WarpParams p_by_value) {
+// SUBS (1 or 3): a block of SUBS x kLdsNT threads owns SUBS tiles SIDE BY SIDE, each with its own box in its own part of the LDS, all
+// walking the channel groups in LOCKSTEP (the barriers are the block's).  What it buys: the x-halo of neighbouring boxes -- partial 128-byte
+// lines that a lone tile fetches for itself, per group, because its neighbours are at other groups at that moment (profiles/r5_chan_pmc.txt)
+// -- is requested by waves of ONE CU within the same few hundred cycles and fetched once.  The grid then counts tile TRIPLES along x; a
+// sub-tile past the frame's right edge recomputes the last columns (clamped loads, identical duplicate stores).
+template <bool VALID, bool LEAN = false, int SUBS = 1>
+__global__ __launch_bounds__(kLdsNT * SUBS, 3) void warp_bwd_lds_chan_kernel(const WarpParams p_by_value) {
     typedef typename std::conditional<LEAN, WarpParamsLeanK, WarpParamsK>::type WPK;       // (LEAN: see WarpParamsLean)
     WPK* pp = (WPK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
     constexpr int NW = kLdsNT / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int red[NW][4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    __shared__ int red_all[SUBS][NW][4];
     int tx, ty, n;
     if (!decode_tile(p, tx, ty, n)) return;
-    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int sub = SUBS > 1 ? (int)threadIdx.x / kLdsNT : 0;
+    const int tid = SUBS > 1 ? (int)threadIdx.x - sub * kLdsNT : (int)threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    unsigned char* smem = smem_all + sub * kLdsBytes;
+    int (*red)[4] = red_all[sub];
+    tx = tx * SUBS + sub;
     const int w = p.w, h = p.h, C = p.c;
     const uint32_t hw = (uint32_t)(h * w);
     const float* __restrict__ fu = p.flow + n * p.flow_bs;
@@ -1094,17 +1073,21 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
     LdsCoords Tc;
     LdsBox Bx;
     const int sq = OFL_WP_SHEAR(p) ? lds_slope_row(p, fu, hw, tx, ty * kLdsTH + kLdsTH / 2) : 0;
-    lds_coords_box<true, true>(p, tx, ty, uu, vv, sq, Tc, Bx, red);
-    if (__builtin_expect(!Bx.fits, 0)) {     // (block-uniform, cold)
-        chan_tile_from_global<VALID>(reinterpret_cast<WarpParamsK*>(pp), Tc, tx, ty, n, fmk);
-        return;
-    }
+    lds_coords_box<true, true>(p, tx, ty, uu, vv, sq, Tc, Bx, red, ly);
+    // a box of which not even OFL_WARP_CLIP rows fit (an extreme stretch; or an empty one: every tap outside the frame) stages NOTHING and
+    // every pixel takes the global fix-up below -- cold, but the tile keeps walking the groups with its block (barriers are the block's)
+    const bool nofit = !Bx.fits;                             // (uniform over the sub-tile)
+    if (__builtin_expect(nofit, 0)) { Bx.nch = 0; Bx.bh = 0; Bx.clipped = true; }
     // --- per-tile invariants: taps, weights, staging geometry -------------------------------------------------------------
     int si[16];
     float wg[16];
     uint32_t below = 0u;                                     // pixels of this lane with a tap below the staged rows of a clipped box
     lds_taps(p, Tc, Bx, si, wg);
-    if (__builtin_expect(Bx.clipped, 0)) {
+    if (__builtin_expect(nofit, 0)) {
+        below = 0xfu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) si[i] = 0;
+    } else if (__builtin_expect(Bx.clipped, 0)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                        // (lds_gather_impl's test, on the row of the lower taps)
             const int xi = (int)__builtin_amdgcn_fmed3f(floorf(Tc.sx[k]), -2.0f, (float)w), yi = (int)__builtin_amdgcn_fmed3f(floorf(Tc.sy[k]), -2.0f, (float)h);
@@ -1118,7 +1101,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
         }
     }
     const bool any_below = Bx.clipped && __any(below != 0u);  // wave-uniform
-    const int rounds = (Bx.nch + kLdsNT - 1) / kLdsNT;       // 1 .. kLdsIters, block-uniform
+    const int rounds = (Bx.nch + kLdsNT - 1) / kLdsNT;       // 0 (nothing fits) .. kLdsIters, uniform over the sub-tile
     uint32_t goff[kLdsIters];                                // (widths that are multiples of 4 only: no chunk straddles a row end)
     int slot[kLdsIters];
     {
@@ -1210,7 +1193,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
         gather(outv);
         if (__builtin_expect(any_below, 0)) {
             if (below != 0u) {
-                const Out4 fixed = chan_pixels_from_global<3, true>(reinterpret_cast<WarpParamsK*>(pp), sb0, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
+                const Out4 fixed = chan_pixels_from_global<3, true>(reinterpret_cast<WarpParamsK*>(pp), sb0, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}}, tx, ty, n, ly);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) outv[k] = fixed.v[k];
             }
@@ -1238,7 +1221,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_chan_kernel(const Warp
         gather(outv);
         if (__builtin_expect(any_below, 0)) {
             if (below != 0u) {
-                const Out4 fixed = chan_pixels_from_global<4, false>(reinterpret_cast<WarpParamsK*>(pp), sb0 + (int64_t)mine * hw, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}});
+                const Out4 fixed = chan_pixels_from_global<4, false>(reinterpret_cast<WarpParamsK*>(pp), sb0 + (int64_t)mine * hw, pix, below, Out4{{outv[0], outv[1], outv[2], outv[3]}}, tx, ty, n, ly);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) outv[k] = fixed.v[k];
             }
@@ -3059,6 +3042,27 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void*
 int ofl_wide_launch_chan(const void* params, int valid, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
+#if OFL_WARP_CHAN_SUBS > 1
+    {   // three tiles side by side per block, in lockstep (see the kernel): 768 threads, 3 x 52 KB of LDS, one block = 12 waves per CU
+        constexpr int S = OFL_WARP_CHAN_SUBS;
+        WarpParams q3 = q;
+        const unsigned g3 = warp_geometry(q3, kLdsTWQ * 4 * S, kLdsTH);
+        static bool attr_set = false;                             // (more than 64 KB of dynamic LDS must be asked for, once per kernel)
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)warp_bwd_lds_chan_kernel<true, true, S>, hipFuncAttributeMaxDynamicSharedMemorySize, S * kLdsBytes);
+            hipFuncSetAttribute((const void*)warp_bwd_lds_chan_kernel<false, true, S>, hipFuncAttributeMaxDynamicSharedMemorySize, S * kLdsBytes);
+            hipFuncSetAttribute((const void*)warp_bwd_lds_chan_kernel<true, false, S>, hipFuncAttributeMaxDynamicSharedMemorySize, S * kLdsBytes);
+            hipFuncSetAttribute((const void*)warp_bwd_lds_chan_kernel<false, false, S>, hipFuncAttributeMaxDynamicSharedMemorySize, S * kLdsBytes);
+            attr_set = true;
+        }
+        if (warp_is_lean(q3)) {
+            if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+            else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+        } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, false, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+        else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, false, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+        return (int)hipGetLastError();
+    }
+#endif
     const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
     if (warp_is_lean(q)) {
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
