@@ -59,7 +59,10 @@ int ofl_version(void);
  *                          (auto picks by size: one tile per block for tiny launches, two for small ones, columns of four
  *                          from ~B = 8 at 1080p; all three run the same device code per tile -- tests compare them),
  *                      5 = like auto, but a warp of more than 3 channels runs as separate launches of 3 channels instead of the
- *                          channel-loop kernel (one launch that walks the channels in groups of 4 inside the block; W % 4 == 0). */
+ *                          channel-loop kernel (one launch that walks the channels in groups of 4 inside the block; W % 4 == 0),
+ *                      6 = like auto, but the four-tile column kernel of large launches stages ONE y-sheared rectangle per tile instead of
+ *                          per-row extents (the default for plain warps of 1..3 channels with W % 4 == 0 and no rounding: every source row
+ *                          a 64 x 16 tile touches has its own first chunk and length). */
 #define OFL_OPT_WARP_PATH 1
 /*   OFL_OPT_WARP_SHEAR: 1 = the LDS-staged warp kernel stages a y-sheared box (default), 0 = plain bounding box
  *   (speed only; the results are identical). */

@@ -19,7 +19,7 @@
 #pragma clang fp contract(off)
 
 // the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
-int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void* stream);
+int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int rows, void* stream);   // rows: per-row extents (warp_bwd_rows_kernel) where they apply
 int ofl_wide_launch_chan(const void* params, int valid, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles
 
 namespace {
@@ -376,7 +376,7 @@ __device__ __forceinline__ int lds_pitch(int n) {   // smallest P >= n with P % 
 }
 
 struct LdsCoords { float sx[4], sy[4]; };                              // un-normalised sample positions of 4 pixels
-struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits, interior, clipped; };   // wave-uniform staging geometry (interior: box staged, every tap of every pixel inside the image; clipped: only the first bh rows of an oversize box are staged)
+struct LdsBox { int bx0, miny, cw, Pp, bh, nch, sq, cbase; bool fits, interior, clipped; const uint32_t* ent; int org, cxo; };   // wave-uniform staging geometry (interior: box staged, every tap of every pixel inside the image; clipped: only the first bh rows of an oversize box are staged)
 
 // Y-SHEARED box: a 32-wide tile under a flow with dv/dx != 0 touches a slanted band of source rows, and a plain bounding
 // box wastes the two triangles above and below it.  Chunk column c (4 pixels) of the staged box therefore starts at image
@@ -595,7 +595,20 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
 // with its upstream gradient `gq` into ATen's gix / giy sums (grid_sampler_2d_backward), chained through the
 // un-normalisation, normalise_coords and `grid - flow` exactly as autograd does -- same expressions, same order as the
 // one-pixel-per-lane kernel of ofl_aux_kernels.hip (the two are compared bit for bit); outv[k] = (d/du, d/dv, -, -).
-template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, bool GRAD = false, bool CLIP = false, typename WP = WarpParams>
+constexpr int kRowTab = 64;                    // rows of a tile's row table (warp_bwd_rows_kernel)
+#ifndef OFL_ROWS_DEDUPE
+#define OFL_ROWS_DEDUPE 1
+#endif
+#ifndef OFL_ROWS_PAD
+#define OFL_ROWS_PAD 0        // 1: rows padded to the rectangle's pitch rule -- measured slower everywhere (+2 ... 6 %: more LDS, no fewer conflicts -- the rows' own start columns already scatter them)
+#endif
+#ifndef OFL_ROWS_STAMPS
+#define OFL_ROWS_STAMPS 0
+#endif
+#ifndef OFL_ROWS_SCHED_BARRIER
+#define OFL_ROWS_SCHED_BARRIER 0
+#endif
+template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, bool GRAD = false, bool CLIP = false, typename WP = WarpParams, bool ROWS = false>
 __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                                                 const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                                 const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
@@ -616,6 +629,49 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
         const bool y0 = INTERIOR || (uint32_t)yi < (uint32_t)h, y1 = INTERIOR || (uint32_t)(yi + 1) < (uint32_t)h;
         const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
         f4 tv[4];
+        if (ROWS) {
+#if OFL_ROWS_SCHED_BARRIER
+            if ((k % OFL_ROWS_SCHED_BARRIER) == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);   // (bounds the taps in flight: the kernel sits at the register limit)
+#endif
+            // ROW TABLE (warp_bwd_rows_kernel): image rows yi, yi + 1 each have their own start chunk and length; entry = byte address
+            // of the row's slot for chunk (cxo + 128), biased, | 16 * length << 16 (0: row not staged; 1: a row without valid taps)
+            const int yr = yi - B.org;
+            const bool inr = INTERIOR || (uint32_t)yr < (uint32_t)(kRowTab - 1);
+            const int yrc = inr ? yr : 0;
+            const uint32_t e0 = B.ent[yrc], e1 = B.ent[yrc + 1];
+            const bool staged = INTERIOR || (inr && e0 != 0u && e1 != 0u) || !(ok[0] || ok[1] || ok[2] || ok[3]);
+            if (staged) {
+                const uint32_t m0 = (uint32_t)xi & 3u, m1 = (uint32_t)(xi + 1) & 3u;
+                const int q0 = (((xi >> 2) - B.cxo) << 4) - 4096, q1 = ((((xi + 1) >> 2) - B.cxo) << 4) - 4096;
+                const int si[4] = {ok[0] ? (int)(e0 & 0xffffu) + (int)__umul24(m0, e0 >> 16) + q0 : 0, ok[1] ? (int)(e0 & 0xffffu) + (int)__umul24(m1, e0 >> 16) + q1 : 0,
+                                   ok[2] ? (int)(e1 & 0xffffu) + (int)__umul24(m0, e1 >> 16) + q0 : 0, ok[3] ? (int)(e1 & 0xffffu) + (int)__umul24(m1, e1 >> 16) + q1 : 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tv[j] = *reinterpret_cast<const f4*>(smem + si[j]);
+            }
+            if (!staged) {
+                // (a row outside the table or beyond the block's chunk budget: the pixel's taps from global memory, as for an oversize box)
+                const int xc = min(max(xi, 0), w - 2);
+                const int ew = xi - xc, ee = xi + 1 - xc;
+                const int yrr[2] = {min(max(yi, 0), h - 1), min(max(yi + 1, 0), h - 1)};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t og = (uint32_t)(yrr[r] * w + xc);
+                    f4 tw = {0.f, 0.f, 0.f, 0.f}, te = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const f2 pr = ld2(sb + c * hw + og);
+                        tw[c] = ew == 1 ? pr[1] : pr[0]; te[c] = ee == 1 ? pr[1] : pr[0];
+                    }
+                    if (VALID) {
+                        const uint32_t m2 = sm ? ld16(sm + og) : 0x0101u;
+                        tw[3] = ((ew == 1 ? m2 >> 8 : m2) & 0xffu) != 0u ? 1.0f : 0.0f;
+                        te[3] = ((ee == 1 ? m2 >> 8 : m2) & 0xffu) != 0u ? 1.0f : 0.0f;
+                    }
+                    tv[2 * r] = ok[2 * r] ? tw : (f4){0.f, 0.f, 0.f, 0.f};
+                    tv[2 * r + 1] = ok[2 * r + 1] ? te : (f4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
         const int yr = yi - B.miny;   // row in the sheared box, per tap column
         const int ra = yr - lds_shear(xi >> 2, B.sq), rb = yr - lds_shear((xi + 1) >> 2, B.sq);
         // (clipped box: a pixel whose lower taps fall below the staged rows takes the global path below, the others the LDS)
@@ -666,6 +722,7 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                 tv[j] = t;
             }
         }
+        }
         if (GRAD) {
             float gix = 0.0f, giy = 0.0f;
 #pragma unroll
@@ -686,13 +743,13 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
     }
 }
 
-template <int NC, bool VALID, bool SUB = false, typename TS = float, bool GRAD = false, bool CLIP = false, typename WP = WarpParams>
+template <int NC, bool VALID, bool SUB = false, typename TS = float, bool GRAD = false, bool CLIP = false, typename WP = WarpParams, bool ROWS = false>
 __device__ __forceinline__ void lds_gather(const WP& p, uint32_t hw,
                                            const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
                                            const LdsCoords& T, const LdsBox& B, const unsigned char* smem, f4 (&outv)[4],
                                            const float* __restrict__ sbb = nullptr, const f4* gq = nullptr) {
-    if (B.interior) lds_gather_impl<NC, VALID, true, SUB, TS, GRAD, false>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
-    else lds_gather_impl<NC, VALID, false, SUB, TS, GRAD, CLIP>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
+    if (B.interior) lds_gather_impl<NC, VALID, true, SUB, TS, GRAD, false, WP, ROWS>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
+    else lds_gather_impl<NC, VALID, false, SUB, TS, GRAD, CLIP, WP, ROWS>(p, hw, sb, sm, T, B, smem, outv, sbb, gq);
 }
 
 // the fused addend of a tile (mode 3), loaded ahead of younger loads and stores: the wait for it must not cover them
@@ -966,6 +1023,353 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
 #if OFL_WARP_KARG
 #undef p
 #endif
+}
+
+// ROW TABLES (OFL_WARP_ROWS; VERDICT r4 item 2: "per-row extents of the staged box").  The column kernel above stages ONE y-sheared
+// rectangle per tile; under the bench flow (sigma 8) it holds 1.65 source pixels per output pixel of a 64 x 16 tile, and a rougher flow
+// overflows it (10.8 % of the tiles at sigma 12, 27.5 % at sigma 16).  Here every source ROW the tile touches has its own first chunk
+// and length (tools/box_rows_model_wide3.py: 1.27 staged pixels per output pixel at sigma 8, 1.35 / 1.45 at sigma 12 / 16, and what does
+// not fit is a handful of PIXELS, not tiles):
+//   post   every lane puts the chunk range of its 4 pixels' taps on the rows they touch: ds_min / ds_max on a 64-row table whose
+//          first row `org` is an ESTIMATE (the flow at 3 x 3 points of the tile, scalar loads, minus a margin) -- so that no
+//          block-wide reduction has to come first.  A row outside the table is dropped and flagged.
+//   scan   after the barrier that publishes the previous tile's staged data anyway, every wave reads the table (lane = row),
+//          clips the ranges to the frame, prefix-sums the lengths (DPP) and writes one 32-bit ENTRY per row for the gather:
+//          biased byte address of the row's first slot | 16 * length << 16.  Rows beyond the block's 768 chunks are not staged.
+//   issue  chunk i of the packed rows -> thread i (dense, 3 rounds): the row of a wave's first chunk from a ballot, the rows of
+//          its other 63 by a short uniform loop over the following rows' sums (v_readlane), the row's start / length by ds_bpermute.
+//   gather two entries per pixel (rows yi, yi + 1: one ds_read2_b32), address = entry + (x & 3) * length16 + 16 * (x >> 2): no shear,
+//          no multiply by a pitch.  A pixel with an unstaged row takes its taps from global memory (as for an oversize box).
+// Same expressions per pixel as the column kernel: bit-identical.  Lean launches on 64 x 16 tiles only (ofl_wide_launch_column).
+#ifndef OFL_WARP_ROWS
+#define OFL_WARP_ROWS 1
+#endif
+constexpr int kRowChunks = kLdsIters * kLdsNT - 16;             // chunks (4 pixels, one 16-byte slot each) a block stages per tile (3 blocks per CU: 53.3 KB with the tables below)
+constexpr int kRowsLdsBytes = 16 * (2 + 4 * kRowChunks);        // slot 0 (zeros: invalid taps) + the packed rows + a spare slot (rows_extra)
+constexpr int kRowMargin = 8;
+struct RowTabs { int tmin[2][kRowTab + 1]; int tmax[2][kRowTab + 1]; uint32_t ent[2][kRowTab]; uint8_t start[2][kRowChunks]; };   // ([kRowTab]: "a post was dropped"; start[i]: 1 + the row whose first chunk is chunk i, else 0)
+struct RowGeo { int org, cxo, tot; bool interior; };            // wave-uniform
+struct RowScan { int incl, sc, a; };                         // lane = row: chunks up to and including this row; the same | padded chunks << 16; first chunk | length << 16
+__device__ __forceinline__ int rows_pitch(int cw) { return OFL_ROWS_PAD ? (cw ? lds_pitch(4 * cw) >> 2 : 0) : cw; }   // LDS chunks (4 slots) a row of cw chunks occupies
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// first table row and reference chunk column of the T tiles of a column, from the flow at 3 x 3 points of each: ONE vector load
+// (tile k in the 16 lanes of DPP row k: lanes 0..8 its nine samples of v, lane 9 a sample of u), a row minimum, v_readlane.
+// (First cut: 10 scalar loads per tile.  The compiler chained them -- load, wait, min, next load -- and the 40 round trips were 30 %
+// of a block's life in the phase stamps.)  Issued before the flow loads: older in the vmcnt queue, waited for without them.
+template <int T, typename WP>
+__device__ __forceinline__ float rows_origins_load(const WP& p, const float* __restrict__ fu, uint32_t hw, int tx, int tyg) {
+    static_assert(T <= 4, "one DPP row per tile of the column");
+    const int l = threadIdx.x & 63, k = l >> 4, j = min(l & 15, 9);
+    const int w = p.w, h = p.h;
+    const int sy = j < 9 ? j / 3 : 1, sx = j < 9 ? j % 3 : 0;
+    const int x = min(tx * (kLdsTWQ * 4) + (sx == 0 ? 0 : sx == 1 ? kLdsTWQ * 2 : kLdsTWQ * 4 - 1), w - 1);
+    const int y = min((tyg * T + min(k, T - 1)) * kLdsTH + (sy == 0 ? 0 : sy == 1 ? kLdsTH / 2 : kLdsTH - 1), h - 1);
+    const float f = fu[(j < 9 ? hw : 0u) + (uint32_t)(y * w + x)];
+    return (j < 9 ? (float)y : (float)x) - p.flow_sign * f;          // sample row (lanes 0..8) / sample column (lane 9 and its duplicates)
+}
+template <int T, typename WP>
+__device__ __forceinline__ void rows_origins(const WP& p, float s, int (&org)[T], int (&cxo)[T]) {
+    const int j = threadIdx.x & 15;
+    float m = j < 9 ? s : 3.0e38f;
+#define OFL_FMIN_DPP(ctrl) m = fminf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), (ctrl), 0xf, 0xf, false)))
+    OFL_FMIN_DPP(0xB1); OFL_FMIN_DPP(0x4E); OFL_FMIN_DPP(0x141); OFL_FMIN_DPP(0x140);
+#undef OFL_FMIN_DPP
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const float mn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16 * k));
+        const float xl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16 * k + 9));
+        org[k] = (int)floorf(__builtin_amdgcn_fmed3f(mn, -2.0f, (float)p.h)) - kRowMargin;
+        cxo[k] = ((int)floorf(__builtin_amdgcn_fmed3f(xl, -2.0f, (float)p.w)) >> 2) + 16;
+    }
+}
+
+template <typename WP>
+__device__ __forceinline__ void rows_post(const WP& p, const LdsCoords& T, int org, int* tmin, int* tmax) {
+    const float wf = (float)p.w, hf = (float)p.h;
+    int xlo = 0x7fffffff, xhi = -0x7fffffff, ylo = 0x7fffffff, yhi = -0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // (the clamps of the gather: beyond [-2, size] every tap is out of range anyway)
+        const int xi = (int)__builtin_amdgcn_fmed3f(floorf(T.sx[k]), -2.0f, wf), yi = (int)__builtin_amdgcn_fmed3f(floorf(T.sy[k]), -2.0f, hf);
+        xlo = min(xlo, xi); xhi = max(xhi, xi); ylo = min(ylo, yi); yhi = max(yhi, yi);
+    }
+    const int cmin = xlo >> 2, cmax = (xhi + 1) >> 2;
+    const int a = ylo - org, b = yhi + 1 - org;             // the table rows this lane's taps touch
+    // Under a smooth flow the 16 lanes of a tile row all post to the same two or three rows (same-address LDS atomics).  A lane
+    // therefore leaves the minimum to its LEFT neighbour when that one touches the same rows and starts no later, and the maximum to
+    // its RIGHT neighbour likewise: by induction along the 16 lanes (a DPP row) somebody with the rows' extreme value posts it, whatever
+    // the flow -- under a smooth one only the two ends of each run do.  (Measured: -3 ... -6 % at sigma 0.5; the general form of the
+    // test -- the neighbour's range CONTAINS the row, per row -- cost sigma 8 +2 %.)
+#if OFL_ROWS_DEDUPE
+    const int ab = (a & 0xffff) | (b << 16);
+    const int abl = __builtin_amdgcn_update_dpp(1, ab, 0x111, 0xf, 0xf, false), cml = __builtin_amdgcn_update_dpp(0x7fffffff, cmin, 0x111, 0xf, 0xf, false);     // row_shr:1 (old: an empty range)
+    const int abr = __builtin_amdgcn_update_dpp(1, ab, 0x101, 0xf, 0xf, false), cxr = __builtin_amdgcn_update_dpp(-0x7fffffff, cmax, 0x101, 0xf, 0xf, false);    // row_shl:1
+    const bool pmin = !(abl == ab && cml <= cmin), pmax = !(abr == ab && cxr >= cmax);     // (the SAME rows: one compare, and what a smooth flow produces)
+#else
+    const bool pmin = true, pmax = true;
+#endif
+    bool drop = false;
+    int r = a;
+#pragma unroll
+    for (int j = 0; j < 2; ++j, ++r) {     // (a lane touches at least two rows)
+        if ((uint32_t)r < (uint32_t)kRowTab) {
+            if (pmin) atomicMin(&tmin[r], cmin);
+            if (pmax) atomicMax(&tmax[r], cmax);
+        } else drop = true;
+    }
+    for (; r <= b; ++r) {
+        if ((uint32_t)r < (uint32_t)kRowTab) {
+            if (pmin) atomicMin(&tmin[r], cmin);
+            if (pmax) atomicMax(&tmax[r], cmax);
+        } else drop = true;
+    }
+    if (drop) atomicMax(&tmax[kRowTab], 1);
+}
+
+template <bool ENT = true, typename WP>
+__device__ __forceinline__ void rows_scan(const WP& p, const int* tmin, const int* tmax, uint32_t* ent, uint8_t* start, int org, int cxo, RowGeo& G, RowScan& R) {
+    const int l = threadIdx.x & 63;
+    const int mn = tmin[l], mx = tmax[l], ov = tmax[kRowTab];
+    const int rowy = org + l, cmaxw = (p.w - 1) >> 2;
+    const int c0 = max(mn, 0), c1 = min(mx, cmaxw);
+    const bool any = mx >= mn, inimg = (uint32_t)rowy < (uint32_t)p.h;
+    const bool valid = any && c1 >= c0 && inimg;
+    const int cw = valid ? c1 - c0 + 1 : 0;
+    // two sums in one scan: chunks (low half: chunk i -> thread i) and chunks of LDS the rows occupy (high half; the same unless
+    // OFL_ROWS_PAD pads a row to the rectangle's pitch rule, rows_pitch)
+    const int cwc = min(cw, 1000);                                   // (a row that long is not staged; clamped, the 64 sums fit 16 bits)
+    const uint32_t sc = (uint32_t)wave_incl_scan(cwc | (rows_pitch(cwc) << 16));
+    const int incl = (int)(sc & 0xffffu), pincl = (int)(sc >> 16);
+    const int d = c0 - cxo;
+    const bool fit = incl <= kRowChunks && pincl <= kRowChunks;      // (both sums are monotonic: the rows that fit are a prefix)
+    const bool stg = valid && fit && (uint32_t)(d + 128) <= 256u;
+    const int nst = __popcll(__ballot(fit));
+    G.tot = nst ? __builtin_amdgcn_readlane(incl, nst - 1) : 0;
+    const uint32_t e = stg ? ((uint32_t)(16 * (1 + 4 * (pincl - rows_pitch(cwc)) - d + 256)) | ((uint32_t)(16 * cw) << 16)) : ((any && !valid) ? 1u : 0u);
+    const bool outside = any && (mn < 0 || mx > (p.w >> 2) - 1 || !inimg);      // a tap outside the frame (or in its last, partial chunk)
+    G.interior = (ov <= 0) && (__ballot((valid && !stg) || outside) == 0ull) && G.tot > 0;
+    if (ENT && threadIdx.x < 64) ent[l] = e;
+    // chunk -> row for rows_map: every wave marks the rows' first chunks itself (identical values from all four waves, and a wave
+    // reads its own writes in order: no barrier between this and rows_issue)
+    if (ENT && cw > 0 && fit) start[incl - cw] = (uint8_t)(l + 1);
+    R.incl = incl; R.sc = (int)sc; R.a = c0 | (cw << 16);
+    G.org = org; G.cxo = cxo;
+}
+
+// chunk i0 + lane of the packed rows -> global offset of its 4 pixels and its LDS slot | row length << 16 (-1: past the last chunk).
+// The row of a chunk = the last row that starts at or before it: the start marks of the wave's 64 chunks, a prefix maximum over the
+// lanes (DPP), and the row that holds the wave's first chunk (a ballot) as the carry.  (First cut: a uniform loop over the following
+// rows' sums with v_readlane -- 5 000 to 8 000 ticks per tile in the phase stamps, a third of the kernel.)
+__device__ __forceinline__ int wave_incl_max(int v) {               // (values >= 0)
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+template <typename WP>
+__device__ __forceinline__ void rows_map(const WP& p, const RowGeo& G, const RowScan& R, const uint8_t* start, int i0, uint32_t& g, int& slot) {
+    const int i = i0 + (int)(threadIdx.x & 63);
+    const int carry = __popcll(__ballot(R.incl <= i0)) + 1;          // 1 + the row that holds the wave's first chunk
+    const int row = max(wave_incl_max((int)start[min(i, kRowChunks - 1)]), carry) - 1;
+    const int rowc = min(row, kRowTab - 1);
+    const int ra = __builtin_amdgcn_ds_bpermute(rowc << 2, R.a), rs = __builtin_amdgcn_ds_bpermute(rowc << 2, R.sc);
+    const int cwr = ra >> 16, c0 = ra & 0xffff, cl = i - ((rs & 0xffff) - cwr), pb = (int)((uint32_t)rs >> 16) - rows_pitch(cwr);
+    const bool on = i < G.tot;
+    g = on ? (uint32_t)(__mul24(G.org + rowc, p.w) + ((c0 + cl) << 2)) : 0u;
+    slot = on ? ((1 + 4 * pb + cl) | (cwr << 16)) : -1;
+}
+
+// the first kRowIters * kLdsNT chunks are staged through registers, in flight while the previous tile is gathered ...
+constexpr int kRowIters = 2;
+template <int NC> struct RowStage { int slot[kRowIters]; f4 q[kRowIters][NC]; uint32_t mq[kRowIters]; };
+template <int NC, bool VALID, typename WP>
+__device__ __forceinline__ void rows_issue(const WP& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
+                                           const RowGeo& G, const RowScan& R, const uint8_t* start, RowStage<NC>& S) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#pragma unroll
+    for (int it = 0; it < kRowIters; ++it) {
+        S.slot[it] = -1;
+        const int i0 = it * kLdsNT + wv * 64;
+        if (it < OFL_WARP_UNCOND_ROUNDS || i0 < G.tot) {       // (the first round whatever the tile: countable loads, see lds_issue)
+            uint32_t g;
+            rows_map(p, G, R, start, i0, g, S.slot[it]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) S.q[it][c] = ld4(sb + c * hw + g);
+            if (VALID) S.mq[it] = ld32(sm ? sm + g : reinterpret_cast<const uint8_t*>(sb) + g);
+            else S.mq[it] = 0x01010101u;
+        }
+    }
+}
+
+template <int NC, bool VALID>
+__device__ __forceinline__ void rows_put(f4* lds, int slot, const f4 (&q)[NC], uint32_t mq) {
+    const int sl0 = slot & 0xffff, cwr = slot >> 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f4 sl = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sl[c] = q[c][k];
+        if (VALID) sl[3] = fminf((float)((mq >> (8 * k)) & 0xffu), 1.0f);   // non-zero byte -> 1
+        lds[sl0 + k * cwr] = sl;
+    }
+}
+
+template <int NC, bool VALID>
+__device__ __forceinline__ void rows_write(f4* lds, const RowStage<NC>& S, bool has_sm) {
+    if (threadIdx.x == 0) lds[0] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < kRowIters; ++it) {
+        if (S.slot[it] >= 0) rows_put<NC, VALID>(lds, S.slot[it], S.q[it], (VALID && !has_sm) ? 0x01010101u : S.mq[it]);
+    }
+}
+
+// ... and the chunks beyond them (a tile with more than 2 staged pixels per output pixel: 1 % of the tiles at sigma 8, 9 % at 12, 23 % at 16)
+// in a round of their own, loaded and written on the spot by the tile's own iteration: its registers are not live across a gather
+// (three rounds through registers put the kernel over the 168-register limit, and a scratch reload waits for every load in flight).
+// The table is still there (reset only after the gather): the scan is simply redone.
+template <int NC, bool VALID, typename WP>
+__device__ __forceinline__ void rows_extra(const WP& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
+                                           const int* tmin, const int* tmax, const uint8_t* start, const RowGeo& G, f4* lds) {
+    if (__builtin_expect(G.tot > kRowIters * kLdsNT, 0)) {
+        RowGeo G2; RowScan R;
+        rows_scan<false>(p, tmin, tmax, (uint32_t*)nullptr, (uint8_t*)nullptr, G.org, G.cxo, G2, R);     // (the start marks of this tile are still there)
+        const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        uint32_t g; int slot;
+        rows_map(p, G, R, start, kRowIters * kLdsNT + wv * 64, g, slot);
+        f4 q[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) q[c] = ld4(sb + c * hw + g);
+        const uint32_t mq = (VALID && sm) ? ld32(sm + g) : 0x01010101u;
+        // (no branch round the use of these loads: on a path that skipped their wait they would count as in flight at the join, and the
+        // compiler's next waits -- vmcnt(2), (1), (0) -- then wait for the NEXT tile's flow instead: a lane without a chunk writes a spare slot)
+        rows_put<NC, VALID>(lds, slot >= 0 ? slot : 1 + 4 * kRowChunks, q, mq);
+    }
+}
+
+#if OFL_ROWS_STAMPS
+__device__ unsigned long long g_rows_stamp[16];
+#define OFL_RS(i_) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_[i_] += t_ - last_; last_ = t_; } while (0)
+#else
+#define OFL_RS(i_)
+#endif
+template <int T, int NC, bool VALID>
+__global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpParams p_by_value) {
+    WarpParamsLeanK* pp = (WarpParamsLeanK*)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*pp)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ RowTabs rt;
+    int tx, tyg, n;
+    if (!decode_tile(p, tx, tyg, n)) return;
+    const int tid = threadIdx.x, lx = tid % kLdsTWQ, ly = tid / kLdsTWQ;
+    const int w = p.w, h = p.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    const float* __restrict__ fu = p.flow + n * p.flow_bs;
+    const float* __restrict__ sb = p.src + n * p.src_bs;
+    const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
+    const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
+    const int xq = min(tx * (kLdsTWQ * 4) + lx * 4, w - 4);
+    f4 uu[T], vv[T];
+    uint32_t fmk[T];
+    auto load_flow = [&](int k) {
+        const uint32_t pix = (uint32_t)(min((tyg * T + k) * kLdsTH + ly, h - 1) * w + xq);
+        uu[k] = ld4nt(fu + pix); vv[k] = ld4nt(fu + hw + pix);
+        fmk[k] = 0x01010101u;
+        if (VALID) fmk[k] = ld32(fm ? fm + pix : reinterpret_cast<const uint8_t*>(fu) + pix);
+    };
+    // the flow-mask word of a tile is loaded with its flow (two tiles ahead: a countable load) but used last, by its stores: it waits
+    // in the LDS, not in a register -- at the register limit (168) the allocator spilled exactly these words, and a scratch reload is a
+    // VMEM operation whose wait (vmcnt(0)) also waits for the next tile's staging loads
+    __shared__ uint32_t park[2][kLdsNT];
+    auto fm_park = [&](int k) { if (VALID) park[k & 1][tid] = fmk[k]; };
+    auto fmw = [&](int k) -> uint32_t { return (VALID && !fm) ? 0x01010101u : (VALID ? park[k & 1][tid] : 0x01010101u); };
+    auto reset = [&](int t) { if (tid <= kRowTab) { rt.tmin[t][tid] = 0x7fffffff; rt.tmax[t][tid] = -0x7fffffff; } };
+    auto clear_starts = [&](int t) { if (tid < kRowChunks / 4) reinterpret_cast<uint32_t*>(rt.start[t])[tid] = 0u; };     // (before the barrier that precedes the tile's scan; double-buffered: rows_extra still reads the other one)
+#if OFL_ROWS_STAMPS
+    unsigned long long acc_[12] = {}, last_ = __builtin_amdgcn_s_memtime();
+#endif
+    const float osample = rows_origins_load<T>(p, fu, hw, tx, tyg);
+    load_flow(0);
+    if (T > 1) load_flow(1);
+    reset(0); reset(1);                   // tile k posts to table k & 1; it is reset for tile k + 2 while tile k is gathered
+    clear_starts(0);
+    int org[T], cxo[T];
+    rows_origins<T>(p, osample, org, cxo);
+    OFL_RS(10);
+    f4* lds = reinterpret_cast<f4*>(smem);
+    LdsCoords Tc[T];
+    RowGeo Gx[T];
+    RowStage<NC> S;
+    RowScan R;
+    lds_barrier();
+    OFL_RS(11);
+    lds_coords_box_a<false>(p, tx, tyg * T, uu[0], vv[0], 0, Tc[0], (int (*)[4])nullptr);
+    OFL_RS(1);
+    rows_post(p, Tc[0], org[0], rt.tmin[0], rt.tmax[0]);
+    fm_park(0);
+    OFL_RS(2);
+    lds_barrier();
+    OFL_RS(4);
+    rows_scan(p, rt.tmin[0], rt.tmax[0], rt.ent[0], rt.start[0], org[0], cxo[0], Gx[0], R);
+    OFL_RS(5);
+    rows_issue<NC, VALID>(p, sb, sm, hw, Gx[0], R, rt.start[0], S);
+    OFL_RS(6);
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        OFL_OPAQUE_S(pp);
+        const int tyk = tyg * T + k;       // (a tile past the bottom edge recomputes and re-stores the frame's last row: OFL_WARP_ALWAYS_T)
+        if (k + 1 < T) {
+            lds_coords_box_a<false>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], 0, Tc[k + 1], (int (*)[4])nullptr);
+            OFL_RS(1);
+            rows_post(p, Tc[k + 1], org[k + 1], rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1]);
+            fm_park(k + 1);
+            OFL_RS(2);
+        }
+        if (k + 2 < T) load_flow(k + 2);
+        rows_write<NC, VALID>(lds, S, sm != nullptr);
+        rows_extra<NC, VALID>(p, sb, sm, hw, rt.tmin[k & 1], rt.tmax[k & 1], rt.start[k & 1], Gx[k], lds);
+        if (k + 1 < T) clear_starts((k + 1) & 1);
+        OFL_RS(3);
+        lds_barrier();
+        OFL_RS(4);
+        if (k + 1 < T) {
+            rows_scan(p, rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1], rt.ent[(k + 1) & 1], rt.start[(k + 1) & 1], org[k + 1], cxo[k + 1], Gx[k + 1], R);
+            OFL_RS(5);
+            rows_issue<NC, VALID>(p, sb, sm, hw, Gx[k + 1], R, rt.start[(k + 1) & 1], S);
+            OFL_RS(6);
+        }
+        LdsBox B;
+        B.fits = true; B.clipped = false; B.interior = Gx[k].interior; B.ent = rt.ent[k & 1]; B.org = Gx[k].org; B.cxo = Gx[k].cxo;
+        f4 outv[4];
+        const f4 none[NC] = {};
+        lds_gather<NC, VALID, false, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[k], B, smem, outv);
+        OFL_RS(7);
+        lds_store<NC, VALID, false, false, float>(p, tx, tyk, n, hw, fmw(k), outv, none);
+        OFL_RS(8);
+        if (k + 1 >= T) break;
+        if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's scan, two barriers ago)
+        lds_barrier();
+        OFL_RS(9);
+    }
+#if OFL_ROWS_STAMPS
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_rows_stamp[i], acc_[i]);
+        atomicAdd(&g_rows_stamp[15], 1ull);
+    }
+#endif
+#undef p
 }
 
 // MANY CHANNELS (C >= 4; Flow.apply of an N-C-H-W feature tensor, utils.py:469-555): ONE launch for all of them.  A block owns one
@@ -1383,7 +1787,7 @@ struct SplatParams {
     static constexpr bool kLean = false;
 };
 // The COMMON CASE as a type: the same bytes read as SplatParamsLean promise the gather path that the call has a flow (not positions),
-// no flow window, a width that is a multiple of 4, no rounding and no raw sums -- `SP::kLean` folds those run-time switches (and the
+// no flow window, a width that is a multiple of 4 and no rounding -- `SP::kLean` folds those run-time switches (and the
 // scalar loads, compares and branches they cost per use) out of the lean instantiations of the bin and gather kernels.  The host
 // picks them when the promises hold (splat_tiled_impl): apply 's' -6.5 %, switch_ref -8.7 % (profiles/r5_splat_lean.txt).
 struct SplatParamsLean : SplatParams { static constexpr bool kLean = true; };
@@ -1391,7 +1795,7 @@ struct SplatParamsLean : SplatParams { static constexpr bool kLean = true; };
 #define OFL_SP_WINDOW(s_) (!std::remove_reference<decltype(s_)>::type::kLean && (s_).fw != 0)
 #define OFL_SP_WREM(s_) (std::remove_reference<decltype(s_)>::type::kLean ? 0 : ((s_).w & 3))
 #define OFL_SP_HAS_FLOW(s_) (std::remove_reference<decltype(s_)>::type::kLean || (s_).flow != nullptr)
-#define OFL_SP_RAW(s_) (!std::remove_reference<decltype(s_)>::type::kLean && (s_).raw != 0)
+#define OFL_SP_RAW(s_) ((s_).raw != 0)          /* (run-time in the lean kernels too: the warp's backward pass -- ofl_splat_sum_f32 -- is a lean call) */
 #define OFL_SP_ROUND(s_) (std::remove_reference<decltype(s_)>::type::kLean ? (int32_t)OFL_ROUND_NONE : (s_).round_mode)
 
 // flow window (padded apply): offset of frame pixel (x, y) in a flow-geometry plane (clamped: replicate) and whether it is inside
@@ -3005,13 +3409,33 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 }  // namespace
 
 // This translation unit (ofl_warp_wide.hip) provides ONE thing: the column kernel of a large plain warp on 64 x 16 tiles.
-int ofl_wide_launch_column(const void* params, int nc, int valid, int add, void* stream) {
+#if OFL_ROWS_STAMPS
+extern "C" __attribute__((visibility("default"))) int ofl_debug_rows_stamps(unsigned long long* out, int clear) {
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rows_stamp), sizeof(unsigned long long) * 16);
+    if (clear) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_rows_stamp), z, sizeof(z)); }
+    return 0;
+}
+#endif
+int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int rows, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
     const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
     hipStream_t st = (hipStream_t)stream;
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
     const bool lean = warp_is_lean(q);
+    if (OFL_WARP_ROWS && rows && lean && !add) {                  // per-row extents instead of one sheared rectangle (warp_bwd_rows_kernel)
+#define OFL_ROWS_CASE(NC)                                                                                                    \
+        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, NC, true>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);   \
+        else hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, NC, false>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        switch (nc) {
+            case 1: OFL_ROWS_CASE(1) break;
+            case 2: OFL_ROWS_CASE(2) break;
+            default: OFL_ROWS_CASE(3) break;
+        }
+#undef OFL_ROWS_CASE
+        return (int)hipGetLastError();
+    }
 #if OFL_WARP_COL_ADD >= 2
     if (add && OFL_WARP_REUSE && q.add_is_flow) {
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
@@ -3072,7 +3496,7 @@ int ofl_wide_launch_chan(const void* params, int valid, void* stream) {
     return (int)hipGetLastError();
 }
 #else
-int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests), 5 = auto but more than 3 channels as separate launches of 3 (tests: the channel-loop kernel against them)
+int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests), 5 = auto but more than 3 channels as separate launches of 3 (tests: the channel-loop kernel against them), 6 = auto but the column kernel's sheared rectangle instead of per-row extents (tests, A/B)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
@@ -3103,7 +3527,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     if (OFL_WARP_COL_ADD && kLdsT > 2 && add && NC == 2 && !p.flow_flags) {
         WarpParams q = p;
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
-        if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, (void*)st);
+        if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 0, (void*)st);
         if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
             if (warp_is_lean(q)) {
                 if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
@@ -3148,7 +3572,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     WarpParams q = p;
     const unsigned g = (kLdsT > 2 && !add && !p.flow_flags) ? warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) : 0u;
     if (g >= kColumnMinGroups && g_warp_path != 3) {
-        if (OFL_WARP_WIDE) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 0, (void*)st);    // 64 x 16 tiles: -1.9 % (see kLdsNT)
+        if (OFL_WARP_WIDE) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 0, g_warp_path != 6, (void*)st);    // 64 x 16 tiles: -1.9 % (see kLdsNT)
         if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
@@ -3251,7 +3675,7 @@ inline unsigned fallback_resident_blocks(const void* kernel, int which) {
 
 // the promises of SplatParamsLean hold for this call (the lean instantiations exist for 2 and 3 channels)
 inline bool splat_is_lean(const SplatParams& s) {
-    return OFL_SP_LEAN && s.flow != nullptr && s.fw == 0 && (s.w & 3) == 0 && s.raw == 0 && s.round_mode == OFL_ROUND_NONE;
+    return OFL_SP_LEAN && s.flow != nullptr && s.fw == 0 && (s.w & 3) == 0 && s.round_mode == OFL_ROUND_NONE;
 }
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
@@ -3307,10 +3731,10 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 30; }   // 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 31; }   // 31: OFL_OPT_WARP_PATH value 6 (the sheared rectangle instead of per-row extents: warp_bwd_rows_kernel is the default for large lean launches); 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
-    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 5) { g_warp_path = value; return OFL_OK; }
+    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 6) { g_warp_path = value; return OFL_OK; }
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }

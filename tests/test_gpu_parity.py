@@ -191,7 +191,7 @@ def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, frame, dev):
                 dict(flow_mask=fmk, want_valid=True, addend=add, a_sign=-1.0, g_sign=1.0)]
     for kw in kws:
         outs = []
-        for path in (0, 1, 3, 4):               # auto (= columns of four here), generic, two tiles per block, one tile per block
+        for path in (0, 1, 3, 4, 6):            # auto (= columns of four here: per-row extents when the launch is lean, W % 4 == 0), generic, two tiles per block, one tile per block, columns of four with the sheared rectangle
             _native.set_warp_path(path)
             try:
                 outs.append(_native.warp_bwd(flow, src, **kw))
@@ -214,6 +214,74 @@ def test_oversize_boxes_staged_in_part_stay_exact(c, stretch, frame, dev):
         assert np.array_equal(outs[0][0][:k].cpu().numpy(), exp, equal_nan=True)
         if kw.get("want_valid"):
             assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > 0.99999) & fmk[:k].cpu().numpy())
+
+
+@pytest.mark.parametrize("kind", ["rotation", "waves", "zoom_in", "steep_rows", "steep_columns", "outward", "blocks"])
+@pytest.mark.parametrize("c", [1, 2, 3])
+def test_row_tables_on_strongly_curved_flows(kind, c, dev):
+    """warp_bwd_rows_kernel (per-row extents of the staged box: every source row a 64 x 16 tile touches has its own first chunk and
+    length in a 64-row table about an ESTIMATED origin) against the sheared rectangle (path 6), the generic kernel (path 1) and the
+    oracle, on flows that make the rows of a tile differ as much as they can: a rotation (every row another start), waves (curved
+    bands), a zoom-in (few short rows), slopes steep enough for rows to fall outside the table and for lanes to span many rows, a
+    flow that leaves the frame, and per-block constants (discontinuities: more than 512 chunks -- the extra staging round -- and
+    more than the block's budget).  The batch is large enough for the launcher to pick the column kernel."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    h, w = 176, 256
+    n = 6912 // (((w + 31) // 32) * ((h + 63) // 64)) + 1
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    cx, cy = w / 2, h / 2
+    if kind == "rotation":
+        a = 0.45
+        u = (xs - cx) - ((xs - cx) * np.cos(a) - (ys - cy) * np.sin(a))
+        v = (ys - cy) - ((xs - cx) * np.sin(a) + (ys - cy) * np.cos(a))
+    elif kind == "waves":
+        u = 9.0 * torch.sin(ys / 7.0) + 4.0 * torch.cos(xs / 5.0)
+        v = 14.0 * torch.sin(xs / 9.0) + 3.0 * torch.sin(ys / 4.0)
+    elif kind == "zoom_in":
+        u = (xs - cx) * 0.7
+        v = (ys - cy) * 0.7
+    elif kind == "steep_rows":
+        u = torch.zeros_like(xs)
+        v = (xs - cx) * 1.3 + 6.0 * torch.sin(ys / 5.0)
+    elif kind == "steep_columns":
+        u = (ys - cy) * 2.2
+        v = 5.0 * torch.sin(xs / 6.0)
+    elif kind == "outward":
+        u = (xs - cx) * 0.2 - 180.0
+        v = (ys - cy) * 0.3 + 120.0
+    else:
+        g0 = torch.Generator().manual_seed(3)
+        lo = torch.randn(2, h // 8, w // 8, generator=g0) * 25.0
+        u, v = [torch.nn.functional.interpolate(t[None, None], size=(h, w), mode='nearest')[0, 0] for t in lo]
+    flow = (torch.stack([u, v])[None] + _smooth(n, h, w, 1.5, 29, torch.device('cpu'))).contiguous().to(dev)
+    g = torch.Generator().manual_seed(13)
+    src = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    fmk = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    for kw in (dict(src_mask=sm, flow_mask=fmk, want_valid=True), dict(), dict(want_valid=True), dict(flow_sign=-1.0, src_mask=sm, want_valid=True)):
+        outs = []
+        for path in (0, 6, 1):
+            _native.set_warp_path(path)
+            try:
+                outs.append(_native.warp_bwd(flow, src, **kw))
+            finally:
+                _native.set_warp_path(0)
+        for other in outs[1:]:
+            for a_, b_ in zip(outs[0], other):
+                assert (a_ is None) == (b_ is None)
+                if a_ is not None:
+                    assert torch.equal(a_, b_)
+        k = 2
+        s_ = src[:k].cpu().numpy()
+        if kw.get("want_valid"):
+            m = sm[:k].cpu().numpy().astype(np.float32) if "src_mask" in kw else np.ones((k, h, w), np.float32)
+            s_ = np.concatenate([s_, m[:, None]], 1)
+        gref = oracle.G(np.float32(kw.get("flow_sign", 1.0)) * flow[:k].cpu().numpy(), s_)
+        assert np.array_equal(outs[0][0][:k].cpu().numpy(), gref[:, :c], equal_nan=True)
+        if kw.get("want_valid"):
+            fm_ = fmk[:k].cpu().numpy() if "flow_mask" in kw else np.ones((k, h, w), bool)
+            assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > 0.99999) & fm_)
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260),
