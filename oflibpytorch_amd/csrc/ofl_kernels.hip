@@ -605,6 +605,9 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table (wa
 #ifndef OFL_ROWS_STAMPS
 #define OFL_ROWS_STAMPS 0
 #endif
+#ifndef OFL_WARP_ROWS_ADD
+#define OFL_WARP_ROWS_ADD 1
+#endif
 #ifndef OFL_ROWS_SCHED_BARRIER
 #define OFL_ROWS_SCHED_BARRIER 0
 #endif
@@ -1264,8 +1267,11 @@ __device__ unsigned long long g_rows_stamp[16];
 #else
 #define OFL_RS(i_)
 #endif
-template <int T, int NC, bool VALID>
+// ADD: the fused composition of mode 3 (flow_class.py:1804-1808): out = a_sign * flow + g_sign * warped, the addend being the flow
+// operand itself (add_is_flow) -- its registers are kept instead of the tile's positions, which are formed again at gather time.
+template <int T, int NC, bool VALID, bool ADD = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpParams p_by_value) {
+    static_assert(!ADD || NC == 2, "ADD: flows");
     WarpParamsLeanK* pp = (WarpParamsLeanK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1308,7 +1314,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     rows_origins<T>(p, osample, org, cxo);
     OFL_RS(10);
     f4* lds = reinterpret_cast<f4*>(smem);
-    LdsCoords Tc[T];
+    LdsCoords Tc[ADD ? 1 : T];
     RowGeo Gx[T];
     RowStage<NC> S;
     RowScan R;
@@ -1330,9 +1336,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         OFL_OPAQUE_S(pp);
         const int tyk = tyg * T + k;       // (a tile past the bottom edge recomputes and re-stores the frame's last row: OFL_WARP_ALWAYS_T)
         if (k + 1 < T) {
-            lds_coords_box_a<false>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], 0, Tc[k + 1], (int (*)[4])nullptr);
+            lds_coords_box_a<false>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], 0, Tc[ADD ? 0 : k + 1], (int (*)[4])nullptr);
             OFL_RS(1);
-            rows_post(p, Tc[k + 1], org[k + 1], rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1]);
+            rows_post(p, Tc[ADD ? 0 : k + 1], org[k + 1], rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1]);
             fm_park(k + 1);
             OFL_RS(2);
         }
@@ -1351,11 +1357,11 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         }
         LdsBox B;
         B.fits = true; B.clipped = false; B.interior = Gx[k].interior; B.ent = rt.ent[k & 1]; B.org = Gx[k].org; B.cxo = Gx[k].cxo;
-        f4 outv[4];
-        const f4 none[NC] = {};
-        lds_gather<NC, VALID, false, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[k], B, smem, outv);
+        f4 outv[4], ad[NC] = {};
+        if (ADD) { lds_coords_box_a<false>(p, tx, tyk, uu[k], vv[k], 0, Tc[0], (int (*)[4])nullptr); ad[0] = uu[k]; ad[NC - 1] = vv[k]; }
+        lds_gather<NC, VALID, false, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[ADD ? 0 : k], B, smem, outv);
         OFL_RS(7);
-        lds_store<NC, VALID, false, false, float>(p, tx, tyk, n, hw, fmw(k), outv, none);
+        lds_store<NC, VALID, ADD, false, float>(p, tx, tyk, n, hw, fmw(k), outv, ad);
         OFL_RS(8);
         if (k + 1 >= T) break;
         if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's scan, two barriers ago)
@@ -3424,6 +3430,11 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     hipStream_t st = (hipStream_t)stream;
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
     const bool lean = warp_is_lean(q);
+    if (OFL_WARP_ROWS && rows && lean && add && nc == 2 && q.add_is_flow) {      // mode 3 (the addend is the flow operand) with per-row extents
+        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, 2, true, true>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        else hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, 2, false, true>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        return (int)hipGetLastError();
+    }
     if (OFL_WARP_ROWS && rows && lean && !add) {                  // per-row extents instead of one sheared rectangle (warp_bwd_rows_kernel)
 #define OFL_ROWS_CASE(NC)                                                                                                    \
         if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, NC, true>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);   \
@@ -3447,6 +3458,8 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
     }
+#else
+    if (add) return (int)hipErrorInvalidValue;     // (callers route an addend here only when the row-table kernel above takes it)
 #endif
 #define OFL_WIDE_CASE(NC)                                                                                                                   \
     if (lean) {                                                                                                                              \
@@ -3528,6 +3541,9 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         WarpParams q = p;
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
         if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 0, (void*)st);
+        // large launches of mode 3 proper: 64 x 16 tiles with per-row extents (warp_bwd_rows_kernel<.., ADD>)
+        if (OFL_WARP_ROWS_ADD && NC == 2 && p.add_is_flow && warp_is_lean(q) && g >= 6912u && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4)
+            return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 1, (void*)st);
         if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
             if (warp_is_lean(q)) {
                 if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);

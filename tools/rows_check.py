@@ -22,10 +22,19 @@ _, _, img, m1, m2, tm = bench.make_inputs(n, h, w, dev, 0)
 px = n * h * w
 
 
-def run(flow, path, timed=True, masks=True):
+f1 = bench.smooth_flow(n, h, w, 8.0, 1000, dev)
+
+
+def run(flow, path, timed=True, masks=True, op="apply"):
     _native.set_warp_path(path)
     fl = ofl.Flow(flow, 't', m2 if masks else None)
-    call = (lambda: fl.apply(img, target_mask=tm, return_valid_area=True)) if masks else (lambda: fl.apply(img))
+    if op == "apply":
+        call = (lambda: fl.apply(img, target_mask=tm, return_valid_area=True)) if masks else (lambda: fl.apply(img))
+    else:                                  # combine_with mode 3: the fused composition (the flow operand is the addend)
+        other = ofl.Flow(f1, 't', m1 if masks else None)
+        def call():
+            r = other.combine_with(fl, 3)
+            return (r.vecs, r.mask)
     out = call()
     t = 0.0
     if timed:
@@ -54,6 +63,13 @@ for s in args.sigmas:
     t6, t0 = sorted(t6s)[len(t6s) // 2], sorted(t0s)[len(t0s) // 2]
     print("sigma %4.1f  rectangle %.4f ms (%.1f %%)   row tables %.4f ms (%.1f %%)   %+.1f %%   identical: %s" % (
         s, t6, 35 * px / t6 / 8e7, t0, 35 * px / t0 / 8e7, 100 * (t0 / t6 - 1), same(o0, o6)), flush=True)
+    t6s, t0s = [], []
+    for _ in range(args.reps):
+        o6, t = run(f, 6, op="combine3"); t6s.append(t)
+        o0, t = run(f, 0, op="combine3"); t0s.append(t)
+    t6, t0 = sorted(t6s)[len(t6s) // 2], sorted(t0s)[len(t0s) // 2]
+    print("   mode 3   rectangle %.4f ms (%.1f %%)   row tables %.4f ms (%.1f %%)   %+.1f %%   identical: %s" % (
+        t6, 27 * px / t6 / 8e7, t0, 27 * px / t0 / 8e7, 100 * (t0 / t6 - 1), same(o0, o6)), flush=True)
 if not args.no_hostile:
     g = torch.Generator(device='cpu').manual_seed(5)
     f = bench.smooth_flow(n, h, w, 8.0, 5000, dev)
@@ -68,4 +84,6 @@ if not args.no_hostile:
         for masks in (True, False):
             o6, _ = run(fl, 6, timed=False, masks=masks); o0, t0 = run(fl, 0, timed=True, masks=masks)
             o1, _ = run(fl, 1, timed=False, masks=masks)
-            print("%-40s masks %-5s identical to the rectangle: %s, to the generic kernel: %s   (%.3f ms)" % (name, masks, same(o0, o6), same(o0, o1), t0), flush=True)
+            c6, _ = run(fl, 6, timed=False, masks=masks, op="combine3"); c0, _ = run(fl, 0, timed=False, masks=masks, op="combine3"); c1, _ = run(fl, 1, timed=False, masks=masks, op="combine3")
+            print("%-40s masks %-5s identical to the rectangle: %s, to the generic kernel: %s   (%.3f ms)   mode 3: %s, %s" % (
+                name, masks, same(o0, o6), same(o0, o1), t0, same(c0, c6), same(c0, c1)), flush=True)
