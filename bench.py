@@ -507,7 +507,7 @@ def main():
                        "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
                        "ms_per_step_max": round(per_step[-1], 4),
                        "value_min": round(gpx / (per_step[-1] * 1e-3) / 1e6, 1), "value_max": round(gpx / (per_step[0] * 1e-3) / 1e6, 1)},
-            "roofline": {"bound": "hbm", "kernel": "warp_bwd_lds_column_kernel<4,3,valid> (Flow.apply 't')",
+            "roofline": {"bound": "hbm", "kernel": "warp_bwd_rows_kernel<4,3,valid> (Flow.apply 't': four-tile columns of 64 x 16 tiles, per-row extents of the staged box)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": args.traffic_bytes,

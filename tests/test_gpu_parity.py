@@ -284,6 +284,51 @@ def test_row_tables_on_strongly_curved_flows(kind, c, dev):
             assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > 0.99999) & fm_)
 
 
+@pytest.mark.parametrize("kind", ["waves", "steep_rows", "blocks", "outward"])
+@pytest.mark.parametrize("c,valid", [(4, False), (7, True), (9, False)])
+def test_channel_loop_with_row_tables(kind, c, valid, dev):
+    """The channel-loop kernel of LARGE many-channel warps (64 x 16 tiles, >= 13 824 tiles) forms its per-tile invariants -- chunk map,
+    tap addresses -- from per-row extents (warp_bwd_lds_chan_kernel<.., ROWS>); against the same kernel on the sheared rectangle
+    (path 6), separate launches of 3 channels (path 5) and the generic kernel (path 1), bit for bit, on flows that curve, leave the
+    table, leave the frame or jump (rows beyond the block's chunk budget: those pixels take the global fix-up)."""
+    from oflibpytorch_amd import _native
+    h, w = 176, 256
+    n = 2 * 6912 // (((w + 31) // 32) * ((h + 15) // 16)) + 2
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    cx, cy = w / 2, h / 2
+    if kind == "waves":
+        u = 9.0 * torch.sin(ys / 7.0) + 4.0 * torch.cos(xs / 5.0)
+        v = 14.0 * torch.sin(xs / 9.0) + 3.0 * torch.sin(ys / 4.0)
+    elif kind == "steep_rows":
+        u = torch.zeros_like(xs)
+        v = (xs - cx) * 1.3 + 6.0 * torch.sin(ys / 5.0)
+    elif kind == "outward":
+        u = (xs - cx) * 0.2 - 180.0
+        v = (ys - cy) * 0.3 + 120.0
+    else:
+        g0 = torch.Generator().manual_seed(3)
+        lo = torch.randn(2, h // 8, w // 8, generator=g0) * 25.0
+        u, v = [torch.nn.functional.interpolate(t[None, None], size=(h, w), mode='nearest')[0, 0] for t in lo]
+    flow = (torch.stack([u, v])[None] + _smooth(n, h, w, 1.5, 31, torch.device('cpu'))).contiguous().to(dev)
+    g = torch.Generator().manual_seed(17)
+    src = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    fmk = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    kw = dict(src_mask=sm, flow_mask=fmk, want_valid=True) if valid else dict()
+    outs = []
+    for path in (0, 6, 5, 1):
+        _native.set_warp_path(path)
+        try:
+            outs.append(_native.warp_bwd(flow, src, **kw))
+        finally:
+            _native.set_warp_path(0)
+    for other in outs[1:]:
+        for a_, b_ in zip(outs[0], other):
+            assert (a_ is None) == (b_ is None)
+            if a_ is not None:
+                assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260),
                                    (2, 3, 37, 50), (2, 2, 33, 47), (1, 1, 19, 6), (1, 3, 70, 129), (2, 2, 40, 5),    # widths that are not multiples of 4
                                    (2, 4, 40, 64), (1, 7, 33, 45), (2, 6, 20, 36),                               # more than 3 channels: the channel-loop kernel (W % 4 == 0) / groups of 3

@@ -53,8 +53,13 @@ for C in a.channels:
         lib.ofl_set_option(1, 0)
         got = fn()
         t1 = timed(fn)
-        same = all(torch.equal(x, y) for x, y in zip(ref if isinstance(ref, tuple) else (ref,), got if isinstance(got, tuple) else (got,)))
+        lib.ofl_set_option(1, 6)               # the channel loop on the sheared rectangle (the default stages per-row extents)
+        rect = fn()
+        t6 = timed(fn)
+        lib.ofl_set_option(1, 0)
+        tup = lambda v: v if isinstance(v, tuple) else (v,)
+        same = all(torch.equal(x, y) for x, y in zip(tup(ref), tup(got))) and all(torch.equal(x, y) for x, y in zip(tup(rect), tup(got)))
         px = n * h * w
-        print("C=%3d %-5s B=%d sigma %.0f: launches of 3 %.3f ms (%.3f of 8 TB/s)   channel loop %.3f ms (%.3f of 8 TB/s)   %s"
-              % (C, name, n, a.sigma, t3, bpp * px / (t3 * 1e-3) / 8e12, t1, bpp * px / (t1 * 1e-3) / 8e12, "bit-identical" if same else "DIFFERENT"))
+        print("C=%3d %-5s B=%d sigma %.0f: launches of 3 %.3f ms (%.3f of 8 TB/s)   channel loop, rectangle %.3f ms (%.3f)   channel loop, row extents %.3f ms (%.3f of 8 TB/s)   %s"
+              % (C, name, n, a.sigma, t3, bpp * px / (t3 * 1e-3) / 8e12, t6, bpp * px / (t6 * 1e-3) / 8e12, t1, bpp * px / (t1 * 1e-3) / 8e12, "bit-identical" if same else "DIFFERENT"))
     del feat

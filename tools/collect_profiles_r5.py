@@ -9,7 +9,7 @@ DST = os.path.join(ROOT, "profiles")
 names = {"bench.json": "r5_bench.json", "bench_kernel_stats.csv": "r5_bench_kernel_stats.csv", "bench_pmc_summary.txt": "r5_bench_pmc_summary.txt",
          "bench_ops.txt": "r5_bench_ops_B16.txt", "ops_kernel_stats.csv": "r5_bench_ops_kernel_stats.csv", "bench_grad.txt": "r5_bench_grad_B16.txt",
          "splat_pmc_summary.txt": "r5_splat_gather_pmc_summary.txt",
-         "sigma_sweep.txt": "r5_sigma_sweep.txt", "bench_chan.txt": "r5_bench_chan.txt", "flags.txt": "r5_validation_wait.txt", "timeline.txt": "r5_step_timeline.txt"}
+         "sigma_sweep.txt": "r5_sigma_sweep.txt", "rows_check.txt": "r5_warp_row_extents_check.txt", "bench_chan.txt": "r5_bench_chan.txt", "flags.txt": "r5_validation_wait.txt", "timeline.txt": "r5_step_timeline.txt"}
 for a, b in names.items():
     p = os.path.join(SRC, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:
@@ -20,14 +20,14 @@ if os.path.exists(summ):
     text = open(summ).read()
     best = None
     for block in re.split(r"\n(?=\S)", text):
-        if "warp_bwd_lds_column_kernel<4, 3, true, false" in block:
+        if "warp_bwd_rows_kernel<4, 3, true" in block or "warp_bwd_lds_column_kernel<4, 3, true, false" in block:
             f = re.search(r"FETCH_SIZE\s+mean=([0-9.e+]+)", block)
             w = re.search(r"WRITE_SIZE\s+mean=([0-9.e+]+)", block)
             if f and w:
                 best = (float(f.group(1)), float(w.group(1)))
     if best:
         fetch_kib, write_kib = best
-        out = {"kernel": "warp_bwd_lds_column_kernel<4, 3, true, false, false, false, float, float, false>",
+        out = {"kernel": "warp_bwd_rows_kernel<4, 3, true, false>",
                "workload": "B=64 1080x1920 Flow.apply 't' C=3 + valid", "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                "fetch_correction": 2.0, "traffic_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024,
                "algorithmic_bytes_per_launch": 35 * 64 * 1080 * 1920,

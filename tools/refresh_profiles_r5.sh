@@ -43,6 +43,8 @@ done
 { echo "$BOX"; python3 tools/pmc_summary.py $O splat_; } > $O/splat_pmc_summary.txt 2>&1
 # roughness sweep of the warp, the validation wait, the step's timeline at B = 8
 { echo "$BOX"; for s in 0.5 2 4 8 12 16; do python tools/ab_warp.py --sigma $s --reps 2 --only 1 2>/dev/null | grep "shear on" | tail -1 | sed "s/^/sigma $s  /"; done; } > $O/sigma_sweep.txt
+# the row-table kernel against the sheared rectangle (one process, alternating, medians), identity on hostile flows
+{ echo "$BOX"; python tools/rows_check.py --batch 64 --reps 7 2>/dev/null; } > $O/rows_check.txt
 { echo "$BOX"; python tools/ab_flags.py; } > $O/flags.txt 2>/dev/null
 { echo "$BOX"; python tools/step_timeline.py; python tools/step_timeline.py --batch 64; } > $O/timeline.txt 2>/dev/null
 ls $O
