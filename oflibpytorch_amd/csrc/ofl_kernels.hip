@@ -608,6 +608,9 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table (wa
 #ifndef OFL_WARP_ROWS_ADD
 #define OFL_WARP_ROWS_ADD 1
 #endif
+#ifndef OFL_ROWS_T
+#define OFL_ROWS_T 4
+#endif
 #ifndef OFL_ROWS_SCHED_BARRIER
 #define OFL_ROWS_SCHED_BARRIER 0
 #endif
@@ -3490,15 +3493,18 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     hipStream_t st = (hipStream_t)stream;
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
     const bool lean = warp_is_lean(q);
+    constexpr int RT = OFL_ROWS_T;                                // tiles per column of the row-table kernel
     if (OFL_WARP_ROWS && rows && lean && add && nc == 2 && q.add_is_flow) {      // mode 3 (the addend is the flow operand) with per-row extents
-        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, 2, true, true>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);
-        else hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, 2, false, true>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        const unsigned gr = RT == TT ? g : warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
+        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);
         return (int)hipGetLastError();
     }
     if (OFL_WARP_ROWS && rows && lean && !add) {                  // per-row extents instead of one sheared rectangle (warp_bwd_rows_kernel)
+        const unsigned gr = RT == TT ? g : warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
 #define OFL_ROWS_CASE(NC)                                                                                                    \
-        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, NC, true>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);   \
-        else hipLaunchKernelGGL((warp_bwd_rows_kernel<TT, NC, false>), dim3(g), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);   \
+        else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, false>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);
         switch (nc) {
             case 1: OFL_ROWS_CASE(1) break;
             case 2: OFL_ROWS_CASE(2) break;
@@ -3877,7 +3883,7 @@ static int warp_bwd_impl(
         if (OFL_WARP_CHAN && c >= (valid ? 7 : 4) && (w & 3) == 0 && !addend && !src_b && !dst_flags && g_warp_path != 5) {
             WarpParams q = p;
             const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
-            if (OFL_WARP_CHAN_WIDE && g1 >= 2 * 6912u) return ofl_wide_launch_chan(&p, p.valid ? 1 : 0, g_warp_path != 6, (void*)st);
+            if (OFL_WARP_CHAN_WIDE && g1 >= 2 * 6912u) return ofl_wide_launch_chan(&p, p.valid ? 1 : 0, g_warp_path != 6 && c >= 7, (void*)st);   // (row extents from two channel groups on: with one group their set-up is not amortised -- C = 4: 0.148 against 0.138 ms)
             if (warp_is_lean(q)) {
                 if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
                 else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);

@@ -285,7 +285,7 @@ def test_row_tables_on_strongly_curved_flows(kind, c, dev):
 
 
 @pytest.mark.parametrize("kind", ["waves", "steep_rows", "blocks", "outward"])
-@pytest.mark.parametrize("c,valid", [(4, False), (7, True), (9, False)])
+@pytest.mark.parametrize("c,valid", [(8, False), (7, True), (9, False)])
 def test_channel_loop_with_row_tables(kind, c, valid, dev):
     """The channel-loop kernel of LARGE many-channel warps (64 x 16 tiles, >= 13 824 tiles) forms its per-tile invariants -- chunk map,
     tap addresses -- from per-row extents (warp_bwd_lds_chan_kernel<.., ROWS>); against the same kernel on the sheared rectangle
