@@ -611,6 +611,9 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table (wa
 #ifndef OFL_ROWS_T
 #define OFL_ROWS_T 4
 #endif
+#ifndef OFL_ROWS_ADD_REFORM
+#define OFL_ROWS_ADD_REFORM 0
+#endif
 #ifndef OFL_ROWS_SCHED_BARRIER
 #define OFL_ROWS_SCHED_BARRIER 0
 #endif
@@ -1317,7 +1320,8 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     rows_origins<T>(p, osample, org, cxo);
     OFL_RS(10);
     f4* lds = reinterpret_cast<f4*>(smem);
-    LdsCoords Tc[ADD ? 1 : T];
+    constexpr bool REFORM = ADD && OFL_ROWS_ADD_REFORM;      // mode 3: re-form a tile's positions from the flow registers at gather time instead of keeping them
+    LdsCoords Tc[REFORM ? 1 : T];
     RowGeo Gx[T];
     RowStage<NC> S;
     RowScan R;
@@ -1339,9 +1343,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         OFL_OPAQUE_S(pp);
         const int tyk = tyg * T + k;       // (a tile past the bottom edge recomputes and re-stores the frame's last row: OFL_WARP_ALWAYS_T)
         if (k + 1 < T) {
-            lds_coords_box_a<false>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], 0, Tc[ADD ? 0 : k + 1], (int (*)[4])nullptr);
+            lds_coords_box_a<false>(p, tx, tyk + 1, uu[k + 1], vv[k + 1], 0, Tc[REFORM ? 0 : k + 1], (int (*)[4])nullptr);
             OFL_RS(1);
-            rows_post(p, Tc[ADD ? 0 : k + 1], org[k + 1], rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1]);
+            rows_post(p, Tc[REFORM ? 0 : k + 1], org[k + 1], rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1]);
             fm_park(k + 1);
             OFL_RS(2);
         }
@@ -1361,8 +1365,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         LdsBox B;
         B.fits = true; B.clipped = false; B.interior = Gx[k].interior; B.ent = rt.ent[k & 1]; B.org = Gx[k].org; B.cxo = Gx[k].cxo;
         f4 outv[4], ad[NC] = {};
-        if (ADD) { lds_coords_box_a<false>(p, tx, tyk, uu[k], vv[k], 0, Tc[0], (int (*)[4])nullptr); ad[0] = uu[k]; ad[NC - 1] = vv[k]; }
-        lds_gather<NC, VALID, false, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[ADD ? 0 : k], B, smem, outv);
+        if (REFORM) lds_coords_box_a<false>(p, tx, tyk, uu[k], vv[k], 0, Tc[0], (int (*)[4])nullptr);
+        if (ADD) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; }
+        lds_gather<NC, VALID, false, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv);
         OFL_RS(7);
         lds_store<NC, VALID, ADD, false, float>(p, tx, tyk, n, hw, fmw(k), outv, ad);
         OFL_RS(8);
