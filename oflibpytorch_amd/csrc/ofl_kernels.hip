@@ -614,6 +614,9 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table (wa
 #ifndef OFL_ROWS_ADD_REFORM
 #define OFL_ROWS_ADD_REFORM 0
 #endif
+#ifndef OFL_WARP_ROWS_FLOWOPS
+#define OFL_WARP_ROWS_FLOWOPS 1      // the other flow-level instantiations on row tables too: another addend (modes 1-2, Flow.combine), src - src_b staging (mode 1 't'), the output's flag word
+#endif
 #ifndef OFL_ROWS_SCHED_BARRIER
 #define OFL_ROWS_SCHED_BARRIER 0
 #endif
@@ -668,7 +671,8 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                     f4 tw = {0.f, 0.f, 0.f, 0.f}, te = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
-                        const f2 pr = ld2(sb + c * hw + og);
+                        f2 pr = ld2(sb + c * hw + og);
+                        if (SUB) pr = pr - ld2(sbb + c * hw + og);                 // (mode 1 't': the warped field is flow - self)
                         tw[c] = ew == 1 ? pr[1] : pr[0]; te[c] = ee == 1 ? pr[1] : pr[0];
                     }
                     if (VALID) {
@@ -1203,9 +1207,9 @@ __device__ __forceinline__ void rows_map(const WP& p, const RowGeo& G, const Row
 // the first kRowIters * kLdsNT chunks are staged through registers, in flight while the previous tile is gathered ...
 constexpr int kRowIters = 2;
 template <int NC> struct RowStage { int slot[kRowIters]; f4 q[kRowIters][NC]; uint32_t mq[kRowIters]; };
-template <int NC, bool VALID, typename WP>
+template <int NC, bool VALID, bool SUB = false, typename WP>
 __device__ __forceinline__ void rows_issue(const WP& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
-                                           const RowGeo& G, const RowScan& R, const uint8_t* start, RowStage<NC>& S) {
+                                           const RowGeo& G, const RowScan& R, const uint8_t* start, RowStage<NC>& S, const float* __restrict__ sbb = nullptr) {
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #pragma unroll
     for (int it = 0; it < kRowIters; ++it) {
@@ -1215,7 +1219,10 @@ __device__ __forceinline__ void rows_issue(const WP& p, const float* __restrict_
             uint32_t g;
             rows_map(p, G, R, start, i0, g, S.slot[it]);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) S.q[it][c] = ld4(sb + c * hw + g);
+            for (int c = 0; c < NC; ++c) {
+                S.q[it][c] = ld4(sb + c * hw + g);
+                if (SUB) S.q[it][c] = S.q[it][c] - ld4(sbb + c * hw + g);          // (mode 1 't': the warped field is flow - self)
+            }
             if (VALID) S.mq[it] = ld32(sm ? sm + g : reinterpret_cast<const uint8_t*>(sb) + g);
             else S.mq[it] = 0x01010101u;
         }
@@ -1248,9 +1255,9 @@ __device__ __forceinline__ void rows_write(f4* lds, const RowStage<NC>& S, bool 
 // in a round of their own, loaded and written on the spot by the tile's own iteration: its registers are not live across a gather
 // (three rounds through registers put the kernel over the 168-register limit, and a scratch reload waits for every load in flight).
 // The table is still there (reset only after the gather): the scan is simply redone.
-template <int NC, bool VALID, typename WP>
+template <int NC, bool VALID, bool SUB = false, typename WP>
 __device__ __forceinline__ void rows_extra(const WP& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
-                                           const int* tmin, const int* tmax, const uint8_t* start, const RowGeo& G, f4* lds) {
+                                           const int* tmin, const int* tmax, const uint8_t* start, const RowGeo& G, f4* lds, const float* __restrict__ sbb = nullptr) {
     if (__builtin_expect(G.tot > kRowIters * kLdsNT, 0)) {
         RowGeo G2; RowScan R;
         rows_scan<false>(p, tmin, tmax, (uint32_t*)nullptr, (uint8_t*)nullptr, G.org, G.cxo, G2, R);     // (the start marks of this tile are still there)
@@ -1259,7 +1266,10 @@ __device__ __forceinline__ void rows_extra(const WP& p, const float* __restrict_
         rows_map(p, G, R, start, kRowIters * kLdsNT + wv * 64, g, slot);
         f4 q[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) q[c] = ld4(sb + c * hw + g);
+        for (int c = 0; c < NC; ++c) {
+            q[c] = ld4(sb + c * hw + g);
+            if (SUB) q[c] = q[c] - ld4(sbb + c * hw + g);
+        }
         const uint32_t mq = (VALID && sm) ? ld32(sm + g) : 0x01010101u;
         // (no branch round the use of these loads: on a path that skipped their wait they would count as in flight at the join, and the
         // compiler's next waits -- vmcnt(2), (1), (0) -- then wait for the NEXT tile's flow instead: a lane without a chunk writes a spare slot)
@@ -1275,9 +1285,11 @@ __device__ unsigned long long g_rows_stamp[16];
 #endif
 // ADD: the fused composition of mode 3 (flow_class.py:1804-1808): out = a_sign * flow + g_sign * warped, the addend being the flow
 // operand itself (add_is_flow) -- its registers are kept instead of the tile's positions, which are formed again at gather time.
-template <int T, int NC, bool VALID, bool ADD = false>
+// (ADD 2: another addend -- the outer `flow - (...)` of modes 1-2, Flow.combine's cells; SUB: the staged field is src - src_b (mode 1 't');
+// DF: the flag word of the OUTPUT read as a flow under `valid`, as a by-product.)
+template <int T, int NC, bool VALID, int ADD = 0, bool SUB = false, bool DF = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpParams p_by_value) {
-    static_assert(!ADD || NC == 2, "ADD: flows");
+    static_assert((ADD == 0 && !SUB && !DF) || NC == 2, "ADD / SUB / DF: flows");
     WarpParamsLeanK* pp = (WarpParamsLeanK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1289,9 +1301,11 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     const uint32_t hw = (uint32_t)(h * w);
     const float* __restrict__ fu = p.flow + n * p.flow_bs;
     const float* __restrict__ sb = p.src + n * p.src_bs;
+    const float* __restrict__ sbb = SUB ? p.src_b + n * p.src_b_bs : nullptr;
     const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
     const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
     const int xq = min(tx * (kLdsTWQ * 4) + lx * 4, w - 4);
+    int dflags = 0;
     f4 uu[T], vv[T];
     uint32_t fmk[T];
     auto load_flow = [&](int k) {
@@ -1320,7 +1334,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     rows_origins<T>(p, osample, org, cxo);
     OFL_RS(10);
     f4* lds = reinterpret_cast<f4*>(smem);
-    constexpr bool REFORM = ADD && OFL_ROWS_ADD_REFORM;      // mode 3: re-form a tile's positions from the flow registers at gather time instead of keeping them
+    constexpr bool REFORM = ADD == 1 && (OFL_ROWS_ADD_REFORM || DF);     // (with the flag by-product the kept positions spill: 32 B of scratch)      // mode 3: re-form a tile's positions from the flow registers at gather time instead of keeping them
     LdsCoords Tc[REFORM ? 1 : T];
     RowGeo Gx[T];
     RowStage<NC> S;
@@ -1336,7 +1350,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     OFL_RS(4);
     rows_scan(p, rt.tmin[0], rt.tmax[0], rt.ent[0], rt.start[0], org[0], cxo[0], Gx[0], R);
     OFL_RS(5);
-    rows_issue<NC, VALID>(p, sb, sm, hw, Gx[0], R, rt.start[0], S);
+    rows_issue<NC, VALID, SUB>(p, sb, sm, hw, Gx[0], R, rt.start[0], S, sbb);
     OFL_RS(6);
 #pragma unroll
     for (int k = 0; k < T; ++k) {
@@ -1351,31 +1365,35 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         }
         if (k + 2 < T) load_flow(k + 2);
         rows_write<NC, VALID>(lds, S, sm != nullptr);
-        rows_extra<NC, VALID>(p, sb, sm, hw, rt.tmin[k & 1], rt.tmax[k & 1], rt.start[k & 1], Gx[k], lds);
+        rows_extra<NC, VALID, SUB>(p, sb, sm, hw, rt.tmin[k & 1], rt.tmax[k & 1], rt.start[k & 1], Gx[k], lds, sbb);
         if (k + 1 < T) clear_starts((k + 1) & 1);
         OFL_RS(3);
         lds_barrier();
         OFL_RS(4);
+        f4 ad[NC] = {};
         if (k + 1 < T) {
             rows_scan(p, rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1], rt.ent[(k + 1) & 1], rt.start[(k + 1) & 1], org[k + 1], cxo[k + 1], Gx[k + 1], R);
             OFL_RS(5);
-            rows_issue<NC, VALID>(p, sb, sm, hw, Gx[k + 1], R, rt.start[(k + 1) & 1], S);
+            if (ADD == 2) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);           // (ahead of the younger staging loads: waited for without them)
+            rows_issue<NC, VALID, SUB>(p, sb, sm, hw, Gx[k + 1], R, rt.start[(k + 1) & 1], S, sbb);
             OFL_RS(6);
         }
         LdsBox B;
         B.fits = true; B.clipped = false; B.interior = Gx[k].interior; B.ent = rt.ent[k & 1]; B.org = Gx[k].org; B.cxo = Gx[k].cxo;
-        f4 outv[4], ad[NC] = {};
+        f4 outv[4];
         if (REFORM) lds_coords_box_a<false>(p, tx, tyk, uu[k], vv[k], 0, Tc[0], (int (*)[4])nullptr);
-        if (ADD) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; }
-        lds_gather<NC, VALID, false, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv);
+        if (ADD == 1) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; }
+        if (ADD == 2 && k + 1 >= T) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
+        lds_gather<NC, VALID, SUB, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv, sbb);
         OFL_RS(7);
-        lds_store<NC, VALID, ADD, false, float>(p, tx, tyk, n, hw, fmw(k), outv, ad);
+        lds_store<NC, VALID, ADD != 0, DF, float>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
         OFL_RS(8);
         if (k + 1 >= T) break;
         if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's scan, two barriers ago)
         lds_barrier();
         OFL_RS(9);
     }
+    if (DF) { dflags = wave_or_flags(dflags); if ((tid & 63) == 0) flag_or(&p.dst_flags[n], dflags); }
 #if OFL_ROWS_STAMPS
     if (tid == 0) {
 #pragma unroll
@@ -3499,10 +3517,17 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
     const bool lean = warp_is_lean(q);
     constexpr int RT = OFL_ROWS_T;                                // tiles per column of the row-table kernel
-    if (OFL_WARP_ROWS && rows && lean && add && nc == 2 && q.add_is_flow) {      // mode 3 (the addend is the flow operand) with per-row extents
+    if (OFL_WARP_ROWS && rows && lean && nc == 2 && (add || q.src_b || q.dst_flags)) {      // the flow-level variants with per-row extents
         const unsigned gr = RT == TT ? g : warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
-        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);
-        else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        const int am = !add ? 0 : (q.add_is_flow ? 1 : 2);
+#define OFL_ROWS_F(V, A, S, D) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, V, A, S, D>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q)
+        if (q.src_b) { if (!valid || add || q.dst_flags) return (int)hipErrorInvalidValue; OFL_ROWS_F(true, 0, true, false); }          // mode 1 't': src - src_b
+        else if (q.dst_flags) {                                    // (host: only with a valid mask)
+            if (!valid) return (int)hipErrorInvalidValue;
+            if (am == 0) OFL_ROWS_F(true, 0, false, true); else if (am == 1) OFL_ROWS_F(true, 1, false, true); else OFL_ROWS_F(true, 2, false, true);
+        } else if (am == 1) { if (valid) OFL_ROWS_F(true, 1, false, false); else OFL_ROWS_F(false, 1, false, false); }                  // mode 3 proper
+        else { if (valid) OFL_ROWS_F(true, 2, false, false); else OFL_ROWS_F(false, 2, false, false); }                                 // another addend
+#undef OFL_ROWS_F
         return (int)hipGetLastError();
     }
     if (OFL_WARP_ROWS && rows && lean && !add) {                  // per-row extents instead of one sheared rectangle (warp_bwd_rows_kernel)
@@ -3599,6 +3624,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
             const unsigned gc = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
             constexpr int TT = kLdsT > 2 ? kLdsT : 3;
             if (gc >= 6912u) {
+                if (OFL_WARP_ROWS_FLOWOPS && warp_is_lean(q) && g_warp_path != 6) return ofl_wide_launch_column(&p, 2, 1, 0, 1, (void*)st);   // 64 x 16 tiles, per-row extents
                 if (warp_is_lean(q)) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2, float, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
                 else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
                 return (int)hipGetLastError();
@@ -3608,6 +3634,10 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         return (int)hipGetLastError();
     }
     if (NC == 2 && p.dst_flags) {                          // (host: only with a valid mask)
+        if (OFL_WARP_ROWS_FLOWOPS && kLdsT > 2 && valid && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) {   // large lean launches: the row-table kernel keeps the flag by-product
+            WarpParams q = p;
+            if (warp_is_lean(q) && warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) >= 6912u) return ofl_wide_launch_column(&p, 2, 1, add ? 1 : 0, 1, (void*)st);
+        }
         if (add) hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, true, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         else hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         return (int)hipGetLastError();
@@ -3618,7 +3648,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
         if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 0, (void*)st);
         // large launches of mode 3 proper: 64 x 16 tiles with per-row extents (warp_bwd_rows_kernel<.., ADD>)
-        if (OFL_WARP_ROWS_ADD && NC == 2 && p.add_is_flow && warp_is_lean(q) && g >= 6912u && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4)
+        if (OFL_WARP_ROWS_ADD && NC == 2 && (p.add_is_flow || OFL_WARP_ROWS_FLOWOPS) && warp_is_lean(q) && g >= 6912u && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4)
             return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 1, (void*)st);
         if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
             if (warp_is_lean(q)) {

@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--big", action="store_true", help="frames up to 1100 x 2000 (fewer cases)")
+    ap.add_argument("--rows", action="store_true", help="as --column, on launches the ROW-TABLE kernels take (W % 4 == 0, no rounding, no flag by-product; "
+                    "plain warps of 1-3 channels, mode 3, and 7-12 channels in the channel loop): auto == the sheared rectangle (path 6) == generic, bit for bit")
     ap.add_argument("--column", action="store_true", help="warp only, batches large enough for the launcher to pick the four-tile column kernel "
                     "(>= 6 912 column groups): auto == generic == two tiles per block == one tile per block, bit for bit")
     a = ap.parse_args()
@@ -149,6 +151,11 @@ def main():
         if a.column:
             h, w, c = int(rng.integers(2, 200)), int(rng.integers(4, 300)), int(rng.integers(1, 4))
             n = 6912 // (((w + 31) // 32) * ((h + 63) // 64)) + int(rng.integers(1, 9))
+        if a.rows:
+            a.column = True
+            h, w = int(rng.integers(2, 200)), 4 * int(rng.integers(1, 76))
+            c = int(rng.integers(1, 4)) if rng.random() < 0.7 else int(rng.integers(7, 13))
+            n = (2 if c > 3 else 1) * 6912 // (((w + 31) // 32) * ((h + (15 if c > 3 else 63)) // (16 if c > 3 else 64))) + int(rng.integers(1, 9))
         kind, flow = rand_flow(rng, g, n, h, w, dev)
         src = (torch.rand(n, c, h, w, generator=g) * 300 - 100).to(dev)
         sm = (torch.rand(n, h, w, generator=g) > rng.uniform(0, 0.4)).to(dev)
@@ -157,21 +164,26 @@ def main():
         kw = dict(flow_sign=float(rng.choice([1.0, -1.0])))
         if rng.random() < 0.7:
             kw.update(src_mask=sm if rng.random() < 0.7 else None, flow_mask=fm if rng.random() < 0.7 else None, want_valid=True)
-        if rng.random() < 0.4:
+        if a.rows:
+            if c == 2 and rng.random() < 0.6:                # mode 3 proper (the flow is the addend) / another addend (modes 1-2, Flow.combine)
+                kw.update(addend=flow if rng.random() < 0.5 else torch.randn(n, c, h, w, generator=g).to(dev), a_sign=float(rng.choice([1.0, -1.0])), g_sign=float(rng.choice([1.0, -1.0])))
+            elif c == 2 and kw.get("want_valid") and rng.random() < 0.4:      # mode 1 't': the staged field is src - src_b
+                kw.update(src_b=(torch.rand(n, c, h, w, generator=g) * 50).to(dev))
+        elif rng.random() < 0.4:
             kw.update(addend=flow if (c == 2 and rng.random() < 0.5) else torch.randn(n, c, h, w, generator=g).to(dev),
                       a_sign=float(rng.choice([1.0, -1.0])), g_sign=float(rng.choice([1.0, -1.0])))
         elif rng.random() < 0.3:
             kw.update(round_mode=int(rng.integers(1, 3)))
-        if rng.random() < 0.3:
+        if rng.random() < 0.3 and not a.rows:
             kw.update(want_flags=True, want_src_flags=(c == 2))
         outs = []
-        for path in ((0, 1, 3, 4) if a.column else (0, 1)):
+        for path in ((0, 6, 1, 5) if a.rows else (0, 1, 3, 4) if a.column else (0, 1)):
             _native.set_warp_path(path)
             try:
                 outs.append(_native.warp_bwd(flow, src, **kw))
             finally:
                 _native.set_warp_path(0)
-        if c == 2 and kw.get("want_valid") and not kw.get("round_mode"):
+        if c == 2 and kw.get("want_valid") and not kw.get("round_mode") and "src_b" not in kw:
             rf = _native.warp_bwd(flow, src, want_dst_flags=True, **kw)
             assert rf[4].cpu().tolist() == _native.flow_flags(rf[0], rf[1]).cpu().tolist(), "warp dst_flags %s %s" % ((n, c, h, w), kind)
         for other in outs[1:]:
