@@ -20,6 +20,7 @@
 
 // the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
 int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int rows, void* stream);   // rows: per-row extents (warp_bwd_rows_kernel) where they apply
+int ofl_wide_launch_rows_h(const void* params, void* stream);                  // fp16 sources on the row-table kernel
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles; rows: per-row extents where they apply
 
 namespace {
@@ -1207,8 +1208,8 @@ __device__ __forceinline__ void rows_map(const WP& p, const RowGeo& G, const Row
 // the first kRowIters * kLdsNT chunks are staged through registers, in flight while the previous tile is gathered ...
 constexpr int kRowIters = 2;
 template <int NC> struct RowStage { int slot[kRowIters]; f4 q[kRowIters][NC]; uint32_t mq[kRowIters]; };
-template <int NC, bool VALID, bool SUB = false, typename WP>
-__device__ __forceinline__ void rows_issue(const WP& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
+template <int NC, bool VALID, bool SUB = false, typename TS = float, typename WP>
+__device__ __forceinline__ void rows_issue(const WP& p, const TS* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
                                            const RowGeo& G, const RowScan& R, const uint8_t* start, RowStage<NC>& S, const float* __restrict__ sbb = nullptr) {
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 #pragma unroll
@@ -1255,8 +1256,8 @@ __device__ __forceinline__ void rows_write(f4* lds, const RowStage<NC>& S, bool 
 // in a round of their own, loaded and written on the spot by the tile's own iteration: its registers are not live across a gather
 // (three rounds through registers put the kernel over the 168-register limit, and a scratch reload waits for every load in flight).
 // The table is still there (reset only after the gather): the scan is simply redone.
-template <int NC, bool VALID, bool SUB = false, typename WP>
-__device__ __forceinline__ void rows_extra(const WP& p, const float* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
+template <int NC, bool VALID, bool SUB = false, typename TS = float, typename WP>
+__device__ __forceinline__ void rows_extra(const WP& p, const TS* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
                                            const int* tmin, const int* tmax, const uint8_t* start, const RowGeo& G, f4* lds, const float* __restrict__ sbb = nullptr) {
     if (__builtin_expect(G.tot > kRowIters * kLdsNT, 0)) {
         RowGeo G2; RowScan R;
@@ -1287,7 +1288,7 @@ __device__ unsigned long long g_rows_stamp[16];
 // operand itself (add_is_flow) -- its registers are kept instead of the tile's positions, which are formed again at gather time.
 // (ADD 2: another addend -- the outer `flow - (...)` of modes 1-2, Flow.combine's cells; SUB: the staged field is src - src_b (mode 1 't');
 // DF: the flag word of the OUTPUT read as a flow under `valid`, as a by-product.)
-template <int T, int NC, bool VALID, int ADD = 0, bool SUB = false, bool DF = false>
+template <int T, int NC, bool VALID, int ADD = 0, bool SUB = false, bool DF = false, typename TS = float>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpParams p_by_value) {
     static_assert((ADD == 0 && !SUB && !DF) || NC == 2, "ADD / SUB / DF: flows");
     WarpParamsLeanK* pp = (WarpParamsLeanK*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1300,7 +1301,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     const int w = p.w, h = p.h;
     const uint32_t hw = (uint32_t)(h * w);
     const float* __restrict__ fu = p.flow + n * p.flow_bs;
-    const float* __restrict__ sb = p.src + n * p.src_bs;
+    const TS* __restrict__ sb = reinterpret_cast<const TS*>(p.src) + n * p.src_bs;      // (fp16 sources: p.src points at halves)
     const float* __restrict__ sbb = SUB ? p.src_b + n * p.src_b_bs : nullptr;
     const uint8_t* __restrict__ sm = p.src_mask ? p.src_mask + n * p.src_mask_bs : nullptr;
     const uint8_t* __restrict__ fm = p.flow_mask ? p.flow_mask + n * p.flow_mask_bs : nullptr;
@@ -1350,7 +1351,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     OFL_RS(4);
     rows_scan(p, rt.tmin[0], rt.tmax[0], rt.ent[0], rt.start[0], org[0], cxo[0], Gx[0], R);
     OFL_RS(5);
-    rows_issue<NC, VALID, SUB>(p, sb, sm, hw, Gx[0], R, rt.start[0], S, sbb);
+    rows_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Gx[0], R, rt.start[0], S, sbb);
     OFL_RS(6);
 #pragma unroll
     for (int k = 0; k < T; ++k) {
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         }
         if (k + 2 < T) load_flow(k + 2);
         rows_write<NC, VALID>(lds, S, sm != nullptr);
-        rows_extra<NC, VALID, SUB>(p, sb, sm, hw, rt.tmin[k & 1], rt.tmax[k & 1], rt.start[k & 1], Gx[k], lds, sbb);
+        rows_extra<NC, VALID, SUB, TS>(p, sb, sm, hw, rt.tmin[k & 1], rt.tmax[k & 1], rt.start[k & 1], Gx[k], lds, sbb);
         if (k + 1 < T) clear_starts((k + 1) & 1);
         OFL_RS(3);
         lds_barrier();
@@ -1375,7 +1376,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
             rows_scan(p, rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1], rt.ent[(k + 1) & 1], rt.start[(k + 1) & 1], org[k + 1], cxo[k + 1], Gx[k + 1], R);
             OFL_RS(5);
             if (ADD == 2) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);           // (ahead of the younger staging loads: waited for without them)
-            rows_issue<NC, VALID, SUB>(p, sb, sm, hw, Gx[k + 1], R, rt.start[(k + 1) & 1], S, sbb);
+            rows_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Gx[k + 1], R, rt.start[(k + 1) & 1], S, sbb);
             OFL_RS(6);
         }
         LdsBox B;
@@ -1384,7 +1385,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         if (REFORM) lds_coords_box_a<false>(p, tx, tyk, uu[k], vv[k], 0, Tc[0], (int (*)[4])nullptr);
         if (ADD == 1) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; }
         if (ADD == 2 && k + 1 >= T) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
-        lds_gather<NC, VALID, SUB, float, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv, sbb);
+        lds_gather<NC, VALID, SUB, TS, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv, sbb);
         OFL_RS(7);
         lds_store<NC, VALID, ADD != 0, DF, float>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
         OFL_RS(8);
@@ -3572,6 +3573,17 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     return (int)hipGetLastError();
 }
 
+// a flow stored in fp16 gathered from its halves (ofl_warp_bwd_h_f32), large lean launches: the row-table kernel
+int ofl_wide_launch_rows_h(const void* params, void* stream) {
+    WarpParams q = *static_cast<const WarpParams*>(params);
+    q.lds_bytes = kLdsBytes;
+    constexpr int RT = OFL_ROWS_T;
+    const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
+    if (!OFL_WARP_ROWS || !warp_is_lean(q) || !q.valid || q.addend || q.dst_flags) return (int)hipErrorInvalidValue;
+    if (q.src_b) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, 0, true, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
+    else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, 0, false, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
+    return (int)hipGetLastError();
+}
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
@@ -4063,6 +4075,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_h_f32(
         constexpr int TT = kLdsT > 2 ? kLdsT : 3;
         if (gc >= 6912u) {
             const bool lean = warp_is_lean(q);
+            if (OFL_WARP_ROWS_FLOWOPS && lean && g_warp_path != 6) return ofl_wide_launch_rows_h(&p, stream);      // 64 x 16 tiles, per-row extents
             if (src_b) { if (lean) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
                          else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
             else { if (lean) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
