@@ -1123,28 +1123,29 @@ __device__ __forceinline__ void rows_post(const WP& p, const LdsCoords& T, int o
     // its RIGHT neighbour likewise: by induction along the 16 lanes (a DPP row) somebody with the rows' extreme value posts it, whatever
     // the flow -- under a smooth one only the two ends of each run do.  (Measured: -3 ... -6 % at sigma 0.5; the general form of the
     // test -- the neighbour's range CONTAINS the row, per row -- cost sigma 8 +2 %.)
+    // (rows outside the table are dropped and flagged; clamped to it first, so that a lane whose 4 pixels span the frame -- a fold, a
+    // huge value -- walks 64 rows at most, and the packed compare below cannot alias)
+    const bool drop = a < 0 || b >= kRowTab;
+    const int a0 = max(a, 0), b0 = min(b, kRowTab - 1);
 #if OFL_ROWS_DEDUPE
-    const int ab = (a & 0xffff) | (b << 16);
-    const int abl = __builtin_amdgcn_update_dpp(1, ab, 0x111, 0xf, 0xf, false), cml = __builtin_amdgcn_update_dpp(0x7fffffff, cmin, 0x111, 0xf, 0xf, false);     // row_shr:1 (old: an empty range)
-    const int abr = __builtin_amdgcn_update_dpp(1, ab, 0x101, 0xf, 0xf, false), cxr = __builtin_amdgcn_update_dpp(-0x7fffffff, cmax, 0x101, 0xf, 0xf, false);    // row_shl:1
+    const int ab = a0 | (b0 << 16);
+    const int abl = __builtin_amdgcn_update_dpp(-1, ab, 0x111, 0xf, 0xf, false), cml = __builtin_amdgcn_update_dpp(0x7fffffff, cmin, 0x111, 0xf, 0xf, false);     // row_shr:1 (old: no neighbour)
+    const int abr = __builtin_amdgcn_update_dpp(-1, ab, 0x101, 0xf, 0xf, false), cxr = __builtin_amdgcn_update_dpp(-0x7fffffff, cmax, 0x101, 0xf, 0xf, false);    // row_shl:1
     const bool pmin = !(abl == ab && cml <= cmin), pmax = !(abr == ab && cxr >= cmax);     // (the SAME rows: one compare, and what a smooth flow produces)
 #else
     const bool pmin = true, pmax = true;
 #endif
-    bool drop = false;
-    int r = a;
 #pragma unroll
-    for (int j = 0; j < 2; ++j, ++r) {     // (a lane touches at least two rows)
-        if ((uint32_t)r < (uint32_t)kRowTab) {
+    for (int j = 0; j < 2; ++j) {          // (a lane touches at least two rows)
+        const int r = a0 + j;
+        if (r <= b0) {
             if (pmin) atomicMin(&tmin[r], cmin);
             if (pmax) atomicMax(&tmax[r], cmax);
-        } else drop = true;
+        }
     }
-    for (; r <= b; ++r) {
-        if ((uint32_t)r < (uint32_t)kRowTab) {
-            if (pmin) atomicMin(&tmin[r], cmin);
-            if (pmax) atomicMax(&tmax[r], cmax);
-        } else drop = true;
+    for (int r = a0 + 2; r <= b0; ++r) {
+        if (pmin) atomicMin(&tmin[r], cmin);
+        if (pmax) atomicMax(&tmax[r], cmax);
     }
     if (drop) atomicMax(&tmax[kRowTab], 1);
 }
