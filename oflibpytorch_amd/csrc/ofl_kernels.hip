@@ -21,6 +21,7 @@
 // the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
 int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int rows, void* stream);   // rows: per-row extents (warp_bwd_rows_kernel) where they apply
 int ofl_wide_launch_rows_h(const void* params, void* stream);                  // fp16 sources on the row-table kernel
+int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream);         // uint8 images (bytes in; bytes or fp32 out) on the row-table kernel
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles; rows: per-row extents where they apply
 
 namespace {
@@ -1289,10 +1290,13 @@ __device__ unsigned long long g_rows_stamp[16];
 // operand itself (add_is_flow) -- its registers are kept instead of the tile's positions, which are formed again at gather time.
 // (ADD 2: another addend -- the outer `flow - (...)` of modes 1-2, Flow.combine's cells; SUB: the staged field is src - src_b (mode 1 't');
 // DF: the flag word of the OUTPUT read as a flow under `valid`, as a by-product.)
-template <int T, int NC, bool VALID, int ADD = 0, bool SUB = false, bool DF = false, typename TS = float>
+// (TS / TD / ROUND: uint8 images warped from and to their bytes -- ofl_warp_bwd_u8 -- read the rounding mode at run time; the width is a
+// multiple of 4 in every launch of this kernel.)
+template <int T, int NC, bool VALID, int ADD = 0, bool SUB = false, bool DF = false, typename TS = float, typename TD = float, bool ROUND = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpParams p_by_value) {
     static_assert((ADD == 0 && !SUB && !DF) || NC == 2, "ADD / SUB / DF: flows");
-    WarpParamsLeanK* pp = (WarpParamsLeanK*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef typename std::conditional<ROUND, WarpParamsK, WarpParamsLeanK>::type WPK;
+    WPK* pp = (WPK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ RowTabs rt;
@@ -1388,7 +1392,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         if (ADD == 2 && k + 1 >= T) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
         lds_gather<NC, VALID, SUB, TS, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv, sbb);
         OFL_RS(7);
-        lds_store<NC, VALID, ADD != 0, DF, float>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
+        lds_store<NC, VALID, ADD != 0, DF, TD>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
         OFL_RS(8);
         if (k + 1 >= T) break;
         if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's scan, two barriers ago)
@@ -3585,6 +3589,24 @@ int ofl_wide_launch_rows_h(const void* params, void* stream) {
     else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, 0, false, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
+// uint8 images warped from and to their bytes (ofl_warp_bwd_u8; 1 or 3 channels, W % 4 == 0), large launches: the row-table kernel
+int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream) {
+    WarpParams q = *static_cast<const WarpParams*>(params);
+    q.lds_bytes = kLdsBytes;
+    constexpr int RT = OFL_ROWS_T;
+    const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
+    if (!OFL_WARP_ROWS || (q.w & 3) != 0 || q.flow_flags || q.addend || q.src_b || q.dst_flags || !(nc == 1 || nc == 3)) return (int)hipErrorInvalidValue;
+#define OFL_ROWS_U8(NC, V, TD) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, V, 0, false, false, uint8_t, TD, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
+    if (dst_is_u8) {
+        if (nc == 1) { if (q.valid) OFL_ROWS_U8(1, true, uint8_t); else OFL_ROWS_U8(1, false, uint8_t); }
+        else { if (q.valid) OFL_ROWS_U8(3, true, uint8_t); else OFL_ROWS_U8(3, false, uint8_t); }
+    } else {                                          // (Flow.apply of a uint8 image: fp32 out, rounded or not as the caller says)
+        if (nc == 1) { if (q.valid) OFL_ROWS_U8(1, true, float); else OFL_ROWS_U8(1, false, float); }
+        else { if (q.valid) OFL_ROWS_U8(3, true, float); else OFL_ROWS_U8(3, false, float); }
+    }
+#undef OFL_ROWS_U8
+    return (int)hipGetLastError();
+}
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
@@ -4025,6 +4047,10 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_u8(
         q.src = reinterpret_cast<const float*>(src + c0 * hw);             // (the uint8 kernels re-read these as byte pointers)
         q.dst = dst_is_u8 ? reinterpret_cast<float*>(static_cast<uint8_t*>(dst) + c0 * hw) : static_cast<float*>(dst) + c0 * hw;
         if (c0 > 0) { q.valid = nullptr; q.src_mask = nullptr; }
+        if (OFL_WARP_ROWS_FLOWOPS && (nc == 1 || nc == 3) && (w & 3) == 0 && kLdsT > 2 && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) {
+            WarpParams qg = q;                           // large launches: 64 x 16 tiles, per-row extents
+            if (warp_geometry(qg, kLdsTWQ * 4, kLdsT * kLdsTH) >= 6912u) { rc = ofl_wide_launch_rows_u8(&q, nc, dst_is_u8, stream); if (rc) return rc; continue; }
+        }
         if (dst_is_u8) {
             switch (nc) {
                 case 1: rc = launch_warp_lds_u8<1, uint8_t>(q, g, st); break;

@@ -284,6 +284,44 @@ def test_row_tables_on_strongly_curved_flows(kind, c, dev):
             assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > 0.99999) & fm_)
 
 
+@pytest.mark.parametrize("c", [1, 3])
+@pytest.mark.parametrize("kind", ["waves", "blocks"])
+def test_row_tables_uint8_images(kind, c, dev):
+    """uint8 images warped from and to their bytes (ofl_warp_bwd_u8, round-half-even + clamp) on the row-table kernel of large launches
+    (1 or 3 channels, W % 4 == 0): == the two-tile kernel (path 6 / 3) == the generic kernel (path 1), bit for bit, values and valid mask."""
+    from oflibpytorch_amd import _native
+    h, w = 176, 256
+    n = 6912 // (((w + 31) // 32) * ((h + 63) // 64)) + 1
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    if kind == "waves":
+        u = 9.0 * torch.sin(ys / 7.0) + 4.0 * torch.cos(xs / 5.0)
+        v = 14.0 * torch.sin(xs / 9.0) + 3.0 * torch.sin(ys / 4.0)
+    else:
+        g0 = torch.Generator().manual_seed(3)
+        lo = torch.randn(2, h // 8, w // 8, generator=g0) * 25.0
+        u, v = [torch.nn.functional.interpolate(t[None, None], size=(h, w), mode='nearest')[0, 0] for t in lo]
+    flow = (torch.stack([u, v])[None] + _smooth(n, h, w, 1.5, 37, torch.device('cpu'))).contiguous().to(dev)
+    g = torch.Generator().manual_seed(19)
+    src = torch.randint(0, 256, (n, c, h, w), generator=g, dtype=torch.uint8).to(dev)
+    sm = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    fmk = (torch.rand(n, h, w, generator=g) > 0.1).to(dev)
+    for kw in (dict(src_mask=sm, flow_mask=fmk, want_valid=True), dict()):
+        outs = []
+        for path in (0, 6, 3, 1):
+            _native.set_warp_path(path)
+            try:
+                outs.append(_native.warp_bwd(flow, src, round_mode=_native.ROUND_U8, out_uint8=True, **kw))
+                outs[-1] = outs[-1] + _native.warp_bwd(flow, src, **kw)[:2]          # (fp32 out, no rounding: Flow.apply of a uint8 image)
+            finally:
+                _native.set_warp_path(0)
+        assert outs[0][0].dtype == torch.uint8
+        for other in outs[1:]:
+            for a_, b_ in zip(outs[0], other):
+                assert (a_ is None) == (b_ is None)
+                if a_ is not None:
+                    assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("kind", ["waves", "steep_rows", "blocks", "outward"])
 @pytest.mark.parametrize("c,valid", [(8, False), (7, True), (9, False)])
 def test_channel_loop_with_row_tables(kind, c, valid, dev):
