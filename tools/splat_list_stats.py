@@ -21,7 +21,7 @@ for sigma in args.sigma:
     ofl.Flow(f, 's').switch_ref()
     torch.cuda.synchronize()
     ws = _native._last_splat_ws
-    tiles = n * ((w + 31) // 32) * ((h + 15) // 16)
+    tiles = n * ((w + 63) // 64) * ((h + 15) // 16)      # (64 x 16 destination tiles)
     off = 8 + ((n + 3) & ~3)
     cnt = ws[off:off + tiles].float()
     q = torch.quantile(cnt, torch.tensor([0.1, 0.5, 0.9, 0.99], device=dev)).tolist()
