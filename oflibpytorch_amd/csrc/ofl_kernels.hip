@@ -21,6 +21,7 @@
 // the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
 int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int rows, void* stream);   // rows: per-row extents (warp_bwd_rows_kernel) where they apply
 int ofl_wide_launch_rows_h(const void* params, void* stream);                  // fp16 sources on the row-table kernel
+int ofl_wide_launch_rows_grad(const void* params, int nc, void* stream);       // gradient wrt the flow on the row-table kernel
 int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream);         // uint8 images (bytes in; bytes or fp32 out) on the row-table kernel
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles; rows: per-row extents where they apply
 
@@ -1292,9 +1293,11 @@ __device__ unsigned long long g_rows_stamp[16];
 // DF: the flag word of the OUTPUT read as a flow under `valid`, as a by-product.)
 // (TS / TD / ROUND: uint8 images warped from and to their bytes -- ofl_warp_bwd_u8 -- read the rounding mode at run time; the width is a
 // multiple of 4 in every launch of this kernel.)
-template <int T, int NC, bool VALID, int ADD = 0, bool SUB = false, bool DF = false, typename TS = float, typename TD = float, bool ROUND = false>
+// (GRAD: the gradient with respect to the FLOW -- ofl_warp_bwd_grad_f32 -- see lds_gather_impl: `addend` is the upstream gradient, dst two planes.)
+template <int T, int NC, bool VALID, int ADD = 0, bool SUB = false, bool DF = false, typename TS = float, typename TD = float, bool ROUND = false, bool GRAD = false>
 __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpParams p_by_value) {
     static_assert((ADD == 0 && !SUB && !DF) || NC == 2, "ADD / SUB / DF: flows");
+    static_assert(!GRAD || (!VALID && ADD == 0 && !SUB && !DF), "GRAD: plain taps");
     typedef typename std::conditional<ROUND, WarpParamsK, WarpParamsLeanK>::type WPK;
     WPK* pp = (WPK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
@@ -1380,7 +1383,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         if (k + 1 < T) {
             rows_scan(p, rt.tmin[(k + 1) & 1], rt.tmax[(k + 1) & 1], rt.ent[(k + 1) & 1], rt.start[(k + 1) & 1], org[k + 1], cxo[k + 1], Gx[k + 1], R);
             OFL_RS(5);
-            if (ADD == 2) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);           // (ahead of the younger staging loads: waited for without them)
+            if (ADD == 2 || GRAD) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);   // (ahead of the younger staging loads: waited for without them)
             rows_issue<NC, VALID, SUB, TS>(p, sb, sm, hw, Gx[k + 1], R, rt.start[(k + 1) & 1], S, sbb);
             OFL_RS(6);
         }
@@ -1389,10 +1392,11 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         f4 outv[4];
         if (REFORM) lds_coords_box_a<false>(p, tx, tyk, uu[k], vv[k], 0, Tc[0], (int (*)[4])nullptr);
         if (ADD == 1) { ad[0] = uu[k]; ad[NC - 1] = vv[k]; }
-        if (ADD == 2 && k + 1 >= T) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
-        lds_gather<NC, VALID, SUB, TS, false, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv, sbb);
+        if ((ADD == 2 || GRAD) && k + 1 >= T) lds_load_addend<NC>(p, tx, tyk, n, hw, ad);
+        lds_gather<NC, VALID, SUB, TS, GRAD, false, typename std::remove_reference<decltype(p)>::type, true>(p, hw, sb, sm, Tc[REFORM ? 0 : k], B, smem, outv, sbb, GRAD ? ad : nullptr);
         OFL_RS(7);
-        lds_store<NC, VALID, ADD != 0, DF, TD>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
+        if (GRAD) { const f4 none[2] = {}; lds_store<2, false, false, false, float>(p, tx, tyk, n, hw, 0u, outv, none); }
+        else lds_store<NC, VALID, ADD != 0, DF, TD>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
         OFL_RS(8);
         if (k + 1 >= T) break;
         if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's scan, two barriers ago)
@@ -3589,6 +3593,18 @@ int ofl_wide_launch_rows_h(const void* params, void* stream) {
     else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, 0, false, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
+// the gradient with respect to the flow (ofl_warp_bwd_grad_f32), large launches with W % 4 == 0: the row-table kernel
+int ofl_wide_launch_rows_grad(const void* params, int nc, void* stream) {
+    WarpParams q = *static_cast<const WarpParams*>(params);
+    q.lds_bytes = kLdsBytes;
+    constexpr int RT = OFL_ROWS_T;
+    const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
+    if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.valid || q.src_b || q.dst_flags) return (int)hipErrorInvalidValue;
+#define OFL_ROWS_G(NC) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, false, 0, false, false, float, float, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
+    switch (nc) { case 1: OFL_ROWS_G(1); break; case 2: OFL_ROWS_G(2); break; default: OFL_ROWS_G(3); break; }
+#undef OFL_ROWS_G
+    return (int)hipGetLastError();
+}
 // uint8 images warped from and to their bytes (ofl_warp_bwd_u8; 1 or 3 channels, W % 4 == 0), large launches: the row-table kernel
 int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
@@ -3875,6 +3891,7 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
     p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;
     const unsigned g = warp_geometry(p, kLdsTWQ * 4, kLdsT * kLdsTH);
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
+    if (OFL_WARP_ROWS_FLOWOPS && g >= 6912u && warp_is_lean(p) && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) return ofl_wide_launch_rows_grad(&p, c, (void*)st);   // 64 x 16 tiles, per-row extents
     switch (c) {
         case 1: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 1, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
         case 2: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
