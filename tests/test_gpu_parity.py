@@ -284,6 +284,36 @@ def test_row_tables_on_strongly_curved_flows(kind, c, dev):
             assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > 0.99999) & fm_)
 
 
+@pytest.mark.parametrize("c", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["waves", "blocks"])
+def test_row_tables_gradient_wrt_flow(kind, c, dev):
+    """The gradient with respect to the flow (ofl_warp_bwd_grad_f32, grad_flow alone) of large launches runs on the row-table kernel (GRAD
+    instantiation): == the column kernel on the sheared rectangle (path 6) == the one-pixel-per-lane kernel (path 1), bit for bit."""
+    from oflibpytorch_amd import _native
+    h, w = 176, 256
+    n = 6912 // (((w + 31) // 32) * ((h + 63) // 64)) + 1
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    if kind == "waves":
+        u = 9.0 * torch.sin(ys / 7.0) + 4.0 * torch.cos(xs / 5.0)
+        v = 14.0 * torch.sin(xs / 9.0) + 3.0 * torch.sin(ys / 4.0)
+    else:
+        g0 = torch.Generator().manual_seed(3)
+        lo = torch.randn(2, h // 8, w // 8, generator=g0) * 25.0
+        u, v = [torch.nn.functional.interpolate(t[None, None], size=(h, w), mode='nearest')[0, 0] for t in lo]
+    flow = (torch.stack([u, v])[None] + _smooth(n, h, w, 1.5, 41, torch.device('cpu'))).contiguous().to(dev)
+    g = torch.Generator().manual_seed(23)
+    src = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    go = torch.randn(n, c, h, w, generator=g).to(dev)
+    outs = []
+    for path in (0, 6, 1):
+        _native.set_warp_path(path)
+        try:
+            outs.append(_native.warp_bwd_grad(flow, src, go, flow_sign=-1.0 if kind == "blocks" else 1.0, g_scale=0.5, want_src=False, want_flow=True)[1])
+        finally:
+            _native.set_warp_path(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("c", [1, 3])
 @pytest.mark.parametrize("kind", ["waves", "blocks"])
 def test_row_tables_uint8_images(kind, c, dev):
