@@ -20,6 +20,7 @@
 
 // the four-tile column kernel on 64 x 16 tiles (ofl_warp_wide.hip: this file compiled with OFL_WIDE_TU); `params` = a WarpParams
 int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int rows, void* stream);   // rows: per-row extents (warp_bwd_rows_kernel) where they apply
+int ofl_wide_launch_rows_small(const void* params, int nc, int valid, int add, int tiles, void* stream);   // small plain launches / mode 3: row tables, 1 or 2 tiles per block
 int ofl_wide_launch_rows_h(const void* params, void* stream);                  // fp16 sources on the row-table kernel
 int ofl_wide_launch_rows_grad(const void* params, int nc, void* stream);       // gradient wrt the flow on the row-table kernel
 int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream);         // uint8 images (bytes in; bytes or fp32 out) on the row-table kernel
@@ -619,6 +620,9 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table (wa
 #endif
 #ifndef OFL_WARP_ROWS_FLOWOPS
 #define OFL_WARP_ROWS_FLOWOPS 1      // the other flow-level instantiations on row tables too: another addend (modes 1-2, Flow.combine), src - src_b staging (mode 1 't'), the output's flag word
+#endif
+#ifndef OFL_WARP_ROWS_SMALL
+#define OFL_WARP_ROWS_SMALL 1       // small plain launches and small mode 3 on the row-table kernel too (1 or 2 tiles per block)
 #endif
 #ifndef OFL_ROWS_SCHED_BARRIER
 #define OFL_ROWS_SCHED_BARRIER 0
@@ -3582,6 +3586,25 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     return (int)hipGetLastError();
 }
 
+// SMALL plain lean launches (below the four-tile column's threshold): the row-table kernel with one tile (tiny: B = 1 at 1080p) or two
+// tiles per block -- B = 2 ... 6 at 1080p: -13 ... -14 % against the two-tile kernel on the sheared rectangle (53 -> 62 %, 58 -> 68 %,
+// 61 -> 71 % of 8 TB/s; tools/small_once.py), B = 1 -1.5 %.  2 / 3 channels (flows / images) and mode 3 proper.
+int ofl_wide_launch_rows_small(const void* params, int nc, int valid, int add, int tiles, void* stream) {
+    WarpParams q = *static_cast<const WarpParams*>(params);
+    q.lds_bytes = kLdsBytes;
+    hipStream_t st = (hipStream_t)stream;
+    if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.src_b || q.dst_flags || !(nc == 2 || nc == 3) || (add && !(nc == 2 && q.add_is_flow))) return (int)hipErrorInvalidValue;
+    const unsigned gs = warp_geometry(q, kLdsTWQ * 4, (tiles == 1 ? 1 : 2) * kLdsTH);
+#define OFL_ROWS_S(T_, NC, V, A) hipLaunchKernelGGL((warp_bwd_rows_kernel<T_, NC, V, A>), dim3(gs), dim3(kLdsNT), kRowsLdsBytes, st, q)
+#define OFL_ROWS_ST(T_)                                                                                   \
+    if (add) { if (valid) OFL_ROWS_S(T_, 2, true, 1); else OFL_ROWS_S(T_, 2, false, 1); }                \
+    else if (nc == 2) { if (valid) OFL_ROWS_S(T_, 2, true, 0); else OFL_ROWS_S(T_, 2, false, 0); }       \
+    else { if (valid) OFL_ROWS_S(T_, 3, true, 0); else OFL_ROWS_S(T_, 3, false, 0); }
+    if (tiles == 1) { OFL_ROWS_ST(1) } else { OFL_ROWS_ST(2) }
+#undef OFL_ROWS_ST
+#undef OFL_ROWS_S
+    return (int)hipGetLastError();
+}
 // a flow stored in fp16 gathered from its halves (ofl_warp_bwd_h_f32), large lean launches: the row-table kernel
 int ofl_wide_launch_rows_h(const void* params, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
@@ -3701,6 +3724,10 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         // large launches of mode 3 proper: 64 x 16 tiles with per-row extents (warp_bwd_rows_kernel<.., ADD>)
         if (OFL_WARP_ROWS_ADD && NC == 2 && (p.add_is_flow || OFL_WARP_ROWS_FLOWOPS) && warp_is_lean(q) && g >= 6912u && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4)
             return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 1, (void*)st);
+        if (OFL_WARP_ROWS_SMALL && NC == 2 && p.add_is_flow && warp_is_lean(q) && g < 6912u && g_warp_path == 0) {     // small mode 3
+            WarpParams q1 = p;
+            return ofl_wide_launch_rows_small(&p, 2, valid ? 1 : 0, 1, warp_geometry(q1, kLdsTWQ * 4, kLdsTH) < 6912u ? 1 : 2, (void*)st);
+        }
         if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
             if (warp_is_lean(q)) {
                 if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
@@ -3729,6 +3756,11 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     {
         WarpParams q1 = p;
         const unsigned g1 = warp_geometry(q1, kLdsTWQ * 4, kLdsTH);
+        // small plain launches on the row-table kernel (1 tile per block for tiny ones, else 2): see ofl_wide_launch_rows_small
+        if (OFL_WARP_ROWS_SMALL && (NC == 2 || NC == 3) && !add && !p.flow_flags && g_warp_path == 0 && warp_is_lean(q1)) {
+            WarpParams q4 = p;
+            if (warp_geometry(q4, kLdsTWQ * 4, kLdsT * kLdsTH) < kColumnMinGroups) return ofl_wide_launch_rows_small(&p, NC, valid ? 1 : 0, 0, g1 < kColumnMinGroups ? 1 : 2, (void*)st);
+        }
         if (g_warp_path == 4 || (g_warp_path != 3 && g1 < kColumnMinGroups)) {
             if (warp_is_lean(q1) && valid) {            // (the lean twins of the two instantiations with a valid mask: BASELINE configs[1] is one of them)
                 if (add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, true, false, false, float, float, false, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
