@@ -621,6 +621,9 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table (wa
 #ifndef OFL_WARP_ROWS_FLOWOPS
 #define OFL_WARP_ROWS_FLOWOPS 1      // the other flow-level instantiations on row tables too: another addend (modes 1-2, Flow.combine), src - src_b staging (mode 1 't'), the output's flag word
 #endif
+#ifndef OFL_WARP_CHAN_WIDE_MIN
+#define OFL_WARP_CHAN_WIDE_MIN (2 * 6912u)      // 32 x 16 tiles of the launch from which the channel loop runs on 64 x 16 tiles
+#endif
 #ifndef OFL_WARP_ROWS_SMALL
 #define OFL_WARP_ROWS_SMALL 1       // small plain launches and small mode 3 on the row-table kernel too (1 or 2 tiles per block)
 #endif
@@ -4002,7 +4005,10 @@ static int warp_bwd_impl(
         if (OFL_WARP_CHAN && c >= (valid ? 7 : 4) && (w & 3) == 0 && !addend && !src_b && !dst_flags && g_warp_path != 5) {
             WarpParams q = p;
             const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
-            if (OFL_WARP_CHAN_WIDE && g1 >= 2 * 6912u) return ofl_wide_launch_chan(&p, p.valid ? 1 : 0, g_warp_path != 6 && c >= 7, (void*)st);   // (row extents from two channel groups on: with one group their set-up is not amortised -- C = 4: 0.148 against 0.138 ms)
+            // 64 x 16 tiles for large launches -- and, with per-row extents (lean, two channel groups or more), for EVERY size: B = 1 C = 64
+            // 0.355 -> 0.255 ms, C = 16 0.071 -> 0.054 ms against the 32 x 16 rectangle version (tools/bench_chan.py --batch 1)
+            const bool rows_chan = OFL_WARP_ROWS && g_warp_path != 6 && c >= 7 && warp_is_lean(q);
+            if (OFL_WARP_CHAN_WIDE && (g1 >= OFL_WARP_CHAN_WIDE_MIN || rows_chan)) return ofl_wide_launch_chan(&p, p.valid ? 1 : 0, rows_chan ? 1 : 0, (void*)st);   // (row extents from two channel groups on: with one group their set-up is not amortised -- C = 4: 0.148 against 0.138 ms)
             if (warp_is_lean(q)) {
                 if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
                 else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
