@@ -62,7 +62,8 @@ int ofl_version(void);
  *                          channel-loop kernel (one launch that walks the channels in groups of 4 inside the block; W % 4 == 0),
  *                      6 = like auto, but the four-tile column kernel of large launches stages ONE y-sheared rectangle per tile instead of
  *                          per-row extents (the default for plain warps of 1..3 channels with W % 4 == 0 and no rounding: every source row
- *                          a 64 x 16 tile touches has its own first chunk and length). */
+ *                          a 64 x 16 tile touches has its own first chunk and length; small launches run it with 1 or 2 tiles per block),
+ *                      7 = like auto, but plain lean launches take the four-tile row-table columns whatever their size (tests). */
 #define OFL_OPT_WARP_PATH 1
 /*   OFL_OPT_WARP_SHEAR: 1 = the LDS-staged warp kernel stages a y-sheared box (default), 0 = plain bounding box
  *   (speed only; the results are identical). */

@@ -18,7 +18,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 31              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 32              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -134,7 +134,8 @@ def set_splat_pass_images(k: int):
 def set_warp_path(mode: int):
     """0 = auto (LDS-staged kernel when eligible), 1 = generic direct-gather kernel only, 3 / 4 = staged with two tiles / one tile
     per block whatever the launch size, 5 = auto but more than 3 channels as separate launches of 3 instead of the channel-loop
-    kernel, 6 = auto but the column kernel's sheared rectangle instead of per-row extents (tests compare them all)."""
+    kernel, 6 = auto but the sheared rectangle instead of per-row extents, 7 = auto but four-tile row-table columns whatever the
+    launch size (tests compare them all)."""
     _check(load_library().ofl_set_option(1, int(mode)), "ofl_set_option")
 
 

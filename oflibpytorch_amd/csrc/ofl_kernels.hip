@@ -3687,7 +3687,7 @@ int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream) 
     return (int)hipGetLastError();
 }
 #else
-int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests), 5 = auto but more than 3 channels as separate launches of 3 (tests: the channel-loop kernel against them), 6 = auto but the column kernel's sheared rectangle instead of per-row extents (tests, A/B)
+int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests), 5 = auto but more than 3 channels as separate launches of 3 (tests: the channel-loop kernel against them), 6 = auto but the sheared rectangle instead of per-row extents (tests, A/B), 7 = auto but plain lean launches on four-tile row-table columns whatever the size (tests)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
@@ -3759,6 +3759,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     {
         WarpParams q1 = p;
         const unsigned g1 = warp_geometry(q1, kLdsTWQ * 4, kLdsTH);
+        if (g_warp_path == 7 && !add && warp_is_lean(q1)) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 0, 1, (void*)st);   // (tests / experiments: four-tile columns with row tables whatever the size)
         // small plain launches on the row-table kernel (1 tile per block for tiny ones, else 2): see ofl_wide_launch_rows_small
         if (OFL_WARP_ROWS_SMALL && (NC == 2 || NC == 3) && !add && !p.flow_flags && g_warp_path == 0 && warp_is_lean(q1)) {
             WarpParams q4 = p;
@@ -3940,10 +3941,10 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 31; }   // 31: OFL_OPT_WARP_PATH value 6 (the sheared rectangle instead of per-row extents: warp_bwd_rows_kernel is the default for large lean launches); 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 32; }   // 32: OFL_OPT_WARP_PATH value 7 (four-tile row-table columns whatever the size); row tables for small launches, the other flow-level warps, fp16 / uint8 sources, the gradient-wrt-flow pass; 31: OFL_OPT_WARP_PATH value 6 (the sheared rectangle instead of per-row extents: warp_bwd_rows_kernel is the default for large lean launches); 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
-    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 6) { g_warp_path = value; return OFL_OK; }
+    if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 7) { g_warp_path = value; return OFL_OK; }
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }

@@ -62,7 +62,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.ofl_flow_flags_f32(null, 0, null, 0, 1e-3, null, 1, 4, 4, null) == -1
     assert lib.ofl_splat_fwd_f32(null, 0, 1.0, null, null, 0, null, 0, 1.0, null, 0, null, 0, null, 0, 0, 0, null,
                                  1, 1, 4, 4, null) == -1
-    assert lib.ofl_set_option(1, 7) == -3 and lib.ofl_set_option(1, 6) == 0 and lib.ofl_set_option(1, 5) == 0 and lib.ofl_set_option(1, 0) == 0      # (5: more than 3 channels as launches of 3; 6: the sheared rectangle instead of per-row extents)
+    assert lib.ofl_set_option(1, 8) == -3 and lib.ofl_set_option(1, 7) == 0 and lib.ofl_set_option(1, 6) == 0 and lib.ofl_set_option(1, 5) == 0 and lib.ofl_set_option(1, 0) == 0      # (5: more than 3 channels as launches of 3; 6: the sheared rectangle instead of per-row extents; 7: four-tile row-table columns whatever the size)
 
 
 def test_round3_entry_points_reject_bad_arguments_without_a_gpu():

@@ -419,7 +419,7 @@ def test_lds_and_generic_paths_agree(shape, sigma, dev):
                dict(flow_sign=-1.0, src_mask=sm, want_valid=True, addend=add, a_sign=1.0, g_sign=-1.0),
                dict(round_mode=2), dict(flow_mask=fmk, want_valid=True, want_flags=True, want_src_flags=(c == 2))):
         outs = []
-        for path in (0, 1, 3, 4, 5):            # auto, generic, staged two tiles per block, staged one tile per block, > 3 channels as launches of 3
+        for path in (0, 1, 3, 4, 5, 6, 7):      # auto (lean launches: row tables, 1 or 2 tiles per block at these sizes), generic, staged two tiles per block, staged one tile per block, > 3 channels as launches of 3, the sheared rectangle, four-tile columns with row tables whatever the size
             if path == 5 and c <= 3:
                 continue
             _native.set_warp_path(path)

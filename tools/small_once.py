@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, bench
 import oflibpytorch_amd as ofl
+from oflibpytorch_amd import _native
+_native.set_warp_path(int(os.environ.get('OFL_PATH', '0')))
 dev = torch.device('cuda', 0)
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 6]:
     f1, f2, img, m1, m2, tm = bench.make_inputs(n, 1080, 1920, dev, 0)
