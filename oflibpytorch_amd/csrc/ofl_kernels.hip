@@ -594,42 +594,41 @@ __device__ __forceinline__ void lds_write(f4* lds, const LdsBox& B, const LdsSta
     }
 }
 
-// step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
-// GRAD (ofl_warp_bwd_grad_f32, gradient with respect to the FLOW): instead of the blend, the taps of a pixel are combined
-// with its upstream gradient `gq` into ATen's gix / giy sums (grid_sampler_2d_backward), chained through the
-// un-normalisation, normalise_coords and `grid - flow` exactly as autograd does -- same expressions, same order as the
-// one-pixel-per-lane kernel of ofl_aux_kernels.hip (the two are compared bit for bit); outv[k] = (d/du, d/dv, -, -).
-constexpr int kRowTab = 64;                    // rows of a tile's row table (warp_bwd_rows_kernel)
+// ---- switches of the ROW-TABLE kernels (warp_bwd_rows_kernel and the ROWS instantiation of the channel loop, below; profiles/r5_warp_row_extents.txt)
+constexpr int kRowTab = 64;                    // rows of a tile's row table
 #ifndef OFL_ROWS_DEDUPE
-#define OFL_ROWS_DEDUPE 1
+#define OFL_ROWS_DEDUPE 1     // neighbouring lanes with the same rows post once (DPP): -3 ... -6 % under smooth flows
 #endif
 #ifndef OFL_ROWS_PAD
 #define OFL_ROWS_PAD 0        // 1: rows padded to the rectangle's pitch rule -- measured slower everywhere (+2 ... 6 %: more LDS, no fewer conflicts -- the rows' own start columns already scatter them)
 #endif
 #ifndef OFL_ROWS_STAMPS
-#define OFL_ROWS_STAMPS 0
+#define OFL_ROWS_STAMPS 0     // 1: s_memtime stamps per phase, summed per block (tools/rows_stamps.py; never in a default build)
 #endif
 #ifndef OFL_WARP_ROWS_ADD
-#define OFL_WARP_ROWS_ADD 1
+#define OFL_WARP_ROWS_ADD 1   // mode 3 (the addend is the flow operand) on the row-table kernel
 #endif
 #ifndef OFL_ROWS_T
-#define OFL_ROWS_T 4
+#define OFL_ROWS_T 4          // tiles per column of large launches (2 and 3 measured: slower at B = 8 and at B = 64)
 #endif
 #ifndef OFL_ROWS_ADD_REFORM
-#define OFL_ROWS_ADD_REFORM 0
+#define OFL_ROWS_ADD_REFORM 0 // 1: mode 3 re-forms a tile's positions from the flow registers at gather time instead of keeping them (+6 % time)
 #endif
 #ifndef OFL_WARP_ROWS_FLOWOPS
-#define OFL_WARP_ROWS_FLOWOPS 1      // the other flow-level instantiations on row tables too: another addend (modes 1-2, Flow.combine), src - src_b staging (mode 1 't'), the output's flag word
+#define OFL_WARP_ROWS_FLOWOPS 1      // the other instantiations on row tables too: another addend (modes 1-2, Flow.combine), src - src_b staging (mode 1 't'), the output's flag word, fp16 / uint8 sources, the gradient with respect to the flow
 #endif
 #ifndef OFL_WARP_CHAN_WIDE_MIN
-#define OFL_WARP_CHAN_WIDE_MIN (2 * 6912u)      // 32 x 16 tiles of the launch from which the channel loop runs on 64 x 16 tiles
+#define OFL_WARP_CHAN_WIDE_MIN (2 * 6912u)      // 32 x 16 tiles of the launch from which the channel loop on the RECTANGLE runs on 64 x 16 tiles (with row extents: every size)
 #endif
 #ifndef OFL_WARP_ROWS_SMALL
 #define OFL_WARP_ROWS_SMALL 1       // small plain launches and small mode 3 on the row-table kernel too (1 or 2 tiles per block)
 #endif
-#ifndef OFL_ROWS_SCHED_BARRIER
-#define OFL_ROWS_SCHED_BARRIER 0
-#endif
+
+// step 4a: gather from LDS (or from global memory when the box did not fit) and blend; per pixel (c0, c1, c2, mask channel)
+// GRAD (ofl_warp_bwd_grad_f32, gradient with respect to the FLOW): instead of the blend, the taps of a pixel are combined
+// with its upstream gradient `gq` into ATen's gix / giy sums (grid_sampler_2d_backward), chained through the
+// un-normalisation, normalise_coords and `grid - flow` exactly as autograd does -- same expressions, same order as the
+// one-pixel-per-lane kernel of ofl_aux_kernels.hip (the two are compared bit for bit); outv[k] = (d/du, d/dv, -, -).
 template <int NC, bool VALID, bool INTERIOR, bool SUB = false, typename TS = float, bool GRAD = false, bool CLIP = false, typename WP = WarpParams, bool ROWS = false>
 __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
                                                 const TS* __restrict__ sb, const uint8_t* __restrict__ sm,
@@ -652,9 +651,6 @@ __device__ __forceinline__ void lds_gather_impl(const WP& p, uint32_t hw,
         const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
         f4 tv[4];
         if (ROWS) {
-#if OFL_ROWS_SCHED_BARRIER
-            if ((k % OFL_ROWS_SCHED_BARRIER) == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);   // (bounds the taps in flight: the kernel sits at the register limit)
-#endif
             // ROW TABLE (warp_bwd_rows_kernel): image rows yi, yi + 1 each have their own start chunk and length; entry = byte address
             // of the row's slot for chunk (cxo + 128), biased, | 16 * length << 16 (0: row not staged; 1: a row without valid taps)
             const int yr = yi - B.org;
