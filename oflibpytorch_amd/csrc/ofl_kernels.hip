@@ -2197,7 +2197,7 @@ constexpr int kSpQ = OFL_SP_Q;                               // records the gath
 constexpr int kSubW = 16, kSubH = OFL_SP_SUBH;               // source subtiles: 4 lanes x 4 pixels wide, kSubH rows
 constexpr int kSubLanes = 4 * kSubH;                         // lanes per subtile (16: a DPP row; 8: half a row)
 constexpr int kRegH = 16;                                    // a bin block covers a 64 x 16 source region (its wave w: rows 4 w .. 4 w + 3)
-static_assert(kSubH == 2 || kSubH == 4, "subtile height");
+static_assert(kSubH == 1 || kSubH == 2 || kSubH == 4, "subtile height");
 constexpr int kBinCap = (512 / kSubH) * (kSpTW / 32);        // subtiles one destination tile can list (fixed-address lists: 4 * kBinCap bytes per tile)
 constexpr int kBinSpread = 256;                              // destination tiles one subtile may touch
 constexpr unsigned kFallbackBlocks = 256;                    // grid of the two-pass fallback inside the tiled splat: one block per CU, resident as a whole
@@ -2347,11 +2347,15 @@ __device__ __forceinline__ void sp_src_done(const SP& s, int sx4, int sy, bool i
 
 // min / max of two packed 16-bit fields over the lanes of a subtile (16: a DPP row, 8: half a row; every lane gets the result)
 __device__ __forceinline__ int row_pk_min_dpp(int v) {
-    v = pk_min16(v, OFL_DPP(v, 0xB1)); v = pk_min16(v, OFL_DPP(v, 0x4E)); v = pk_min16(v, OFL_DPP(v, 0x141));
+    v = pk_min16(v, OFL_DPP(v, 0xB1)); v = pk_min16(v, OFL_DPP(v, 0x4E));
+    if (kSubLanes == 4) return v;                                          // (a quad: the two quad permutations complete it)
+    v = pk_min16(v, OFL_DPP(v, 0x141));
     return kSubLanes == 16 ? pk_min16(v, OFL_DPP(v, 0x140)) : v;          // (8 lanes: the half-row mirror completes it)
 }
 __device__ __forceinline__ int row_pk_max_dpp(int v) {
-    v = pk_max16(v, OFL_DPP(v, 0xB1)); v = pk_max16(v, OFL_DPP(v, 0x4E)); v = pk_max16(v, OFL_DPP(v, 0x141));
+    v = pk_max16(v, OFL_DPP(v, 0xB1)); v = pk_max16(v, OFL_DPP(v, 0x4E));
+    if (kSubLanes == 4) return v;
+    v = pk_max16(v, OFL_DPP(v, 0x141));
     return kSubLanes == 16 ? pk_max16(v, OFL_DPP(v, 0x140)) : v;
 }
 
