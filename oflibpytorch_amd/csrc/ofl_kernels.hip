@@ -22,7 +22,7 @@
 int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int rows, void* stream);   // rows: per-row extents (warp_bwd_rows_kernel) where they apply
 int ofl_wide_launch_rows_small(const void* params, int nc, int valid, int add, int tiles, void* stream);   // small plain launches / mode 3: row tables, 1 or 2 tiles per block
 int ofl_wide_launch_rows_h(const void* params, void* stream);                  // fp16 sources on the row-table kernel
-int ofl_wide_launch_rows_grad(const void* params, int nc, void* stream);       // gradient wrt the flow on the row-table kernel
+int ofl_wide_launch_rows_grad(const void* params, int nc, int tiles, void* stream);       // gradient wrt the flow on the row-table kernel
 int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream);         // uint8 images (bytes in; bytes or fp32 out) on the row-table kernel
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles; rows: per-row extents where they apply
 
@@ -3620,14 +3620,17 @@ int ofl_wide_launch_rows_h(const void* params, void* stream) {
     return (int)hipGetLastError();
 }
 // the gradient with respect to the flow (ofl_warp_bwd_grad_f32), large launches with W % 4 == 0: the row-table kernel
-int ofl_wide_launch_rows_grad(const void* params, int nc, void* stream) {
+int ofl_wide_launch_rows_grad(const void* params, int nc, int tiles, void* stream) {      // tiles per block: OFL_ROWS_T for large launches, 1 / 2 for tiny / small ones
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
     constexpr int RT = OFL_ROWS_T;
-    const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
+    const int tt = tiles == 1 ? 1 : (tiles == 2 ? 2 : RT);
+    const unsigned gr = warp_geometry(q, kLdsTWQ * 4, tt * kLdsTH);
     if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.valid || q.src_b || q.dst_flags) return (int)hipErrorInvalidValue;
-#define OFL_ROWS_G(NC) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, false, 0, false, false, float, float, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
-    switch (nc) { case 1: OFL_ROWS_G(1); break; case 2: OFL_ROWS_G(2); break; default: OFL_ROWS_G(3); break; }
+#define OFL_ROWS_G(T_, NC) hipLaunchKernelGGL((warp_bwd_rows_kernel<T_, NC, false, 0, false, false, float, float, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
+#define OFL_ROWS_GT(T_) switch (nc) { case 1: OFL_ROWS_G(T_, 1); break; case 2: OFL_ROWS_G(T_, 2); break; default: OFL_ROWS_G(T_, 3); break; }
+    if (tt == 1) { OFL_ROWS_GT(1) } else if (tt == 2) { OFL_ROWS_GT(2) } else { OFL_ROWS_GT(RT) }
+#undef OFL_ROWS_GT
 #undef OFL_ROWS_G
     return (int)hipGetLastError();
 }
@@ -3927,7 +3930,13 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
     p.shear = (g_warp_shear && (int64_t)h + 4 * (int64_t)w + 8 < 32760) ? 1 : 0;
     const unsigned g = warp_geometry(p, kLdsTWQ * 4, kLdsT * kLdsTH);
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
-    if (OFL_WARP_ROWS_FLOWOPS && g >= 6912u && warp_is_lean(p) && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) return ofl_wide_launch_rows_grad(&p, c, (void*)st);   // 64 x 16 tiles, per-row extents
+    if (OFL_WARP_ROWS_FLOWOPS && warp_is_lean(p) && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) {   // 64 x 16 tiles, per-row extents
+        if (g >= 6912u || g_warp_path == 7) return ofl_wide_launch_rows_grad(&p, c, OFL_ROWS_T, (void*)st);
+        if (OFL_WARP_ROWS_SMALL && g_warp_path == 0) {            // small launches (the shapes training runs at): one tile per block for tiny ones, else two
+            WarpParams q1 = p;
+            return ofl_wide_launch_rows_grad(&p, c, warp_geometry(q1, kLdsTWQ * 4, kLdsTH) < 6912u ? 1 : 2, (void*)st);
+        }
+    }
     switch (c) {
         case 1: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 1, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
         case 2: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
