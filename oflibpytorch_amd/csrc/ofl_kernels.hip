@@ -1047,22 +1047,28 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
 #endif
 }
 
-// ROW TABLES (OFL_WARP_ROWS; VERDICT r4 item 2: "per-row extents of the staged box").  The column kernel above stages ONE y-sheared
-// rectangle per tile; under the bench flow (sigma 8) it holds 1.65 source pixels per output pixel of a 64 x 16 tile, and a rougher flow
-// overflows it (10.8 % of the tiles at sigma 12, 27.5 % at sigma 16).  Here every source ROW the tile touches has its own first chunk
-// and length (tools/box_rows_model_wide3.py: 1.27 staged pixels per output pixel at sigma 8, 1.35 / 1.45 at sigma 12 / 16, and what does
-// not fit is a handful of PIXELS, not tiles):
-//   post   every lane puts the chunk range of its 4 pixels' taps on the rows they touch: ds_min / ds_max on a 64-row table whose
-//          first row `org` is an ESTIMATE (the flow at 3 x 3 points of the tile, scalar loads, minus a margin) -- so that no
-//          block-wide reduction has to come first.  A row outside the table is dropped and flagged.
-//   scan   after the barrier that publishes the previous tile's staged data anyway, every wave reads the table (lane = row),
-//          clips the ranges to the frame, prefix-sums the lengths (DPP) and writes one 32-bit ENTRY per row for the gather:
-//          biased byte address of the row's first slot | 16 * length << 16.  Rows beyond the block's 768 chunks are not staged.
-//   issue  chunk i of the packed rows -> thread i (dense, 3 rounds): the row of a wave's first chunk from a ballot, the rows of
-//          its other 63 by a short uniform loop over the following rows' sums (v_readlane), the row's start / length by ds_bpermute.
+// ROW TABLES (OFL_WARP_ROWS; VERDICT r4 item 2: "per-row extents of the staged box"; profiles/r5_warp_row_extents.txt).  The column
+// kernel above stages ONE y-sheared rectangle per tile; under the bench flow (sigma 8) it holds 1.65 source pixels per output pixel of a
+// 64 x 16 tile, and a rougher flow overflows it (10.8 % of the tiles at sigma 12, 27.5 % at sigma 16).  Here every source ROW the tile
+// touches has its own first chunk and length, the rows packed back to back in LDS (tools/box_rows_model_wide3.py: 1.27 staged pixels per
+// output pixel at sigma 8, 1.35 / 1.45 at sigma 12 / 16, and what does not fit is a handful of PIXELS, not tiles):
+//   post   every lane puts the chunk range of its 4 pixels' taps on the image rows they touch: ds_min / ds_max on a 64-row table whose
+//          first row `org` is an ESTIMATE (the flow at 3 x 3 points of each tile of the column: ONE vector load, rows_origins) -- so
+//          that no block-wide reduction has to come first.  A row outside the table is dropped and flagged; neighbouring lanes with
+//          the same rows post once (DPP).
+//   scan   after the barrier that publishes the previous tile's staged data anyway, every wave reads the table (lane = row), clips the
+//          ranges to the frame, prefix-sums the lengths (DPP), writes one 32-bit ENTRY per row for the gather (biased byte address of
+//          the row's slot for a reference chunk | 16 * length << 16; 0: not staged, 1: no valid tap) and marks the rows' first chunks
+//          in a byte map.  Rows beyond the block's kRowChunks chunks are not staged.
+//   issue  chunk i of the packed rows -> thread i (dense): the row of a chunk = prefix MAXIMUM (DPP) of the start marks of the wave's
+//          64 chunks, the row that holds the wave's first chunk (ballot + popcount) as the carry; the row's start / length by
+//          ds_bpermute from the scan's registers.  Two rounds through registers, in flight while the previous tile is gathered; the
+//          rare third is loaded and written on the spot (rows_extra).
 //   gather two entries per pixel (rows yi, yi + 1: one ds_read2_b32), address = entry + (x & 3) * length16 + 16 * (x >> 2): no shear,
 //          no multiply by a pitch.  A pixel with an unstaged row takes its taps from global memory (as for an oversize box).
-// Same expressions per pixel as the column kernel: bit-identical.  Lean launches on 64 x 16 tiles only (ofl_wide_launch_column).
+// Same expressions per pixel as the column kernel: bit-identical.  64 x 16 tiles (ofl_warp_wide.hip); launches with W % 4 == 0 and no
+// flow-flag by-product: four tiles per block for large ones, one or two for small ones (ofl_wide_launch_column / _rows_small / _rows_h /
+// _rows_u8 / _rows_grad, and the channel loop's ROWS instantiation).
 #ifndef OFL_WARP_ROWS
 #define OFL_WARP_ROWS 1
 #endif
