@@ -623,6 +623,9 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table
 #ifndef OFL_ROWS_T1_MAX
 #define OFL_ROWS_T1_MAX 5000u      // 32 x 16 tiles of a launch below which the row-table kernel runs one tile per block (above: two, up to the column threshold); tools/shapes_once.py: 3 600 / 4 096 tiles 3 % better with one, 6 144 tiles 13 % better with two
 #endif
+#ifndef OFL_ROWS_T4_MIN
+#define OFL_ROWS_T4_MIN 5800u      // four-tile column groups (32-wide geometry) from which the row-table kernel runs four tiles per block (below: two / one)
+#endif
 #ifndef OFL_WARP_ROWS_SMALL
 #define OFL_WARP_ROWS_SMALL 1       // small plain launches and small mode 3 on the row-table kernel too (1 or 2 tiles per block)
 #endif
@@ -3737,9 +3740,9 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
         if (OFL_WARP_COL_ADD >= 2) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 0, (void*)st);
         // large launches of mode 3 proper: 64 x 16 tiles with per-row extents (warp_bwd_rows_kernel<.., ADD>)
-        if (OFL_WARP_ROWS_ADD && NC == 2 && (p.add_is_flow || OFL_WARP_ROWS_FLOWOPS) && warp_is_lean(q) && g >= 6912u && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4)
+        if (OFL_WARP_ROWS_ADD && NC == 2 && (p.add_is_flow || OFL_WARP_ROWS_FLOWOPS) && warp_is_lean(q) && g >= (g_warp_path == 0 && p.add_is_flow && OFL_WARP_ROWS_SMALL ? OFL_ROWS_T4_MIN : 6912u) && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4)
             return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 1, 1, (void*)st);
-        if (OFL_WARP_ROWS_SMALL && NC == 2 && p.add_is_flow && warp_is_lean(q) && g < 6912u && g_warp_path == 0) {     // small mode 3
+        if (OFL_WARP_ROWS_SMALL && NC == 2 && p.add_is_flow && warp_is_lean(q) && g < OFL_ROWS_T4_MIN && g_warp_path == 0) {     // small mode 3
             WarpParams q1 = p;
             return ofl_wide_launch_rows_small(&p, 2, valid ? 1 : 0, 1, warp_geometry(q1, kLdsTWQ * 4, kLdsTH) < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
         }
@@ -3775,7 +3778,9 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         // small plain launches on the row-table kernel (1 tile per block for tiny ones, else 2): see ofl_wide_launch_rows_small
         if (OFL_WARP_ROWS_SMALL && (NC == 2 || NC == 3) && !add && !p.flow_flags && g_warp_path == 0 && warp_is_lean(q1)) {
             WarpParams q4 = p;
-            if (warp_geometry(q4, kLdsTWQ * 4, kLdsT * kLdsTH) < kColumnMinGroups) return ofl_wide_launch_rows_small(&p, NC, valid ? 1 : 0, 0, g1 < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
+            const unsigned g4 = warp_geometry(q4, kLdsTWQ * 4, kLdsT * kLdsTH);
+            if (g4 < OFL_ROWS_T4_MIN) return ofl_wide_launch_rows_small(&p, NC, valid ? 1 : 0, 0, g1 < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
+            if (g4 < kColumnMinGroups) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 0, 1, (void*)st);      // (four tiles per block a little earlier than the rectangle's kernels: B = 6 at 1080p 76.5 -> 74.5 us)
         }
         if (g_warp_path == 4 || (g_warp_path != 3 && g1 < kColumnMinGroups)) {
             if (warp_is_lean(q1) && valid) {            // (the lean twins of the two instantiations with a valid mask: BASELINE configs[1] is one of them)
@@ -3940,7 +3945,7 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
     const unsigned g = warp_geometry(p, kLdsTWQ * 4, kLdsT * kLdsTH);
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
     if (OFL_WARP_ROWS_FLOWOPS && warp_is_lean(p) && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) {   // 64 x 16 tiles, per-row extents
-        if (g >= 6912u || g_warp_path == 7) return ofl_wide_launch_rows_grad(&p, c, OFL_ROWS_T, (void*)st);
+        if (g >= (OFL_WARP_ROWS_SMALL && g_warp_path == 0 ? OFL_ROWS_T4_MIN : 6912u) || g_warp_path == 7) return ofl_wide_launch_rows_grad(&p, c, OFL_ROWS_T, (void*)st);
         if (OFL_WARP_ROWS_SMALL && g_warp_path == 0) {            // small launches (the shapes training runs at): one tile per block for tiny ones, else two
             WarpParams q1 = p;
             return ofl_wide_launch_rows_grad(&p, c, warp_geometry(q1, kLdsTWQ * 4, kLdsTH) < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
