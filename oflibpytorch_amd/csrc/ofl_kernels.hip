@@ -1358,7 +1358,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     rows_origins<T>(p, osample, org, cxo);
     OFL_RS(10);
     f4* lds = reinterpret_cast<f4*>(smem);
-    constexpr bool REFORM = ADD == 1 && (OFL_ROWS_ADD_REFORM || DF);     // (with the flag by-product the kept positions spill: 32 B of scratch)      // mode 3: re-form a tile's positions from the flow registers at gather time instead of keeping them
+    // mode 3: a tile's positions are KEPT from the posts to the gather (-6 % against re-forming them from the flow registers) -- except with
+    // the flag by-product, where the kept positions spill (32 B of scratch)
+    constexpr bool REFORM = ADD == 1 && (OFL_ROWS_ADD_REFORM || DF);
     LdsCoords Tc[REFORM ? 1 : T];
     RowGeo Gx[T];
     RowStage<NC> S;
@@ -1414,7 +1416,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         else lds_store<NC, VALID, ADD != 0, DF, TD>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
         OFL_RS(8);
         if (k + 1 >= T) break;
-        if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's scan, two barriers ago)
+        if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's rows_extra, before the barrier above)
         lds_barrier();
         OFL_RS(9);
     }
