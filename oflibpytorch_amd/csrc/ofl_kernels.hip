@@ -609,7 +609,7 @@ constexpr int kRowTab = 64;                    // rows of a tile's row table
 #define OFL_WARP_ROWS_ADD 1   // mode 3 (the addend is the flow operand) on the row-table kernel
 #endif
 #ifndef OFL_ROWS_T
-#define OFL_ROWS_T 4          // tiles per column of large launches (2 and 3 measured: slower at B = 8 and at B = 64)
+#define OFL_ROWS_T 4          // tiles per column of large launches (2 and 3 measured: slower at B = 8 and at B = 64; 6 and 8, with an early exit below the frame: apply level, mode 3 +3 ... 5 % -- the prologue is not what is left)
 #endif
 #ifndef OFL_ROWS_ADD_REFORM
 #define OFL_ROWS_ADD_REFORM 0 // 1: mode 3 re-forms a tile's positions from the flow registers at gather time instead of keeping them (+6 % time)
@@ -1097,10 +1097,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // (tile k in the 16 lanes of DPP row k: lanes 0..8 its nine samples of v, lane 9 a sample of u), a row minimum, v_readlane.
 // (First cut: 10 scalar loads per tile.  The compiler chained them -- load, wait, min, next load -- and the 40 round trips were 30 %
 // of a block's life in the phase stamps.)  Issued before the flow loads: older in the vmcnt queue, waited for without them.
-template <int T, typename WP>
+template <int T, int K0 = 0, typename WP>
 __device__ __forceinline__ float rows_origins_load(const WP& p, const float* __restrict__ fu, uint32_t hw, int tx, int tyg) {
-    static_assert(T <= 4, "one DPP row per tile of the column");
-    const int l = threadIdx.x & 63, k = l >> 4, j = min(l & 15, 9);
+    static_assert(T <= 8, "one DPP row per tile: four tiles per load (K0: the first of them)");
+    const int l = threadIdx.x & 63, k = K0 + (l >> 4), j = min(l & 15, 9);
     const int w = p.w, h = p.h;
     const int sy = j < 9 ? j / 3 : 1, sx = j < 9 ? j % 3 : 0;
     const int x = min(tx * (kLdsTWQ * 4) + (sx == 0 ? 0 : sx == 1 ? kLdsTWQ * 2 : kLdsTWQ * 4 - 1), w - 1);
@@ -1108,7 +1108,7 @@ __device__ __forceinline__ float rows_origins_load(const WP& p, const float* __r
     const float f = fu[(j < 9 ? hw : 0u) + (uint32_t)(y * w + x)];
     return (j < 9 ? (float)y : (float)x) - p.flow_sign * f;          // sample row (lanes 0..8) / sample column (lane 9 and its duplicates)
 }
-template <int T, typename WP>
+template <int T, int K0 = 0, typename WP>
 __device__ __forceinline__ void rows_origins(const WP& p, float s, int (&org)[T], int (&cxo)[T]) {
     const int j = threadIdx.x & 15;
     float m = j < 9 ? s : 3.0e38f;
@@ -1116,9 +1116,9 @@ __device__ __forceinline__ void rows_origins(const WP& p, float s, int (&org)[T]
     OFL_FMIN_DPP(0xB1); OFL_FMIN_DPP(0x4E); OFL_FMIN_DPP(0x141); OFL_FMIN_DPP(0x140);
 #undef OFL_FMIN_DPP
 #pragma unroll
-    for (int k = 0; k < T; ++k) {
-        const float mn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16 * k));
-        const float xl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16 * k + 9));
+    for (int k = K0; k < (T < K0 + 4 ? T : K0 + 4); ++k) {
+        const float mn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16 * (k - K0)));
+        const float xl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), 16 * (k - K0) + 9));
         org[k] = (int)floorf(__builtin_amdgcn_fmed3f(mn, -2.0f, (float)p.h)) - kRowMargin;
         cxo[k] = ((int)floorf(__builtin_amdgcn_fmed3f(xl, -2.0f, (float)p.w)) >> 2) + 16;
     }
@@ -1350,12 +1350,14 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     unsigned long long acc_[12] = {}, last_ = __builtin_amdgcn_s_memtime();
 #endif
     const float osample = rows_origins_load<T>(p, fu, hw, tx, tyg);
+    const float osample2 = T > 4 ? rows_origins_load<T, 4>(p, fu, hw, tx, tyg) : 0.0f;
     load_flow(0);
     if (T > 1) load_flow(1);
     reset(0); reset(1);                   // tile k posts to table k & 1; it is reset for tile k + 2 while tile k is gathered
     clear_starts(0);
     int org[T], cxo[T];
     rows_origins<T>(p, osample, org, cxo);
+    if (T > 4) rows_origins<T, 4>(p, osample2, org, cxo);
     OFL_RS(10);
     f4* lds = reinterpret_cast<f4*>(smem);
     // mode 3: a tile's positions are KEPT from the posts to the gather (-6 % against re-forming them from the flow registers) -- except with
@@ -1416,6 +1418,7 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
         else lds_store<NC, VALID, ADD != 0, DF, TD>(p, tx, tyk, n, hw, fmw(k), outv, ad, &dflags);
         OFL_RS(8);
         if (k + 1 >= T) break;
+        if (T > 4 && (tyk + 1) * kLdsTH >= h) break;          // (taller columns only: nothing but duplicates of the frame's last row follows)
         if (k + 2 < T) reset(k & 1);       // (its last reader was this tile's rows_extra, before the barrier above)
         lds_barrier();
         OFL_RS(9);
