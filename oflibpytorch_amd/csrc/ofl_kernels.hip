@@ -3608,17 +3608,18 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
 
 // SMALL plain lean launches (below the four-tile column's threshold): the row-table kernel with one tile (tiny: B = 1 at 1080p) or two
 // tiles per block -- B = 2 ... 6 at 1080p: -13 ... -14 % against the two-tile kernel on the sheared rectangle (53 -> 62 %, 58 -> 68 %,
-// 61 -> 71 % of 8 TB/s; tools/small_once.py), B = 1 -1.5 %.  2 / 3 channels (flows / images) and mode 3 proper.
+// 61 -> 71 % of 8 TB/s; tools/small_once.py), B = 1 -1.5 %.  1 ... 3 channels and mode 3 proper.
 int ofl_wide_launch_rows_small(const void* params, int nc, int valid, int add, int tiles, void* stream) {
     WarpParams q = *static_cast<const WarpParams*>(params);
     q.lds_bytes = kLdsBytes;
     hipStream_t st = (hipStream_t)stream;
-    if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.src_b || q.dst_flags || !(nc == 2 || nc == 3) || (add && !(nc == 2 && q.add_is_flow))) return (int)hipErrorInvalidValue;
+    if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.src_b || q.dst_flags || nc < 1 || nc > 3 || (add && !(nc == 2 && q.add_is_flow))) return (int)hipErrorInvalidValue;
     const unsigned gs = warp_geometry(q, kLdsTWQ * 4, (tiles == 1 ? 1 : 2) * kLdsTH);
 #define OFL_ROWS_S(T_, NC, V, A) hipLaunchKernelGGL((warp_bwd_rows_kernel<T_, NC, V, A>), dim3(gs), dim3(kLdsNT), kRowsLdsBytes, st, q)
 #define OFL_ROWS_ST(T_)                                                                                   \
     if (add) { if (valid) OFL_ROWS_S(T_, 2, true, 1); else OFL_ROWS_S(T_, 2, false, 1); }                \
     else if (nc == 2) { if (valid) OFL_ROWS_S(T_, 2, true, 0); else OFL_ROWS_S(T_, 2, false, 0); }       \
+    else if (nc == 1) { if (valid) OFL_ROWS_S(T_, 1, true, 0); else OFL_ROWS_S(T_, 1, false, 0); }       \
     else { if (valid) OFL_ROWS_S(T_, 3, true, 0); else OFL_ROWS_S(T_, 3, false, 0); }
     if (tiles == 1) { OFL_ROWS_ST(1) } else { OFL_ROWS_ST(2) }
 #undef OFL_ROWS_ST
@@ -3781,7 +3782,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         const unsigned g1 = warp_geometry(q1, kLdsTWQ * 4, kLdsTH);
         if (g_warp_path == 7 && !add && warp_is_lean(q1)) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 0, 1, (void*)st);   // (tests / experiments: four-tile columns with row tables whatever the size)
         // small plain launches on the row-table kernel (1 tile per block for tiny ones, else 2): see ofl_wide_launch_rows_small
-        if (OFL_WARP_ROWS_SMALL && (NC == 2 || NC == 3) && !add && !p.flow_flags && g_warp_path == 0 && warp_is_lean(q1)) {
+        if (OFL_WARP_ROWS_SMALL && !add && !p.flow_flags && g_warp_path == 0 && warp_is_lean(q1)) {
             WarpParams q4 = p;
             const unsigned g4 = warp_geometry(q4, kLdsTWQ * 4, kLdsT * kLdsTH);
             if (g4 < OFL_ROWS_T4_MIN) return ofl_wide_launch_rows_small(&p, NC, valid ? 1 : 0, 0, g1 < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
