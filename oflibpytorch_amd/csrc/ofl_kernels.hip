@@ -1342,6 +1342,9 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_rows_kernel(const WarpPara
     // in the LDS, not in a register -- at the register limit (168) the allocator spilled exactly these words, and a scratch reload is a
     // VMEM operation whose wait (vmcnt(0)) also waits for the next tile's staging loads
     __shared__ uint32_t park[2][kLdsNT];
+    // three blocks per CU need <= 53 760 bytes of LDS per block (measured: 53 296 -> three blocks, 53 816 -> two, and every kernel
+    // of this family 10-25 % slower: 520 bytes more in RowTabs did that in an experiment)
+    static_assert(kLdsNT != 256 || kRowsLdsBytes + (int)sizeof(RowTabs) + (int)sizeof(park) <= 53760, "LDS budget of three blocks per CU");
     auto fm_park = [&](int k) { if (VALID) park[k & 1][tid] = fmk[k]; };
     auto fmw = [&](int k) -> uint32_t { return (VALID && !fm) ? 0x01010101u : (VALID ? park[k & 1][tid] : 0x01010101u); };
     auto reset = [&](int t) { if (tid <= kRowTab) { rt.tmin[t][tid] = 0x7fffffff; rt.tmax[t][tid] = -0x7fffffff; } };
