@@ -77,6 +77,10 @@ int ofl_version(void);
  *   All options are PROCESS-GLOBAL, unsynchronised testing / benchmarking aids: set them before any concurrent use of the
  *   library, never from two threads; production code leaves them alone. */
 #define OFL_OPT_SPLAT_FALLBACK_SLOTS 5
+/*   OFL_OPT_SPLAT_PATH: gather kernel of ofl_splat_tiled_f32 and its relatives: 0 = the round-6 kernel (16-24-byte records,
+ *   one-word cells: three 512-thread blocks per CU), 1 = round 5's (32-byte records, two blocks per CU).  Same sums in the same
+ *   order: bit-identical results (the tests compare them); speed only. */
+#define OFL_OPT_SPLAT_PATH 6
 int ofl_set_option(int32_t key, int32_t value);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,

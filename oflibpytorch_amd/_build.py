@@ -5,7 +5,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SOURCES = [os.path.join(_PKG, "csrc", "ofl_kernels.hip"), os.path.join(_PKG, "csrc", "ofl_aux_kernels.hip"),
+SOURCES = [os.path.join(_PKG, "csrc", "ofl_kernels.hip"), os.path.join(_PKG, "csrc", "ofl_aux_kernels.hip"), os.path.join(_PKG, "csrc", "ofl_splat_gather.hip"),
            os.path.join(_PKG, "csrc", "ofl_warp_wide.hip")]
 HEADERS = [os.path.join(_ROOT, "include", "oflib_hip.h")]
 LIB_PATH = os.path.join(_PKG, "libofl_hip.so")

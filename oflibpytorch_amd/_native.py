@@ -573,6 +573,12 @@ def splat_tile_geometry() -> tuple:
     return tw.value, th.value, cap.value
 
 
+def set_splat_gather_kernel(which: int):
+    """Gather splat: 0 = the round-6 kernel (compact records, three blocks per CU; default), 1 = round 5's kernel.  The same sums
+    in the same order -- bit-identical results; tests compare the two, tools time them against each other."""
+    _check(load_library().ofl_set_option(6, int(which)), "ofl_set_option")
+
+
 def set_splat_fallback_slots(k: int):
     """Gather splat: the fallback accumulator holds k images (0 = automatic); tests use 1 to force several rounds."""
     _check(load_library().ofl_set_option(5, int(k)), "ofl_set_option")

@@ -25,6 +25,8 @@ int ofl_wide_launch_rows_h(const void* params, void* stream);                  /
 int ofl_wide_launch_rows_grad(const void* params, int nc, int tiles, void* stream);       // gradient wrt the flow on the row-table kernel
 int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream);         // uint8 images (bytes in; bytes or fp32 out) on the row-table kernel
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles; rows: per-row extents where they apply
+// the gather splat's diet kernel (ofl_splat_gather.hip: this file compiled with OFL_SPLAT_TU); `params` = a GatherParams; elem: 0 fp32, 1 fp16 in / fp32 out, 2 fp16 in and out
+int ofl_splat_launch_gather_diet(const void* params, int nc, int mch, int elem, unsigned grid, void* stream);
 
 namespace {
 
@@ -1916,6 +1918,10 @@ struct SplatParams {
 // scalar loads, compares and branches they cost per use) out of the lean instantiations of the bin and gather kernels.  The host
 // picks them when the promises hold (splat_tiled_impl): apply 's' -6.5 %, switch_ref -8.7 % (profiles/r5_splat_lean.txt).
 struct SplatParamsLean : SplatParams { static constexpr bool kLean = true; };
+// the promises of SplatParamsLean hold for this call (the lean instantiations exist for 2 and 3 channels)
+inline bool splat_is_lean(const SplatParams& s) {
+    return s.flow != nullptr && s.fw == 0 && (s.w & 3) == 0 && s.round_mode == OFL_ROUND_NONE;
+}
 // the switches, as the kernels' helpers read them (s: a SplatParams or SplatParamsLean, in any address space)
 #define OFL_SP_WINDOW(s_) (!std::remove_reference<decltype(s_)>::type::kLean && (s_).fw != 0)
 #define OFL_SP_WREM(s_) (std::remove_reference<decltype(s_)>::type::kLean ? 0 : ((s_).w & 3))
@@ -3353,6 +3359,454 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward splat, gather formulation ON A DIET (round 6): splat_gather_kernel's algorithm with THREE blocks = 24 waves per CU
+// ------------------------------------------------------------------------------------------------
+// profiles/r5_splat_scan.txt: the round-5 kernel is latency-bound -- one block per CU instead of two costs x 1.6 -- and what kept
+// it at two blocks was 81 KB of LDS and 119-125 VGPRs per 512-thread block.  Same phases (A scan, S order, C sum), same arithmetic,
+// same order of every addition; what changed is what a tile keeps in LDS and in registers:
+//   * a RECORD is 16 + 0 / 4 / 8 bytes (1 / 2 / 3 data channels) instead of 32: part A = (fx, fy, d0, d1 -- one channel: the key
+//     in d1's place), part B = the key (2 channels) or (d2, key) (3 channels), in two arrays.  fx = x - x0 and fy = y - y0 are the
+//     reference's weights wt_x1 / wt_y1 themselves (utils.py:1110-1111); the other two, x1 - x and y1 - y with x1 = x0 + 1, are
+//     re-formed by the reader as 1 - fx / 1 - fy: for a cell inside the frame (x0 >= 0) x - x0 is EXACT in fp32 (a multiple of
+//     ulp(x) below 1), so (x0 + 1) - x and 1 - fx are the correct rounding of the same real number -- the same float.  (A cell left
+//     of / above the frame, x0 = -1, only ever serves its x1 / y1 corner: fx is stored as the reference rounds it, 1 - fx is never
+//     read.)  The four products wy * wx are formed by the reader, once per use, as the reference's outer product forms them;
+//   * a CELL is ONE 32-bit word: records so far << 16 | newest record, every record on a chain through `link` (16 bits per record).
+//     A record joins by compare-and-swap on that word (first try: "the cell is empty" -- true for three records in four); the
+//     returned word is the previous head AND the arrival number, so the third arrival still queues the cell for phase S.  4 bytes per
+//     cell instead of 16;
+//   * phase S leaves cells of 3 or 4 records as a chain IN RASTER ORDER (their readers add the records one by one: there is no room
+//     for class sums in 3 x 20 bytes) and pre-sums longer cells into part A of their first 1 + NCH records (marker 0xffff in the
+//     word's count; the chain links those records);
+//   * capacity: 2 048 records with 1 or 2 data channels (flows: fewer banded tiles than the 1 792 of round 5), 1 792 with 3.
+// LDS per block: 45.2 KB (1 channel) / 52.4 KB (2) / 52.9 KB (3) -> 3 blocks per CU; __launch_bounds__(512, 6): <= 80 VGPRs.
+#ifndef OFL_SP_MINB2
+#define OFL_SP_MINB2 6
+#endif
+#ifndef OFL_SP_Q2
+#define OFL_SP_Q2 2048
+#endif
+#ifndef OFL_SP_Q3
+#define OFL_SP_Q3 1792
+#endif
+template <int NC> struct SpLay {
+    static constexpr int kQ = NC == 3 ? OFL_SP_Q3 : OFL_SP_Q2;           // records a tile holds at a time
+    static constexpr int kB = NC == 3 ? 8 : (NC == 2 ? 4 : 0);           // bytes of part B
+    static constexpr int kCW = kSpTW + 1, kCH = kSpTH + 1, kCells = kCW * kCH, kCellsP = (kCells + 63) / 64 * 64;
+    static constexpr int kRawBytes = (16 + kB + 2) * kQ + 4 * kCellsP;   // part A | part B | link | cell words
+    static constexpr int kNet = NC == 3 ? 6 : 8;                         // cells up to kNet records: a sorting network in one lane's registers
+    static constexpr int kLongQ = (kQ / 3 + 7) & ~7, kBigQ = kQ / (kNet + 1) + 1;
+};
+constexpr uint32_t kSp2End = 0xffffu, kSp2Empty = 0x0000ffffu, kSp2Sum = 0xffffu;   // end of a chain | an empty cell's word | count field of a pre-summed cell
+
+template <int NC>
+__device__ __forceinline__ uint32_t sp2_key(const f4* recA, const uint32_t* recB, uint32_t i) {
+    if (NC == 1) return reinterpret_cast<const uint32_t*>(recA)[4 * i + 3];
+    if (NC == 2) return recB[i];
+    return recB[2 * i + 1];
+}
+
+// data channels (mask channel last) of record i; av = its part A
+template <int NC, int NCH>
+__device__ __forceinline__ void sp2_data(const f4& av, const uint32_t* recB, uint32_t i, float (&d)[NCH > 0 ? NCH : 1]) {
+    uint32_t key = 0u;
+    d[0] = av[2];
+    if (NC == 1) key = __float_as_uint(av[3]);
+    if (NC >= 2) d[1] = av[3];
+    if (NC == 2 && NCH > NC) key = recB[i];
+    if (NC == 3) { const uint2 b = *reinterpret_cast<const uint2*>(recB + 2 * i); d[2] = __uint_as_float(b.x); key = b.y; }
+    if (NCH > NC) d[NC] = (float)(key & 1u);                              // the mask channel rides in the key
+}
+
+// One record of the cell whose column is DC (-1, 0, +1) cells from the pair's middle cell and whose row serves corner row KY, added
+// to the sums of the destination pixels that read it (see sp_use): weight = wy[KY] * wx[kx], rounded, then product with the data
+// rounded, then added.
+template <int NC, int NCH, int DC, int KY>
+__device__ __forceinline__ void sp2_use(const f4* recA, const uint32_t* recB, uint32_t i, float (&a)[2][2][1 + NCH]) {
+    const f4 av = recA[i];
+    float d[NCH > 0 ? NCH : 1];
+    sp2_data<NC, NCH>(av, recB, i, d);
+    const float wy = KY == 0 ? 1.0f - av[1] : av[1];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int kx = k - DC;
+        if (kx < 0 || kx > 1) continue;
+        const float wx = kx == 0 ? 1.0f - av[0] : av[0];
+        const float wgt = wy * wx;
+        a[k][kx][0] += wgt;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) a[k][kx][1 + c] += wgt * d[c];
+    }
+}
+
+// a pre-summed cell: part A of the records on its chain holds one f4 (the four corner classes) per channel
+template <int NCH, int DC, int KY>
+__device__ __forceinline__ void sp2_use_presum(const f4* recA, const uint16_t* link, uint32_t i, float (&a)[2][2][1 + NCH]) {
+#pragma unroll
+    for (int c = 0; c < 1 + NCH; ++c) {
+        const f4 pv = recA[i];
+        if (c < NCH) i = link[i];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int kx = k - DC;
+            if (kx < 0 || kx > 1) continue;
+            a[k][kx][c] += pv[KY * 2 + kx];
+        }
+    }
+}
+
+// A cell with more than kNet (and at most 64) records, ordered and summed by the 64 lanes of one wave (see sp_order_big_cell).
+template <int NC, int NCH>
+__device__ __attribute__((noinline)) void sp2_order_big_cell(f4* recA, uint32_t* recB, uint16_t* link, uint32_t* cellw, int c, int lane) {
+    const uint32_t cw = cellw[c];
+    const int cn = (int)__builtin_amdgcn_readfirstlane((int)(cw >> 16));
+    // 1. the cell's record indices, one per lane (the chain is walked once; every lane reads the same word)
+    uint32_t idx = 0, cur = cw & 0xffffu;
+    for (int j = 0; j < cn; ++j) {
+        const uint32_t cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        idx = lane == j ? cs : idx;
+        cur = (uint32_t)link[cs];
+    }
+    const bool mine = lane < cn;
+    // 2. rank of every record = number of keys below its own (keys are source positions: all different)
+    const uint32_t key = mine ? sp2_key<NC>(recA, recB, idx) : 0xffffffffu;
+    uint32_t rank = 0;
+    for (int t = 0; t < cn; ++t) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, t) < key) ? 1u : 0u;
+    // 3. lane r gets the index of the r-th record in raster order
+    uint32_t sorted = 0;
+    if (mine) sorted = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)idx);
+    // 4. lane (class k, channel ch) adds its sum over the records in that order: weight (product of two, rounded) times data, rounded, added
+    const int k = lane & 3, ch = lane >> 2;
+    const bool acc_on = ch < 1 + NCH;
+    const bool is_mask = NCH > NC && ch == 1 + NC;
+    const float* recf = reinterpret_cast<const float*>(recA);
+    float acc = 0.0f;
+    for (int r = 0; r < cn; ++r) {
+        const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)sorted, r);
+        const float fx = recf[4 * ir], fy = recf[4 * ir + 1];
+        const float wv = ((k & 2) ? fy : 1.0f - fy) * ((k & 1) ? fx : 1.0f - fx);
+        float dv = 1.0f;                                                  // (density: the weight itself -- w * 1 is exact)
+        if (is_mask) dv = (float)(sp2_key<NC>(recA, recB, ir) & 1u);
+        else if (ch == 1) dv = recf[4 * ir + 2];
+        else if (ch == 2) dv = recf[4 * ir + 3];
+        else if (ch == 3 && NC == 3) dv = __uint_as_float(recB[2 * ir]);
+        acc += wv * dv;
+    }
+    // 5. the class sums where the cell's readers expect them: part A of the first 1 + NCH records (raster order), on a chain
+    const uint32_t mych = (uint32_t)__builtin_amdgcn_ds_bpermute((acc_on ? ch : 0) << 2, (int)sorted);          // (every lane takes part)
+    const uint32_t nxch = (uint32_t)__builtin_amdgcn_ds_bpermute((ch < NCH ? ch + 1 : 0) << 2, (int)sorted);
+    if (acc_on) {
+        reinterpret_cast<float*>(recA)[4 * mych + k] = acc;
+        if (k == 0) link[mych] = (uint16_t)(ch < NCH ? nxch : kSp2End);
+    }
+    if (lane == 0) cellw[c] = (kSp2Sum << 16) | (uint32_t)__builtin_amdgcn_readlane((int)sorted, 0);
+}
+
+template <int NC, bool MCH, typename TF = float, typename TO = float, bool LEAN = false>
+__global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(const GatherParams p_by_value_unused) {
+    GatherParamsK* pp = (GatherParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
+#define p (*pp)
+    constexpr int NCH = NC + (MCH ? 1 : 0);
+    using L = SpLay<NC>;
+    constexpr int kQ = L::kQ, kCW = L::kCW, kCellsP = L::kCellsP, kNet = L::kNet;
+    constexpr int kCellRounds = (kCellsP + kSpNT2 - 1) / kSpNT2;
+    constexpr uint32_t kEnd = kSp2End;
+    __shared__ __attribute__((aligned(16))) unsigned char raw[L::kRawBytes];
+    __shared__ int qcount, lqn, bqn;
+    __shared__ uint16_t lq[L::kLongQ];                                // cells with more than two records: phase S works on them lane by lane
+    __shared__ uint16_t bq[L::kBigQ];                                 // ... of those, the cells with more than kNet records: a wave each
+    static_assert((size_t)(1 + NCH) * kSpTW * kSpTH * sizeof(float) <= sizeof(raw), "the fold path's accumulators live in the record area");
+    f4* recA = reinterpret_cast<f4*>(raw);
+    uint32_t* recB = reinterpret_cast<uint32_t*>(raw + 16 * kQ);
+    uint16_t* link = reinterpret_cast<uint16_t*>(raw + (16 + L::kB) * kQ);
+    uint32_t* cellw = reinterpret_cast<uint32_t*>(raw + (18 + L::kB) * kQ);
+#define s (*reinterpret_cast<typename std::conditional<LEAN, SplatParamsLeanK, SplatParamsK>::type*>(&pp->s))   /* (see SplatParamsLean) */
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = s.w, h = s.h;
+    const uint32_t hw = (uint32_t)(h * w);
+    constexpr int kHalf = kSpNT2 / kSubLanes, kStep = 2 * kHalf;      // subtiles per half step (kSubLanes lanes each) / per step
+    int tx, ty, n;
+    if (!decode3(p.total, p.per_xcd, p.tiles_img, p.mi_m, p.mi_s, p.mx_m, p.mx_s, p.tiles_x, tx, ty, n)) return;
+    if (p.img_over[n] != 0) return;                                   // this image takes the global-atomics path instead
+    const uint32_t tile = (uint32_t)(n * (int)p.tiles_img + ty * p.tiles_x + tx);
+    const uint32_t* __restrict__ lst = p.list + (int64_t)tile * kBinCap;
+    // the first entries of the list are fetched WITH its length (fixed address, kBinCap slots: entries past the length are stale
+    // ids that are never used)
+    const uint32_t pre[2] = {lst[tid / kSubLanes], lst[kHalf + tid / kSubLanes]};
+    const int nlist = min(p.cnt[tile], kBinCap);
+    OFL_OPAQUE_S(pp);
+    SpTile t;
+    sp_tile_setup<TF>(s, tx, ty, n, t);
+    const int dx0 = t.dx0, dy0 = t.dy0, ly = t.ly, lx2 = t.lx2;
+    int dflags = 0;
+    const int sl = tid & (kSubLanes - 1), srow = sl >> 2, sc4 = sl & 3;
+    // one half step: the hit test of a lane's 4 source pixels, ranks by ballot + popcount, records and cells in LDS
+    auto process = [&](const SpSrc& q, int sx4, int sy, const f4 (&dat)[NC], uint32_t mc4, int r0, int r1) {
+        int cell[4];
+        unsigned long long m[4];
+        int wtot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cx = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, (float)w) - dx0 + 1;
+            const int cy = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, (float)h) - dy0 + 1;
+            const bool hit = ((q.on >> k) & 1u) != 0u && (uint32_t)cx < (uint32_t)kCW && cy >= r0 && cy <= r1;
+            cell[k] = hit ? cy * kCW + cx : -1;
+            m[k] = __ballot(hit);
+            wtot += __popcll(m[k]);
+        }
+        if (wtot != 0) {                                   // wave-uniform
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&qcount, wtot);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t pos = (uint32_t)(wbase + __popcll(m[k] & below));
+                wbase += __popcll(m[k]);
+                if (cell[k] >= 0 && pos < (uint32_t)kQ) {
+                    const float xv = q.x[k], yv = q.y[k];
+                    const float fx = xv - floorf(xv), fy = yv - floorf(yv);                                      // utils.py:1110-1111 (wt_x1, wt_y1)
+                    // key: raster position of the source pixel (15 bits each, checked by ofl_splat_tiled_f32) with the
+                    // mask-channel bit below it -- two records never share a position, so ordering by the whole word is raster order
+                    const uint32_t key = ((((uint32_t)sy << 15) | (uint32_t)(sx4 + k)) << 1) | ((mc4 >> (8 * k)) & 1u);
+                    f4 av = {fx, fy, s.data_sign * dat[0][k], NC >= 2 ? s.data_sign * dat[NC >= 2 ? 1 : 0][k] : __uint_as_float(key)};
+                    recA[pos] = av;
+                    if (NC == 2) recB[pos] = key;
+                    if (NC == 3) *reinterpret_cast<uint2*>(recB + 2 * pos) = make_uint2(__float_as_uint(s.data_sign * dat[NC - 1][k]), key);
+                    // the record joins its cell's chain: compare-and-swap of (count << 16 | head), first try "empty"
+                    uint32_t expect = kSp2Empty;
+                    for (;;) {
+                        const uint32_t got = atomicCAS(&cellw[cell[k]], expect, ((expect & 0xffff0000u) + 0x10000u) | pos);
+                        if (got == expect) break;
+                        expect = got;
+                    }
+                    link[pos] = (uint16_t)expect;
+                    // the cell's THIRD record makes it a cell phase S must order: exactly one thread sees two before its own
+                    if ((expect >> 16) == 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)cell[k];
+                }
+            }
+        }
+    };
+    // ---- A: walk the tile's list (see splat_gather_kernel): per half step EVERY load first, then the end points
+    auto scan = [&](int r0, int r1) {
+        OFL_OPAQUE_S(pp);
+        for (int base = 0; base < nlist; base += kStep) {
+            const bool two = base + kHalf < nlist;             // block-uniform: the second half step has entries
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) continue;
+                const int e = base + u * kHalf + tid / kSubLanes;
+                const bool have = e < nlist;
+                const uint32_t sub = base == 0 ? pre[u] : (have ? lst[e] : 0u);
+                const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
+                const int sx4 = (int)subx * kSubW + sc4 * 4, sy = (int)suby * kSubH + srow;
+                const bool inb = have && (sx4 < w) && (sy < h);
+                SpRaw raw_src;
+                SpRawData<NC> raw_dat;
+                sp_issue_src<TF>(s, n, sx4, sy, inb, (uint32_t)(sy * w + sx4), hw, raw_src);
+                if (inb) sp_issue_data<NC, MCH, TF>(s, n, sx4, sy, hw, raw_dat);
+                SpSrc q;
+                f4 dat[NC];
+                uint32_t mc4 = 0x01010101u;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dat[c] = (f4){0.f, 0.f, 0.f, 0.f};
+                sp_src_done(s, sx4, sy, inb, raw_src, q);
+                if (inb) sp_data_done<NC>(s, raw_dat, dat, mc4);
+                process(q, sx4, sy, dat, mc4, r0, r1);
+            }
+        }
+    };
+    using std::integral_constant;
+    // bands of destination rows: 1 when every record fits the LDS; decided from the number of records the whole tile wants
+    int nb = 1;
+    bool over = false;
+    for (int attempt = 0; attempt < 2 && !over; ++attempt) {
+        const int rows = kSpTH / nb;
+        bool redo = false;
+        for (int band = 0; band < nb; ++band) {
+            const int r0 = band * rows, r1 = r0 + rows;
+#pragma unroll
+            for (int i = 0; i < kCellRounds; ++i)
+                if (tid + i * kSpNT2 < kCellsP) cellw[tid + i * kSpNT2] = kSp2Empty;
+            if (tid == 0) { qcount = 0; lqn = 0; bqn = 0; }
+            __syncthreads();
+            scan(r0, r1);
+            __syncthreads();                                   // records, cells and the count are in place
+            const int nrec = qcount;
+            if (nrec > kQ) {                                   // block-uniform
+                if (nb == 1) {                                 // a band of r rows sees about (r + 1) / 16 of the records
+                    nb = 2;
+                    if (nrec * (kSpTH / 2 + 1) > (kQ - kQ / 8) * kSpTH) nb = 4;
+                    if (nrec * (kSpTH / 4 + 1) > (kQ - kQ / 8) * kSpTH) over = true;   // a fold: straight to the float atomics
+                    redo = !over;
+                } else {
+                    over = true;
+                }
+                break;
+            }
+            // ---- S: cells with more than two records in raster order of their source pixels (ascending key) -- the order in which
+            // the reference's scatter_add_ adds them within a corner class (one or two need nothing: a + b = b + a, sums start from +0).
+            // Three or four: the chain is re-linked in raster order.  Five to kNet: ordered by a network in one lane's registers and
+            // summed per corner class there and then; the class sums overwrite part A of the first 1 + NCH records.  More: a wave.
+            bool toolong = false;
+            const int nlong = lqn;                             // (queued by the scan; the barrier after it covers the queue)
+            for (int qi = tid; qi < nlong; qi += kSpNT2) {
+                const int c = lq[qi];
+                const uint32_t cw = cellw[c];
+                const uint32_t cn = cw >> 16;
+                if (cn > (uint32_t)kSpLong) { toolong = true; continue; }   // the limit is on the LENGTH: the same in every run
+                if (cn > (uint32_t)kNet) { bq[atomicAdd(&bqn, 1)] = (uint16_t)c; continue; }   // a wave's job (below)
+                if (cn <= 4u) {
+                    uint32_t e[4], key[4];
+                    e[0] = cw & 0xffffu; e[1] = link[e[0]]; e[2] = link[e[1]]; e[3] = cn == 4u ? (uint32_t)link[e[2]] : kEnd;
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) key[j4] = e[j4] != kEnd ? sp2_key<NC>(recA, recB, e[j4]) : 0xffffffffu;
+#define OFL_CSWAP(a_, b_) { const bool sw = key[a_] > key[b_]; const uint32_t tk = sw ? key[b_] : key[a_], te = sw ? e[b_] : e[a_]; \
+                            key[b_] = sw ? key[a_] : key[b_]; e[b_] = sw ? e[a_] : e[b_]; key[a_] = tk; e[a_] = te; }
+                    OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
+#undef OFL_CSWAP
+                    link[e[0]] = (uint16_t)e[1]; link[e[1]] = (uint16_t)e[2]; link[e[2]] = (uint16_t)e[3];   // (kEnd sorts last: e[3] for three records)
+                    if (e[3] != kEnd) link[e[3]] = (uint16_t)kEnd;
+                    cellw[c] = (cn << 16) | e[0];
+                } else {
+                    constexpr int M = kNet;
+                    static_assert(M == 8 || M == 6, "sorting network size");
+                    uint32_t ix[M], ky[M];
+                    uint32_t cur = cw & 0xffffu;
+#pragma unroll
+                    for (int j4 = 0; j4 < M; ++j4) {
+                        const bool on = (uint32_t)j4 < cn;
+                        ix[j4] = on ? cur : kEnd;
+                        if (on) cur = link[cur];
+                    }
+#pragma unroll
+                    for (int j4 = 0; j4 < M; ++j4) ky[j4] = ix[j4] != kEnd ? sp2_key<NC>(recA, recB, ix[j4]) : 0xffffffffu;
+#define OFL_CSWAP8(a_, b_) { const bool sw = ky[a_] > ky[b_]; const uint32_t tk = sw ? ky[b_] : ky[a_], te = sw ? ix[b_] : ix[a_]; \
+                             ky[b_] = sw ? ky[a_] : ky[b_]; ix[b_] = sw ? ix[a_] : ix[b_]; ky[a_] = tk; ix[a_] = te; }
+                    if (M == 8) {
+                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5) OFL_CSWAP8(M - 2, M - 1)
+                        OFL_CSWAP8(0, 2) OFL_CSWAP8(1, 3) OFL_CSWAP8(4, M - 2) OFL_CSWAP8(5, M - 1)
+                        OFL_CSWAP8(1, 2) OFL_CSWAP8(5, M - 2) OFL_CSWAP8(0, 4) OFL_CSWAP8(3, M - 1)
+                        OFL_CSWAP8(1, 5) OFL_CSWAP8(2, M - 2)
+                        OFL_CSWAP8(1, 4) OFL_CSWAP8(3, M - 2)
+                        OFL_CSWAP8(2, 4) OFL_CSWAP8(3, 5)
+                        OFL_CSWAP8(3, 4)
+                    } else {
+                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
+                        OFL_CSWAP8(0, 2) OFL_CSWAP8(3, 5) OFL_CSWAP8(1, 4)
+                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
+                        OFL_CSWAP8(1, 2) OFL_CSWAP8(3, 4)
+                        OFL_CSWAP8(2, 3)
+                    }
+#undef OFL_CSWAP8
+                    // the class sums, in raster order: weight (a product, rounded), product with the data rounded, then added (as sp2_use)
+                    f4 sum[1 + NCH];
+#pragma unroll
+                    for (int ch = 0; ch < 1 + NCH; ++ch) sum[ch] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < M; ++r) {
+                        if (r < 5 || (uint32_t)r < cn) {       // (unused slots carry the largest key: they sort last; five records at least are real)
+                            const f4 av = recA[ix[r]];
+                            float d[NCH > 0 ? NCH : 1];
+                            sp2_data<NC, NCH>(av, recB, ix[r], d);
+                            const float wy0 = 1.0f - av[1], wx0 = 1.0f - av[0];
+                            const f4 wv = {wy0 * wx0, wy0 * av[0], av[1] * wx0, av[1] * av[0]};
+                            sum[0] += wv;
+#pragma unroll
+                            for (int ch = 0; ch < NCH; ++ch) sum[1 + ch] += wv * d[ch];
+                        }
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 1 + NCH; ++ch) {
+                        recA[ix[ch]] = sum[ch];
+                        link[ix[ch]] = (uint16_t)(ch < NCH ? ix[ch < NCH ? ch + 1 : 0] : kEnd);
+                    }
+                    cellw[c] = (kSp2Sum << 16) | ix[0];
+                }
+            }
+            if (nlong != 0) {                                  // (block-uniform: a tile without such cells needs no barrier here)
+                over = __syncthreads_or((int)toolong) != 0;
+                const int nbig = bqn;
+                if (!over && nbig != 0) {
+                    for (int b = tid >> 6; b < nbig; b += kSpNT2 / 64) sp2_order_big_cell<NC, NCH>(recA, recB, link, cellw, bq[b], lane);
+                    __syncthreads();
+                }
+            }
+            if (over) break;
+            // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.  The pair reads 3 x 2
+            // cells; every record of a cell is fetched once and added to each corner-class sum it belongs to (sp2_use).
+            const bool mine = t.inimg && ly >= r0 && ly < r1;
+            float tot[2][1 + NCH];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
+            if (mine) {
+                float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
+                auto clear = [&]() {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+                            for (int c = 0; c < 1 + NCH; ++c) a[k][kx][c] = 0.0f;
+                };
+                const int cm = max(lx2 + 1, 0);                            // cell column of pixel 1's x-corner 1 = of pixel 0's x-corner 0
+                auto cell = [&](auto dc_, auto ky_) {
+                    constexpr int DC = decltype(dc_)::value, KY = decltype(ky_)::value;
+                    const int c = (ly + 1 - KY) * kCW + max(cm + DC, 0);   // (solo: pixel 0's own cells do not exist; it is never stored)
+                    const uint32_t cw = cellw[c];
+                    uint32_t cur = cw & 0xffffu;
+                    if (cur == kEnd) return;
+                    if ((cw >> 16) != kSp2Sum) {
+#pragma unroll 1
+                        do { sp2_use<NC, NCH, DC, KY>(recA, recB, cur, a); cur = link[cur]; } while (cur != kEnd);
+                    } else {                                               // phase S left the cell's class sums
+                        sp2_use_presum<NCH, DC, KY>(recA, link, cur, a);
+                    }
+                };
+                clear();                                                   // corner row 0: classes 0, 1
+                cell(integral_constant<int, -1>{}, integral_constant<int, 0>{});
+                cell(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+                cell(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = a[k][0][c] + a[k][1][c];
+                clear();                                                   // corner row 1: classes 2, 3
+                cell(integral_constant<int, -1>{}, integral_constant<int, 1>{});
+                cell(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+                cell(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
+            }
+            OFL_OPAQUE_S(pp);
+            sp_finalize<NC, MCH, TF, TO>(s, t, tot, mine, dflags);
+            if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
+        }
+        if (!redo) break;
+        dflags = 0;                                           // (nothing was finalized before the first band overflowed)
+        __syncthreads();
+    }
+    if (over) {
+        // a fold (more records than four bands hold, or > 64 sources in one cell): redone at once by this block with LDS float
+        // atomics (the records are dead: their LDS is the accumulator); whatever the first bands stored is overwritten
+        if (tid == 0) atomicAdd(&p.stats[1], 1);
+        OFL_OPAQUE_S(pp);
+        sp_tile_atomics<NC, MCH, TF, TO>(p, s, reinterpret_cast<float*>(raw), lst, nlist, t, n);
+        return;
+    }
+    if (NC == 2 && s.dst_flags) {                             // (every thread of the block gets here)
+        dflags = wave_or_flags(dflags);
+        block_flag_or(&s.dst_flags[n], dflags);              // one access per block on the image's word (see block_flag_or)
+    }
+#undef s
+#undef p
+}
+
+// ------------------------------------------------------------------------------------------------
 // flow flags (ofl_flow_flags_f32)
 // ------------------------------------------------------------------------------------------------
 // NT: non-temporal loads -- a batch larger than the last-level cache streams 13 % faster past it (B=64 1080p: 5.8 -> 6.65
@@ -3534,7 +3988,35 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
     return (unsigned)(p.per_xcd * kXcds);
 }
 
-#ifdef OFL_WIDE_TU
+#if defined(OFL_SPLAT_TU)
+}  // namespace
+
+// This translation unit (ofl_splat_gather.hip) provides the gather splat's diet kernel (splat_gather2_kernel) and nothing else.
+template <int NC, bool MCH, typename TF, typename TO>
+static int splat_launch_diet(const GatherParams& gp, unsigned grid, hipStream_t st) {
+    if (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp.s)) hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    else hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    return (int)hipGetLastError();
+}
+int ofl_splat_launch_gather_diet(const void* params, int nc, int mch, int elem, unsigned grid, void* stream) {
+    const GatherParams& gp = *static_cast<const GatherParams*>(params);
+    hipStream_t st = (hipStream_t)stream;
+    if (elem != 0) {
+        if (nc != 2) return OFL_E_UNSUPPORTED;
+        if (mch) return elem == 2 ? splat_launch_diet<2, true, _Float16, _Float16>(gp, grid, st) : splat_launch_diet<2, true, _Float16, float>(gp, grid, st);
+        return elem == 2 ? splat_launch_diet<2, false, _Float16, _Float16>(gp, grid, st) : splat_launch_diet<2, false, _Float16, float>(gp, grid, st);
+    }
+    switch (nc * 2 + (mch ? 1 : 0)) {
+        case 2: return splat_launch_diet<1, false, float, float>(gp, grid, st);
+        case 3: return splat_launch_diet<1, true, float, float>(gp, grid, st);
+        case 4: return splat_launch_diet<2, false, float, float>(gp, grid, st);
+        case 5: return splat_launch_diet<2, true, float, float>(gp, grid, st);
+        case 6: return splat_launch_diet<3, false, float, float>(gp, grid, st);
+        case 7: return splat_launch_diet<3, true, float, float>(gp, grid, st);
+    }
+    return OFL_E_UNSUPPORTED;
+}
+#elif defined(OFL_WIDE_TU)
 }  // namespace
 
 // This translation unit (ofl_warp_wide.hip) provides ONE thing: the column kernel of a large plain warp on 64 x 16 tiles.
@@ -3714,6 +4196,7 @@ int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream) 
 int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generic direct-gather kernel only, 2 (= auto), 3 / 4 staged with two tiles / one tile per block whatever the launch size (tests), 5 = auto but more than 3 channels as separate launches of 3 (tests: the channel-loop kernel against them), 6 = auto but the sheared rectangle instead of per-row extents (tests, A/B), 7 = auto but plain lean launches on four-tile row-table columns whatever the size (tests)
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
+int g_splat_path = 0;   // ofl_set_option(OFL_OPT_SPLAT_PATH, .): 0 = the diet gather kernel (round 6: 16-24-byte records, one-word cells, 3 blocks per CU), 1 = round 5's gather kernel (tests compare the two bit for bit; A/B)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
 
 template <int NC>
@@ -3908,13 +4391,11 @@ inline unsigned fallback_resident_blocks(const void* kernel, int which) {
     return (unsigned)v;
 }
 
-// the promises of SplatParamsLean hold for this call (the lean instantiations exist for 2 and 3 channels)
-inline bool splat_is_lean(const SplatParams& s) {
-    return OFL_SP_LEAN && s.flow != nullptr && s.fw == 0 && (s.w & 3) == 0 && s.round_mode == OFL_ROUND_NONE;
-}
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
-    if (NC >= 2 && splat_is_lean(gp.s)) hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    // round 6: the diet kernel (3 blocks per CU) unless the tests / an A-B ask for round 5's (32-byte records, 2 blocks per CU)
+    if (g_splat_path != 1) return ofl_splat_launch_gather_diet(&gp, NC, MCH ? 1 : 0, std::is_same<TF, float>::value ? 0 : (std::is_same<TO, float>::value ? 1 : 2), grid, (void*)st);
+    if (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp.s)) hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
     else hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
     return (int)hipGetLastError();
 }
@@ -3980,6 +4461,7 @@ __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t v
     if (key == OFL_OPT_WARP_SHEAR && (value == 0 || value == 1)) { g_warp_shear = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }
+    if (key == OFL_OPT_SPLAT_PATH && (value == 0 || value == 1)) { g_splat_path = value; return OFL_OK; }
     return OFL_E_ARG;
 }
 
