@@ -81,6 +81,9 @@ int ofl_version(void);
  *   one-word cells: three 512-thread blocks per CU), 1 = round 5's (32-byte records, two blocks per CU).  Same sums in the same
  *   order: bit-identical results (the tests compare them); speed only. */
 #define OFL_OPT_SPLAT_PATH 6
+/*   OFL_OPT_SPLAT_EXTRA_LDS: bytes of dynamic LDS added to the round-6 gather kernel's launches (0 = none) -- a measuring aid: it
+ *   lowers the blocks a CU holds (28 672: two, 65 536: one) without changing a single instruction (tools/splat_occupancy.py). */
+#define OFL_OPT_SPLAT_EXTRA_LDS 7
 int ofl_set_option(int32_t key, int32_t value);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,
@@ -247,6 +250,12 @@ int64_t ofl_splat_tiled_fallback_images(int32_t n, int32_t planes, int32_t h, in
  * to provoke / predict the fallbacks has to know): destination tile width and height in pixels, and the number of 16 x 2 source
  * subtiles one destination tile can list before its IMAGE takes the two-pass path.  Any pointer may be NULL; returns OFL_OK. */
 int ofl_splat_tile_geometry(int32_t* tile_w, int32_t* tile_h, int32_t* list_capacity);
+/* resources of the gather kernel the given kind of call runs on (round 6: the evidence behind "three blocks per CU"), as the HIP
+ * runtime reports them for the loaded code object: info4[0] = 512-thread blocks resident per CU (with `extra_lds` bytes of dynamic
+ * LDS added, see OFL_OPT_SPLAT_EXTRA_LDS), [1] = static LDS bytes per block, [2] = VGPRs, [3] = scratch bytes per thread.
+ * channels 1..3; elem 0 = fp32, 1 = fp16 in / fp32 out, 2 = fp16 in and out (2 channels); lean: the common-case instantiation
+ * (a flow, no window, W % 4 == 0, no rounding; 2 and 3 channels).  Needs a HIP device. */
+int ofl_splat_gather_info(int32_t channels, int32_t with_mask_chan, int32_t elem, int32_t lean, int32_t extra_lds, int32_t* info4);
 int ofl_splat_tiled_f32(const float* flow, int64_t flow_bs, float flow_sign,
                         const float* xs, const float* ys, int64_t xy_bs,
                         const float* data, int64_t data_bs, float data_sign,

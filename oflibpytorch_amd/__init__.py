@@ -5,7 +5,7 @@ Drop-in for the warp / compose hot path of oflibpytorch (`Flow.apply`, `Flow.com
 `grid_from_unstructured_data`): the reference's Python surface (reference `__init__.py:14-18`) over
 hand-written HIP kernels.  No CPU fallback: see `_native.NativeUnavailable`.
 """
-from .flow_class import Flow
+from .flow_class import Flow, set_revalidate_every_call, get_revalidate_every_call
 from .flow_operations import (combine_flows, switch_flow_ref, invert_flow, valid_target, valid_source, batch_flows,
                               get_flow_padding)
 from .utils import (from_matrix, from_transforms, resize_flow, apply_flow, is_zero_flow, get_pure_pytorch,

@@ -18,7 +18,7 @@ import torch
 from . import _build
 
 FLAG_NONFINITE, FLAG_NZ, FLAG_NZ_THR, FLAG_NZ_MASKED, FLAG_NZ_THR_MASKED = 1, 2, 4, 8, 16
-ABI_VERSION = 32              # ofl_version() of the library this file's argtypes describe
+ABI_VERSION = 33              # ofl_version() of the library this file's argtypes describe
 ROUND_NONE, ROUND_RINT, ROUND_U8 = 0, 1, 2
 THRESHOLD = 1e-3
 
@@ -26,7 +26,7 @@ _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
             "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
-            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32", "ofl_resize_bilinear_f32", "ofl_splat_tile_geometry")
+            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32", "ofl_resize_bilinear_f32", "ofl_splat_tile_geometry", "ofl_splat_gather_info")
 _lib = None
 
 
@@ -78,6 +78,7 @@ def load_library(path: str = None):
     lib.ofl_splat_tiled_pass_images.argtypes = [i32, i32, i32]
     lib.ofl_splat_tiled_fallback_images.argtypes = [i32, i32, i32, i32]
     lib.ofl_splat_tile_geometry.argtypes = [p, p, p]
+    lib.ofl_splat_gather_info.argtypes = [i32, i32, i32, i32, i32, p]
     lib.ofl_splat_tiled_f32.argtypes = [p, i64, f32, p, p, i64, p, i64, f32, p, i64, p, i64, p, i64, p, i64, i32, i32, p, p, p, p, p,
                                         p, p, i64, p, i32, i32, i32, i32, i32, p]
     lib.ofl_warp_bwd_grad_f32.argtypes = [p, i64, f32, p, i64, p, f32, p, i64, p, i32, i32, i32, i32, p]
@@ -577,6 +578,20 @@ def set_splat_gather_kernel(which: int):
     """Gather splat: 0 = the round-6 kernel (compact records, three blocks per CU; default), 1 = round 5's kernel.  The same sums
     in the same order -- bit-identical results; tests compare the two, tools time them against each other."""
     _check(load_library().ofl_set_option(6, int(which)), "ofl_set_option")
+
+
+def set_splat_extra_lds(nbytes: int):
+    """Measuring aid: bytes of dynamic LDS added to every launch of the round-6 gather kernel (0 = none): fewer blocks per CU, not
+    one instruction changed (28 672: two blocks, 65 536: one)."""
+    _check(load_library().ofl_set_option(7, int(nbytes)), "ofl_set_option")
+
+
+def splat_gather_info(channels: int, with_mask_chan: bool = True, elem: int = 0, lean: bool = True, extra_lds: int = 0) -> dict:
+    """Resources of the gather kernel as the HIP runtime reports them: blocks per CU, static LDS bytes, VGPRs, scratch bytes."""
+    info = (ctypes.c_int32 * 4)()
+    _check(load_library().ofl_splat_gather_info(int(channels), 1 if with_mask_chan else 0, int(elem), 1 if lean else 0, int(extra_lds), info),
+           "ofl_splat_gather_info")
+    return {"blocks_per_cu": info[0], "waves_per_cu": info[0] * 8, "lds_bytes": info[1], "vgprs": info[2], "scratch_bytes": info[3]}
 
 
 def set_splat_fallback_slots(k: int):

@@ -26,7 +26,7 @@ int ofl_wide_launch_rows_grad(const void* params, int nc, int tiles, void* strea
 int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* stream);         // uint8 images (bytes in; bytes or fp32 out) on the row-table kernel
 int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream);      // the channel-loop kernel (C >= 4) on 64 x 16 tiles; rows: per-row extents where they apply
 // the gather splat's diet kernel (ofl_splat_gather.hip: this file compiled with OFL_SPLAT_TU); `params` = a GatherParams; elem: 0 fp32, 1 fp16 in / fp32 out, 2 fp16 in and out
-int ofl_splat_launch_gather_diet(const void* params, int nc, int mch, int elem, unsigned grid, void* stream);
+int ofl_splat_launch_gather_diet(const void* params, int nc, int mch, int elem, unsigned grid, void* stream, int extra_lds);   // extra_lds: bytes of dynamic LDS added to the launch (OFL_OPT_SPLAT_EXTRA_LDS: occupancy experiments)
 
 namespace {
 
@@ -2246,6 +2246,8 @@ struct GatherParams {
     int32_t regs_x, regs_y;                                  // bin kernel: 64 x 16 source regions (4 waves x 4 subtiles)
     uint32_t regs_img, rx_m, rx_s, ri_m, ri_s;
     int64_t rtotal, rper_xcd;
+    int32_t* redo_cnt;     // [1] tiles of this pass the one-scan gather kernel left to the second launch (bands / fold)
+    uint32_t* redo_list;   // [4 * n * tiles][2] (tile, first row | end row << 8): the BANDS of rows they were split into
 };
 
 // XCD-aware 32-bit decode of (column, row, image) from the block index
@@ -2866,7 +2868,7 @@ __device__ __forceinline__ void sp_data_done(const SP& s, SpRawData<NC>& r, f4 (
 
 template <int NC, bool MCH, typename TF, typename TO, typename GP, typename SP>
 __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float* acc, const uint32_t* __restrict__ lst, int nlist,
-                                                const SpTile& t, int n);
+                                                const SpTile& t, int n, int r0 = 0, int r1 = kSpTH);
 
 // The gather kernel reads its ~400 bytes of parameters from the KERNARG SEGMENT through a pointer that is made opaque at
 // every phase boundary (OFL_OPAQUE_S): the compiler then fetches what a phase needs with scalar loads where it needs it.
@@ -3292,10 +3294,11 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB) void splat_gather_kernel(const
 // A tile the gather kernel cannot sum in order (a heavy fold of the flow): LDS float atomics over the tile's list (plane 0
 // density, then the data channels; the mask channel accumulates the INVALID weight, so that an all-valid pixel is exactly 1
 // in any order).  Tolerance instead of bit-exactness for these tiles; masks stay exact.  `acc` = (1 + NCH) * 512 floats of
-// LDS no thread of the block still reads; every thread of the block calls this.
+// LDS no thread of the block still reads; every thread of the block calls this.  [r0, r1): the rows of the tile that are summed and
+// stored (round 6: the second launch folds a BAND of a tile, not the whole tile).
 template <int NC, bool MCH, typename TF, typename TO, typename GP, typename SP>
 __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float* acc, const uint32_t* __restrict__ lst, int nlist,
-                                                const SpTile& t, int n) {
+                                                const SpTile& t, int n, int r0, int r1) {
     constexpr int kPx = kSpTW * kSpTH, NCH = NC + (MCH ? 1 : 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = s.w, h = s.h;
@@ -3331,7 +3334,7 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
                 for (int kx = 0; kx < 2; ++kx) {
                     const float wgt = wy[ky] * wx[kx];
                     const int xl = ix[kx], yl = iy[ky];
-                    if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)yl >= (uint32_t)kSpTH) continue;
+                    if (wgt == 0.0f || (uint32_t)xl >= (uint32_t)kSpTW || (uint32_t)(yl - r0) >= (uint32_t)(r1 - r0)) continue;
                     const int d = yl * kSpTW + xl;
                     atomicAdd(&acc[d], wgt);
 #pragma unroll
@@ -3351,7 +3354,7 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
         for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = acc[c * kPx + d];
         if (MCH) tot[k][1 + NC] = tot[k][0] - tot[k][1 + NC];      // density - invalid weight
     }
-    sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg, dflags);
+    sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg && t.ly >= r0 && t.ly < r1, dflags);
     if (NC == 2 && s.dst_flags) {
         dflags = wave_or_flags(dflags);
         if (lane == 0) flag_or(&s.dst_flags[n], dflags);
@@ -3502,7 +3505,12 @@ __device__ __attribute__((noinline)) void sp2_order_big_cell(f4* recA, uint32_t*
     if (lane == 0) cellw[c] = (kSp2Sum << 16) | (uint32_t)__builtin_amdgcn_readlane((int)sorted, 0);
 }
 
-template <int NC, bool MCH, typename TF = float, typename TO = float, bool LEAN = false>
+// REDO = false: the kernel every tile runs on -- ONE scan, no bands: a tile whose records overflow the LDS, or that holds a cell of
+// more than 64 records, puts its id on the pass's redo list and leaves.  REDO = true: a second, small launch that walks that list
+// with the whole repertoire (2 or 4 bands of rows, the float-atomics fold).  Splitting the two takes every loop away from round
+// the hot path's phases: with the band loops in place the compiler hoisted each per-thread invariant of the later phases (tile
+// geometry, output offsets) to the top of the kernel and, at 80 registers, spilled ten of them there (profiles/r6_splat_diet.txt).
+template <int NC, bool MCH, typename TF = float, typename TO = float, bool LEAN = false, bool REDO = false>
 __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(const GatherParams p_by_value_unused) {
     GatherParamsK* pp = (GatherParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
@@ -3522,24 +3530,38 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
     uint32_t* cellw = reinterpret_cast<uint32_t*>(raw + (18 + L::kB) * kQ);
 #define s (*reinterpret_cast<typename std::conditional<LEAN, SplatParamsLeanK, SplatParamsK>::type*>(&pp->s))   /* (see SplatParamsLean) */
     const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int kHalf = kSpNT2 / kSubLanes, kStep = 2 * kHalf;      // subtiles per half step (kSubLanes lanes each) / per step
+    int redo_n = 0;
+    if (REDO) {
+        redo_n = __builtin_amdgcn_readfirstlane(p.redo_cnt[0]);
+        if (tid == 0 && blockIdx.x == 0 && redo_n != 0) atomicAdd(&p.stats[3], redo_n);     // statistics: tiles that took the second launch
+    }
+    int ri = (int)blockIdx.x;
+    if (REDO && ri >= redo_n) return;
+    do {                                                              // (REDO: the tiles of the list, gridDim.x apart; else once)
+    int tx, ty, n, ua = 0, ub = kSpTH;
+    uint32_t tile;
+    if (REDO) {
+        const uint2 unit = reinterpret_cast<const uint2*>(p.redo_list)[ri];
+        // (readfirstlane: these come from a flat load, which the compiler takes for divergent -- and a loop it takes for divergent
+        // may not contain the "+s" pins of the kernarg pointer: "illegal VGPR to SGPR copy")
+        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit.x);
+        ua = __builtin_amdgcn_readfirstlane((int)(unit.y & 0xffu)); ub = __builtin_amdgcn_readfirstlane((int)((unit.y >> 8) & 0xffu));
+        const uint32_t nn = fastdiv(tile, p.mi_m, p.mi_s), rem = tile - nn * p.tiles_img, yy = fastdiv(rem, p.mx_m, p.mx_s);
+        n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (uint32_t)p.tiles_x);
+    } else {
+        if (!decode3(p.total, p.per_xcd, p.tiles_img, p.mi_m, p.mi_s, p.mx_m, p.mx_s, p.tiles_x, tx, ty, n)) return;
+        if (p.img_over[n] != 0) return;                               // this image takes the global-atomics path instead
+        tile = (uint32_t)(n * (int)p.tiles_img + ty * p.tiles_x + tx);
+    }
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
-    constexpr int kHalf = kSpNT2 / kSubLanes, kStep = 2 * kHalf;      // subtiles per half step (kSubLanes lanes each) / per step
-    int tx, ty, n;
-    if (!decode3(p.total, p.per_xcd, p.tiles_img, p.mi_m, p.mi_s, p.mx_m, p.mx_s, p.tiles_x, tx, ty, n)) return;
-    if (p.img_over[n] != 0) return;                                   // this image takes the global-atomics path instead
-    const uint32_t tile = (uint32_t)(n * (int)p.tiles_img + ty * p.tiles_x + tx);
     const uint32_t* __restrict__ lst = p.list + (int64_t)tile * kBinCap;
     // the first entries of the list are fetched WITH its length (fixed address, kBinCap slots: entries past the length are stale
     // ids that are never used)
     const uint32_t pre[2] = {lst[tid / kSubLanes], lst[kHalf + tid / kSubLanes]};
     const int nlist = min(p.cnt[tile], kBinCap);
-    OFL_OPAQUE_S(pp);
-    SpTile t;
-    sp_tile_setup<TF>(s, tx, ty, n, t);
-    const int dx0 = t.dx0, dy0 = t.dy0, ly = t.ly, lx2 = t.lx2;
-    int dflags = 0;
-    const int sl = tid & (kSubLanes - 1), srow = sl >> 2, sc4 = sl & 3;
+    const int dx0 = tx * kSpTW, dy0 = ty * kSpTH;
     // one half step: the hit test of a lane's 4 source pixels, ranks by ballot + popcount, records and cells in LDS
     auto process = [&](const SpSrc& q, int sx4, int sy, const f4 (&dat)[NC], uint32_t mc4, int r0, int r1) {
         int cell[4];
@@ -3549,7 +3571,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
         for (int k = 0; k < 4; ++k) {
             const int cx = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, (float)w) - dx0 + 1;
             const int cy = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, (float)h) - dy0 + 1;
-            const bool hit = ((q.on >> k) & 1u) != 0u && (uint32_t)cx < (uint32_t)kCW && cy >= r0 && cy <= r1;
+            const bool hit = ((q.on >> k) & 1u) != 0u && (uint32_t)cx < (uint32_t)kCW && (REDO ? (cy >= r0 && cy <= r1) : ((uint32_t)cy < (uint32_t)L::kCH));
             cell[k] = hit ? cy * kCW + cx : -1;
             m[k] = __ballot(hit);
             wtot += __popcll(m[k]);
@@ -3588,7 +3610,8 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
         }
     };
     // ---- A: walk the tile's list (see splat_gather_kernel): per half step EVERY load first, then the end points
-    auto scan = [&](int r0, int r1) {
+    auto scan = [&](int r0, int r1, bool first) {
+        const int sl = tid & (kSubLanes - 1), srow = sl >> 2, sc4 = sl & 3;
         OFL_OPAQUE_S(pp);
         for (int base = 0; base < nlist; base += kStep) {
             const bool two = base + kHalf < nlist;             // block-uniform: the second half step has entries
@@ -3597,7 +3620,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
                 if (u == 1 && !two) continue;
                 const int e = base + u * kHalf + tid / kSubLanes;
                 const bool have = e < nlist;
-                const uint32_t sub = base == 0 ? pre[u] : (have ? lst[e] : 0u);
+                const uint32_t sub = (base == 0 && first) ? pre[u] : (have ? lst[e] : 0u);
                 const uint32_t suby = fastdiv(sub, p.sx_m, p.sx_s), subx = sub - suby * (uint32_t)p.subs_x;
                 const int sx4 = (int)subx * kSubW + sc4 * 4, sy = (int)suby * kSubH + srow;
                 const bool inb = have && (sx4 < w) && (sy < h);
@@ -3616,192 +3639,248 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
             }
         }
     };
-    using std::integral_constant;
-    // bands of destination rows: 1 when every record fits the LDS; decided from the number of records the whole tile wants
-    int nb = 1;
-    bool over = false;
-    for (int attempt = 0; attempt < 2 && !over; ++attempt) {
-        const int rows = kSpTH / nb;
-        bool redo = false;
-        for (int band = 0; band < nb; ++band) {
-            const int r0 = band * rows, r1 = r0 + rows;
+    // ---- S: cells with more than two records in raster order of their source pixels (ascending key) -- the order in which the
+    // reference's scatter_add_ adds them within a corner class (one or two need nothing: a + b = b + a, sums start from +0).
+    // Three or four: the chain is re-linked in raster order.  Five to kNet: ordered by a network in one lane's registers and summed
+    // per corner class there and then; the class sums overwrite part A of the first 1 + NCH records.  More: a wave.  Returns true
+    // when a cell holds more than kSpLong records (block-uniform).
+    auto order = [&]() -> bool {
+        bool toolong = false;
+        const int nlong = __builtin_amdgcn_readfirstlane(lqn);   // (queued by the scan; the barrier after it covers the queue.  readfirstlane: block-uniform values read from LDS must be uniform to the compiler too)
+        if (nlong == 0) return false;                      // (block-uniform: a tile without such cells needs no barrier here)
+        for (int qi = tid; qi < nlong; qi += kSpNT2) {
+            const int c = lq[qi];
+            const uint32_t cw = cellw[c];
+            const uint32_t cn = cw >> 16;
+            if (cn > (uint32_t)kSpLong) { toolong = true; continue; }   // the limit is on the LENGTH: the same in every run
+            if (cn > (uint32_t)kNet) { bq[atomicAdd(&bqn, 1)] = (uint16_t)c; continue; }   // a wave's job (below)
+            if (cn <= 4u) {
+                uint32_t e[4], key[4];
+                e[0] = cw & 0xffffu; e[1] = link[e[0]]; e[2] = link[e[1]]; e[3] = cn == 4u ? (uint32_t)link[e[2]] : kEnd;
 #pragma unroll
-            for (int i = 0; i < kCellRounds; ++i)
-                if (tid + i * kSpNT2 < kCellsP) cellw[tid + i * kSpNT2] = kSp2Empty;
-            if (tid == 0) { qcount = 0; lqn = 0; bqn = 0; }
-            __syncthreads();
-            scan(r0, r1);
-            __syncthreads();                                   // records, cells and the count are in place
-            const int nrec = qcount;
-            if (nrec > kQ) {                                   // block-uniform
-                if (nb == 1) {                                 // a band of r rows sees about (r + 1) / 16 of the records
-                    nb = 2;
-                    if (nrec * (kSpTH / 2 + 1) > (kQ - kQ / 8) * kSpTH) nb = 4;
-                    if (nrec * (kSpTH / 4 + 1) > (kQ - kQ / 8) * kSpTH) over = true;   // a fold: straight to the float atomics
-                    redo = !over;
-                } else {
-                    over = true;
-                }
-                break;
-            }
-            // ---- S: cells with more than two records in raster order of their source pixels (ascending key) -- the order in which
-            // the reference's scatter_add_ adds them within a corner class (one or two need nothing: a + b = b + a, sums start from +0).
-            // Three or four: the chain is re-linked in raster order.  Five to kNet: ordered by a network in one lane's registers and
-            // summed per corner class there and then; the class sums overwrite part A of the first 1 + NCH records.  More: a wave.
-            bool toolong = false;
-            const int nlong = lqn;                             // (queued by the scan; the barrier after it covers the queue)
-            for (int qi = tid; qi < nlong; qi += kSpNT2) {
-                const int c = lq[qi];
-                const uint32_t cw = cellw[c];
-                const uint32_t cn = cw >> 16;
-                if (cn > (uint32_t)kSpLong) { toolong = true; continue; }   // the limit is on the LENGTH: the same in every run
-                if (cn > (uint32_t)kNet) { bq[atomicAdd(&bqn, 1)] = (uint16_t)c; continue; }   // a wave's job (below)
-                if (cn <= 4u) {
-                    uint32_t e[4], key[4];
-                    e[0] = cw & 0xffffu; e[1] = link[e[0]]; e[2] = link[e[1]]; e[3] = cn == 4u ? (uint32_t)link[e[2]] : kEnd;
-#pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4) key[j4] = e[j4] != kEnd ? sp2_key<NC>(recA, recB, e[j4]) : 0xffffffffu;
+                for (int j4 = 0; j4 < 4; ++j4) key[j4] = e[j4] != kEnd ? sp2_key<NC>(recA, recB, e[j4]) : 0xffffffffu;
 #define OFL_CSWAP(a_, b_) { const bool sw = key[a_] > key[b_]; const uint32_t tk = sw ? key[b_] : key[a_], te = sw ? e[b_] : e[a_]; \
-                            key[b_] = sw ? key[a_] : key[b_]; e[b_] = sw ? e[a_] : e[b_]; key[a_] = tk; e[a_] = te; }
-                    OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
+                        key[b_] = sw ? key[a_] : key[b_]; e[b_] = sw ? e[a_] : e[b_]; key[a_] = tk; e[a_] = te; }
+                OFL_CSWAP(0, 1) OFL_CSWAP(2, 3) OFL_CSWAP(0, 2) OFL_CSWAP(1, 3) OFL_CSWAP(1, 2)
 #undef OFL_CSWAP
-                    link[e[0]] = (uint16_t)e[1]; link[e[1]] = (uint16_t)e[2]; link[e[2]] = (uint16_t)e[3];   // (kEnd sorts last: e[3] for three records)
-                    if (e[3] != kEnd) link[e[3]] = (uint16_t)kEnd;
-                    cellw[c] = (cn << 16) | e[0];
-                } else {
-                    constexpr int M = kNet;
-                    static_assert(M == 8 || M == 6, "sorting network size");
-                    uint32_t ix[M], ky[M];
-                    uint32_t cur = cw & 0xffffu;
+                link[e[0]] = (uint16_t)e[1]; link[e[1]] = (uint16_t)e[2]; link[e[2]] = (uint16_t)e[3];   // (kEnd sorts last: e[3] for three records)
+                if (e[3] != kEnd) link[e[3]] = (uint16_t)kEnd;
+                cellw[c] = (cn << 16) | e[0];
+            } else {
+                constexpr int M = kNet;
+                static_assert(M == 8 || M == 6, "sorting network size");
+                uint32_t ix[M], ky[M];
+                uint32_t cur = cw & 0xffffu;
 #pragma unroll
-                    for (int j4 = 0; j4 < M; ++j4) {
-                        const bool on = (uint32_t)j4 < cn;
-                        ix[j4] = on ? cur : kEnd;
-                        if (on) cur = link[cur];
-                    }
+                for (int j4 = 0; j4 < M; ++j4) {
+                    const bool on = (uint32_t)j4 < cn;
+                    ix[j4] = on ? cur : kEnd;
+                    if (on) cur = link[cur];
+                }
 #pragma unroll
-                    for (int j4 = 0; j4 < M; ++j4) ky[j4] = ix[j4] != kEnd ? sp2_key<NC>(recA, recB, ix[j4]) : 0xffffffffu;
+                for (int j4 = 0; j4 < M; ++j4) ky[j4] = ix[j4] != kEnd ? sp2_key<NC>(recA, recB, ix[j4]) : 0xffffffffu;
 #define OFL_CSWAP8(a_, b_) { const bool sw = ky[a_] > ky[b_]; const uint32_t tk = sw ? ky[b_] : ky[a_], te = sw ? ix[b_] : ix[a_]; \
-                             ky[b_] = sw ? ky[a_] : ky[b_]; ix[b_] = sw ? ix[a_] : ix[b_]; ky[a_] = tk; ix[a_] = te; }
-                    if (M == 8) {
-                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5) OFL_CSWAP8(M - 2, M - 1)
-                        OFL_CSWAP8(0, 2) OFL_CSWAP8(1, 3) OFL_CSWAP8(4, M - 2) OFL_CSWAP8(5, M - 1)
-                        OFL_CSWAP8(1, 2) OFL_CSWAP8(5, M - 2) OFL_CSWAP8(0, 4) OFL_CSWAP8(3, M - 1)
-                        OFL_CSWAP8(1, 5) OFL_CSWAP8(2, M - 2)
-                        OFL_CSWAP8(1, 4) OFL_CSWAP8(3, M - 2)
-                        OFL_CSWAP8(2, 4) OFL_CSWAP8(3, 5)
-                        OFL_CSWAP8(3, 4)
-                    } else {
-                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
-                        OFL_CSWAP8(0, 2) OFL_CSWAP8(3, 5) OFL_CSWAP8(1, 4)
-                        OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
-                        OFL_CSWAP8(1, 2) OFL_CSWAP8(3, 4)
-                        OFL_CSWAP8(2, 3)
-                    }
+                         ky[b_] = sw ? ky[a_] : ky[b_]; ix[b_] = sw ? ix[a_] : ix[b_]; ky[a_] = tk; ix[a_] = te; }
+                if (M == 8) {
+                    OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5) OFL_CSWAP8(M - 2, M - 1)
+                    OFL_CSWAP8(0, 2) OFL_CSWAP8(1, 3) OFL_CSWAP8(4, M - 2) OFL_CSWAP8(5, M - 1)
+                    OFL_CSWAP8(1, 2) OFL_CSWAP8(5, M - 2) OFL_CSWAP8(0, 4) OFL_CSWAP8(3, M - 1)
+                    OFL_CSWAP8(1, 5) OFL_CSWAP8(2, M - 2)
+                    OFL_CSWAP8(1, 4) OFL_CSWAP8(3, M - 2)
+                    OFL_CSWAP8(2, 4) OFL_CSWAP8(3, 5)
+                    OFL_CSWAP8(3, 4)
+                } else {
+                    OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
+                    OFL_CSWAP8(0, 2) OFL_CSWAP8(3, 5) OFL_CSWAP8(1, 4)
+                    OFL_CSWAP8(0, 1) OFL_CSWAP8(2, 3) OFL_CSWAP8(4, 5)
+                    OFL_CSWAP8(1, 2) OFL_CSWAP8(3, 4)
+                    OFL_CSWAP8(2, 3)
+                }
 #undef OFL_CSWAP8
-                    // the class sums, in raster order: weight (a product, rounded), product with the data rounded, then added (as sp2_use)
-                    f4 sum[1 + NCH];
+                // the class sums, in raster order: weight (a product, rounded), product with the data rounded, then added (as sp2_use)
+                f4 sum[1 + NCH];
 #pragma unroll
-                    for (int ch = 0; ch < 1 + NCH; ++ch) sum[ch] = (f4){0.f, 0.f, 0.f, 0.f};
+                for (int ch = 0; ch < 1 + NCH; ++ch) sum[ch] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < M; ++r) {
-                        if (r < 5 || (uint32_t)r < cn) {       // (unused slots carry the largest key: they sort last; five records at least are real)
-                            const f4 av = recA[ix[r]];
-                            float d[NCH > 0 ? NCH : 1];
-                            sp2_data<NC, NCH>(av, recB, ix[r], d);
-                            const float wy0 = 1.0f - av[1], wx0 = 1.0f - av[0];
-                            const f4 wv = {wy0 * wx0, wy0 * av[0], av[1] * wx0, av[1] * av[0]};
-                            sum[0] += wv;
+                for (int r = 0; r < M; ++r) {
+                    if (r < 5 || (uint32_t)r < cn) {       // (unused slots carry the largest key: they sort last; five records at least are real)
+                        const f4 av = recA[ix[r]];
+                        float d[NCH > 0 ? NCH : 1];
+                        sp2_data<NC, NCH>(av, recB, ix[r], d);
+                        const float wy0 = 1.0f - av[1], wx0 = 1.0f - av[0];
+                        const f4 wv = {wy0 * wx0, wy0 * av[0], av[1] * wx0, av[1] * av[0]};
+                        sum[0] += wv;
 #pragma unroll
-                            for (int ch = 0; ch < NCH; ++ch) sum[1 + ch] += wv * d[ch];
-                        }
+                        for (int ch = 0; ch < NCH; ++ch) sum[1 + ch] += wv * d[ch];
                     }
+                }
 #pragma unroll
-                    for (int ch = 0; ch < 1 + NCH; ++ch) {
-                        recA[ix[ch]] = sum[ch];
-                        link[ix[ch]] = (uint16_t)(ch < NCH ? ix[ch < NCH ? ch + 1 : 0] : kEnd);
-                    }
-                    cellw[c] = (kSp2Sum << 16) | ix[0];
+                for (int ch = 0; ch < 1 + NCH; ++ch) {
+                    recA[ix[ch]] = sum[ch];
+                    link[ix[ch]] = (uint16_t)(ch < NCH ? ix[ch < NCH ? ch + 1 : 0] : kEnd);
                 }
+                cellw[c] = (kSp2Sum << 16) | ix[0];
             }
-            if (nlong != 0) {                                  // (block-uniform: a tile without such cells needs no barrier here)
-                over = __syncthreads_or((int)toolong) != 0;
-                const int nbig = bqn;
-                if (!over && nbig != 0) {
-                    for (int b = tid >> 6; b < nbig; b += kSpNT2 / 64) sp2_order_big_cell<NC, NCH>(recA, recB, link, cellw, bq[b], lane);
-                    __syncthreads();
-                }
-            }
-            if (over) break;
-            // ---- C: the sums of this thread's 2 destination pixels (if their row is in the band), finalize.  The pair reads 3 x 2
-            // cells; every record of a cell is fetched once and added to each corner-class sum it belongs to (sp2_use).
-            const bool mine = t.inimg && ly >= r0 && ly < r1;
-            float tot[2][1 + NCH];
+        }
+        if (__builtin_amdgcn_readfirstlane(__syncthreads_or((int)toolong)) != 0) return true;
+        const int nbig = __builtin_amdgcn_readfirstlane(bqn);
+        if (nbig != 0) {
+            for (int b = tid >> 6; b < nbig; b += kSpNT2 / 64) sp2_order_big_cell<NC, NCH>(recA, recB, link, cellw, bq[b], lane);
+            __syncthreads();
+        }
+        return false;
+    };
+    // ---- C: the sums of this thread's 2 destination pixels.  The pair reads 3 x 2 cells; every record of a cell is fetched once
+    // and added to each corner-class sum it belongs to (sp2_use).
+    using std::integral_constant;
+    auto sums = [&](int ly, int lx2, float (&tot)[2][1 + NCH]) {
+        float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
+        auto clear = [&]() {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
-            if (mine) {
-                float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
-                auto clear = [&]() {
+                for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k)
-#pragma unroll
-                        for (int kx = 0; kx < 2; ++kx)
-#pragma unroll
-                            for (int c = 0; c < 1 + NCH; ++c) a[k][kx][c] = 0.0f;
-                };
-                const int cm = max(lx2 + 1, 0);                            // cell column of pixel 1's x-corner 1 = of pixel 0's x-corner 0
-                auto cell = [&](auto dc_, auto ky_) {
-                    constexpr int DC = decltype(dc_)::value, KY = decltype(ky_)::value;
-                    const int c = (ly + 1 - KY) * kCW + max(cm + DC, 0);   // (solo: pixel 0's own cells do not exist; it is never stored)
-                    const uint32_t cw = cellw[c];
-                    uint32_t cur = cw & 0xffffu;
-                    if (cur == kEnd) return;
-                    if ((cw >> 16) != kSp2Sum) {
+                    for (int c = 0; c < 1 + NCH; ++c) a[k][kx][c] = 0.0f;
+        };
+        const int cm = max(lx2 + 1, 0);                            // cell column of pixel 1's x-corner 1 = of pixel 0's x-corner 0
+        auto cell = [&](auto dc_, auto ky_) {
+            constexpr int DC = decltype(dc_)::value, KY = decltype(ky_)::value;
+            const int c = (ly + 1 - KY) * kCW + max(cm + DC, 0);   // (solo: pixel 0's own cells do not exist; it is never stored)
+            const uint32_t cw = cellw[c];
+            uint32_t cur = cw & 0xffffu;
+            if (cur == kEnd) return;
+            if ((cw >> 16) != kSp2Sum) {
 #pragma unroll 1
-                        do { sp2_use<NC, NCH, DC, KY>(recA, recB, cur, a); cur = link[cur]; } while (cur != kEnd);
-                    } else {                                               // phase S left the cell's class sums
-                        sp2_use_presum<NCH, DC, KY>(recA, link, cur, a);
-                    }
-                };
-                clear();                                                   // corner row 0: classes 0, 1
-                cell(integral_constant<int, -1>{}, integral_constant<int, 0>{});
-                cell(integral_constant<int, 0>{}, integral_constant<int, 0>{});
-                cell(integral_constant<int, 1>{}, integral_constant<int, 0>{});
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = a[k][0][c] + a[k][1][c];
-                clear();                                                   // corner row 1: classes 2, 3
-                cell(integral_constant<int, -1>{}, integral_constant<int, 1>{});
-                cell(integral_constant<int, 0>{}, integral_constant<int, 1>{});
-                cell(integral_constant<int, 1>{}, integral_constant<int, 1>{});
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
+                do { sp2_use<NC, NCH, DC, KY>(recA, recB, cur, a); cur = link[cur]; } while (cur != kEnd);
+            } else {                                               // phase S left the cell's class sums
+                sp2_use_presum<NCH, DC, KY>(recA, link, cur, a);
             }
-            OFL_OPAQUE_S(pp);
-            sp_finalize<NC, MCH, TF, TO>(s, t, tot, mine, dflags);
-            if (nb > 1) __syncthreads();                      // the next band re-uses the LDS
-        }
-        if (!redo) break;
-        dflags = 0;                                           // (nothing was finalized before the first band overflowed)
+        };
+        clear();                                                   // corner row 0: classes 0, 1
+        cell(integral_constant<int, -1>{}, integral_constant<int, 0>{});
+        cell(integral_constant<int, 0>{}, integral_constant<int, 0>{});
+        cell(integral_constant<int, 1>{}, integral_constant<int, 0>{});
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = a[k][0][c] + a[k][1][c];
+        clear();                                                   // corner row 1: classes 2, 3
+        cell(integral_constant<int, -1>{}, integral_constant<int, 1>{});
+        cell(integral_constant<int, 0>{}, integral_constant<int, 1>{});
+        cell(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
+    };
+    auto zero_cells = [&]() {
+#pragma unroll
+        for (int i = 0; i < kCellRounds; ++i)
+            if (tid + i * kSpNT2 < kCellsP) cellw[tid + i * kSpNT2] = kSp2Empty;
+        if (tid == 0) { qcount = 0; lqn = 0; bqn = 0; }
+    };
+    int dflags = 0;
+    if (!REDO) {
+        // ================= the hot path: one scan, order, sum, finalize -- straight-line, nothing kept across the phases that the
+        // phases themselves do not need =================
+        // the un-occlude fill candidates of this thread's pair need the tile's own flow: loaded here, beside the list head (one
+        // round trip for both), kept as two bits
+        SpTile t0;
+        sp_tile_setup<TF>(s, tx, ty, n, t0);
+        uint32_t fillbits = (t0.fill_ok[0] ? 1u : 0u) | (t0.fill_ok[1] ? 2u : 0u);
+        zero_cells();
         __syncthreads();
-    }
-    if (over) {
-        // a fold (more records than four bands hold, or > 64 sources in one cell): redone at once by this block with LDS float
-        // atomics (the records are dead: their LDS is the accumulator); whatever the first bands stored is overwritten
-        if (tid == 0) atomicAdd(&p.stats[1], 1);
+        scan(0, kSpTH, true);
+        __syncthreads();                                   // records, cells and the count are in place
+        // block-uniform: more records than the LDS holds, or a cell of more than kSpLong records -> the second launch, as 2 or 4
+        // independent BANDS of rows (a band of r rows sees about (r + 1) / 17 of the records) that other blocks sum side by side
+        const int nrec = __builtin_amdgcn_readfirstlane(qcount);
+        int nb = 0;
+        if (nrec > kQ) nb = (nrec * (kSpTH / 2 + 1) > (kQ - kQ / 8) * kSpTH) ? 4 : 2;
+        else if (order()) nb = 4;
+        if (nb != 0) {
+            if (tid < nb) {
+                int base = 0;
+                if (tid == 0) base = atomicAdd(&p.redo_cnt[0], nb);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int rows = kSpTH / nb;
+                reinterpret_cast<uint2*>(p.redo_list)[base + tid] = make_uint2(tile, (uint32_t)(tid * rows) | ((uint32_t)(tid * rows + rows) << 8));
+            }
+            return;
+        }
+        asm volatile("" : "+v"(fillbits));
+        SpTile t;                                          // (geometry re-formed here: a few integer operations instead of registers held across the scan)
+        t.n = n; t.dx0 = dx0; t.dy0 = dy0;
+        {
+            const int lx = tid % (kSpTW / 2);
+            t.ly = tid / (kSpTW / 2);
+            const int x2 = min(dx0 + lx * 2, w - 2), y = dy0 + t.ly;
+            t.lx2 = x2 - dx0;
+            t.solo = t.lx2 < 0;
+            t.inimg = (dx0 + lx * 2 < w) && (y < h);
+            t.pix = (uint32_t)(min(y, h - 1) * w + x2);
+            t.wide = dx0 + kSpTW <= w;
+            t.fill_ok[0] = (fillbits & 1u) != 0u; t.fill_ok[1] = (fillbits & 2u) != 0u;
+        }
+        float tot[2][1 + NCH];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
+        if (t.inimg) sums(t.ly, t.lx2, tot);
         OFL_OPAQUE_S(pp);
-        sp_tile_atomics<NC, MCH, TF, TO>(p, s, reinterpret_cast<float*>(raw), lst, nlist, t, n);
-        return;
+        sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg, dflags);
+    } else {
+        // ================= the second launch: one BAND of rows [ua, ub) of a tile per list entry.  A band whose records still do not
+        // fit (or that holds a cell of more than kSpLong records) is halved, down to 4 rows; a 4-row band that does not fit is
+        // summed with LDS float atomics (tolerance instead of bit-exactness for those rows; counted in stats[1]) =================
+        SpTile t;
+        sp_tile_setup<TF>(s, tx, ty, n, t);
+        const int ly = t.ly, lx2 = t.lx2;
+        bool first = true;
+        int a0 = ua, b0 = ub;
+        while (a0 < ub) {                                      // (block-uniform)
+            zero_cells();
+            __syncthreads();
+            scan(a0, b0, first);
+            first = false;
+            __syncthreads();
+            bool fits = __builtin_amdgcn_readfirstlane(qcount) <= kQ;
+            if (fits) fits = !order();
+            if (!fits && b0 - a0 > 4) {                        // halve the band and try again
+                b0 = a0 + (b0 - a0) / 2;
+                __syncthreads();
+                continue;
+            }
+            if (fits) {
+                const bool mine = t.inimg && ly >= a0 && ly < b0;
+                float tot[2][1 + NCH];
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
+                if (mine) sums(ly, lx2, tot);
+                OFL_OPAQUE_S(pp);
+                sp_finalize<NC, MCH, TF, TO>(s, t, tot, mine, dflags);
+            } else {
+                if (tid == 0) atomicAdd(&p.stats[1], 1);
+                OFL_OPAQUE_S(pp);
+                sp_tile_atomics<NC, MCH, TF, TO>(p, s, reinterpret_cast<float*>(raw), lst, nlist, t, n, a0, b0);   // (posts its rows' flag word itself)
+            }
+            __syncthreads();                                   // the next band re-uses the LDS
+            const int span = b0 - a0;
+            a0 = b0; b0 = min(a0 + span, ub);
+        }
     }
     if (NC == 2 && s.dst_flags) {                             // (every thread of the block gets here)
         dflags = wave_or_flags(dflags);
         block_flag_or(&s.dst_flags[n], dflags);              // one access per block on the image's word (see block_flag_or)
     }
+    if (!REDO) break;
+    __syncthreads();                                          // (the next tile of the list re-uses the LDS)
+    ri += (int)gridDim.x;
+    } while (ri < redo_n);
 #undef s
 #undef p
 }
@@ -3992,29 +4071,56 @@ inline unsigned warp_geometry(WarpParams& p, int tile_w, int tile_h) {
 }  // namespace
 
 // This translation unit (ofl_splat_gather.hip) provides the gather splat's diet kernel (splat_gather2_kernel) and nothing else.
+// gp == nullptr: no launch -- the kernel's resources (info[0] blocks of kSpNT2 threads resident per CU, [1] static LDS bytes,
+// [2] VGPRs, [3] scratch bytes per thread) as the runtime reports them
 template <int NC, bool MCH, typename TF, typename TO>
-static int splat_launch_diet(const GatherParams& gp, unsigned grid, hipStream_t st) {
-    if (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp.s)) hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
-    else hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+static int splat_launch_diet(const GatherParams* gp, unsigned grid, hipStream_t st, int extra_lds, int lean, int32_t* info) {
+    const bool ln = gp ? (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp->s)) : (NC >= 2 && lean != 0);
+    const void* fn = ln ? (const void*)splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2)> : (const void*)splat_gather2_kernel<NC, MCH, TF, TO>;
+    constexpr unsigned kRedoGrid = 768;                      // the second launch walks the redo list with this many blocks (3 per CU)
+    if (!gp) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, fn);
+        if (e != hipSuccess) return (int)e;
+        int blocks = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, kSpNT2, (size_t)extra_lds);
+        if (e != hipSuccess) return (int)e;
+        info[0] = blocks; info[1] = (int32_t)fa.sharedSizeBytes; info[2] = fa.numRegs; info[3] = (int32_t)fa.localSizeBytes;
+        return OFL_OK;
+    }
+    if (ln) {
+        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), (size_t)extra_lds, st, *gp);
+        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2), true>), dim3(grid < kRedoGrid ? grid : kRedoGrid), dim3(kSpNT2), 0, st, *gp);
+    } else {
+        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), (size_t)extra_lds, st, *gp);
+        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, false, true>), dim3(grid < kRedoGrid ? grid : kRedoGrid), dim3(kSpNT2), 0, st, *gp);
+    }
     return (int)hipGetLastError();
 }
-int ofl_splat_launch_gather_diet(const void* params, int nc, int mch, int elem, unsigned grid, void* stream) {
-    const GatherParams& gp = *static_cast<const GatherParams*>(params);
-    hipStream_t st = (hipStream_t)stream;
+static int splat_diet_dispatch(const GatherParams* gp, int nc, int mch, int elem, unsigned grid, hipStream_t st, int extra_lds, int lean, int32_t* info) {
     if (elem != 0) {
         if (nc != 2) return OFL_E_UNSUPPORTED;
-        if (mch) return elem == 2 ? splat_launch_diet<2, true, _Float16, _Float16>(gp, grid, st) : splat_launch_diet<2, true, _Float16, float>(gp, grid, st);
-        return elem == 2 ? splat_launch_diet<2, false, _Float16, _Float16>(gp, grid, st) : splat_launch_diet<2, false, _Float16, float>(gp, grid, st);
+        if (mch) return elem == 2 ? splat_launch_diet<2, true, _Float16, _Float16>(gp, grid, st, extra_lds, lean, info) : splat_launch_diet<2, true, _Float16, float>(gp, grid, st, extra_lds, lean, info);
+        return elem == 2 ? splat_launch_diet<2, false, _Float16, _Float16>(gp, grid, st, extra_lds, lean, info) : splat_launch_diet<2, false, _Float16, float>(gp, grid, st, extra_lds, lean, info);
     }
     switch (nc * 2 + (mch ? 1 : 0)) {
-        case 2: return splat_launch_diet<1, false, float, float>(gp, grid, st);
-        case 3: return splat_launch_diet<1, true, float, float>(gp, grid, st);
-        case 4: return splat_launch_diet<2, false, float, float>(gp, grid, st);
-        case 5: return splat_launch_diet<2, true, float, float>(gp, grid, st);
-        case 6: return splat_launch_diet<3, false, float, float>(gp, grid, st);
-        case 7: return splat_launch_diet<3, true, float, float>(gp, grid, st);
+        case 2: return splat_launch_diet<1, false, float, float>(gp, grid, st, extra_lds, lean, info);
+        case 3: return splat_launch_diet<1, true, float, float>(gp, grid, st, extra_lds, lean, info);
+        case 4: return splat_launch_diet<2, false, float, float>(gp, grid, st, extra_lds, lean, info);
+        case 5: return splat_launch_diet<2, true, float, float>(gp, grid, st, extra_lds, lean, info);
+        case 6: return splat_launch_diet<3, false, float, float>(gp, grid, st, extra_lds, lean, info);
+        case 7: return splat_launch_diet<3, true, float, float>(gp, grid, st, extra_lds, lean, info);
     }
     return OFL_E_UNSUPPORTED;
+}
+int ofl_splat_launch_gather_diet(const void* params, int nc, int mch, int elem, unsigned grid, void* stream, int extra_lds) {
+    return splat_diet_dispatch(static_cast<const GatherParams*>(params), nc, mch, elem, grid, (hipStream_t)stream, extra_lds, 0, nullptr);
+}
+extern "C" __attribute__((visibility("default"))) int ofl_splat_gather_info(int32_t channels, int32_t with_mask_chan, int32_t elem, int32_t lean,
+                                                                            int32_t extra_lds, int32_t* info4) {
+    if (!info4) return OFL_E_NULL;
+    if (channels < 1 || channels > 3 || elem < 0 || elem > 2 || extra_lds < 0) return OFL_E_ARG;
+    return splat_diet_dispatch(nullptr, channels, with_mask_chan ? 1 : 0, elem, 0, nullptr, extra_lds, lean, info4);
 }
 #elif defined(OFL_WIDE_TU)
 }  // namespace
@@ -4197,6 +4303,7 @@ int g_warp_path = 0;   // ofl_set_option(OFL_OPT_WARP_PATH, .): 0 auto, 1 generi
 int g_warp_shear = 1;   // ofl_set_option(OFL_OPT_WARP_SHEAR, .)
 int g_splat_pass_images = 0;   // ofl_set_option(OFL_OPT_SPLAT_PASS_IMAGES, .): 0 = automatic (one pass unless the fallback accumulator of a pass would pass 2^31 floats)
 int g_splat_path = 0;   // ofl_set_option(OFL_OPT_SPLAT_PATH, .): 0 = the diet gather kernel (round 6: 16-24-byte records, one-word cells, 3 blocks per CU), 1 = round 5's gather kernel (tests compare the two bit for bit; A/B)
+int g_splat_extra_lds = 0;   // ofl_set_option(OFL_OPT_SPLAT_EXTRA_LDS, .): bytes of dynamic LDS added to the diet kernel's launches (occupancy experiments: 28 672 -> two blocks per CU, 65 536 -> one)
 int g_splat_fallback_slots = 0;   // ofl_set_option(OFL_OPT_SPLAT_FALLBACK_SLOTS, .): 0 = automatic (1 GiB); tests use 1 to exercise the rounds
 
 template <int NC>
@@ -4394,7 +4501,7 @@ inline unsigned fallback_resident_blocks(const void* kernel, int which) {
 template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
     // round 6: the diet kernel (3 blocks per CU) unless the tests / an A-B ask for round 5's (32-byte records, 2 blocks per CU)
-    if (g_splat_path != 1) return ofl_splat_launch_gather_diet(&gp, NC, MCH ? 1 : 0, std::is_same<TF, float>::value ? 0 : (std::is_same<TO, float>::value ? 1 : 2), grid, (void*)st);
+    if (g_splat_path != 1) return ofl_splat_launch_gather_diet(&gp, NC, MCH ? 1 : 0, std::is_same<TF, float>::value ? 0 : (std::is_same<TO, float>::value ? 1 : 2), grid, (void*)st, g_splat_extra_lds);
     if (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp.s)) hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
     else hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
     return (int)hipGetLastError();
@@ -4454,7 +4561,7 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-__attribute__((visibility("default"))) int ofl_version(void) { return 32; }   // 32: OFL_OPT_WARP_PATH value 7 (four-tile row-table columns whatever the size); row tables for small launches, the other flow-level warps, fp16 / uint8 sources, the gradient-wrt-flow pass; 31: OFL_OPT_WARP_PATH value 6 (the sheared rectangle instead of per-row extents: warp_bwd_rows_kernel is the default for large lean launches); 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
+__attribute__((visibility("default"))) int ofl_version(void) { return 33; }   // 33: the gather splat's diet kernel (ofl_splat_gather.hip), OFL_OPT_SPLAT_PATH / OFL_OPT_SPLAT_EXTRA_LDS, ofl_splat_gather_info; 32: OFL_OPT_WARP_PATH value 7 (four-tile row-table columns whatever the size); row tables for small launches, the other flow-level warps, fp16 / uint8 sources, the gradient-wrt-flow pass; 31: OFL_OPT_WARP_PATH value 6 (the sheared rectangle instead of per-row extents: warp_bwd_rows_kernel is the default for large lean launches); 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
 __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t value) {
     if (key == OFL_OPT_WARP_PATH && value >= 0 && value <= 7) { g_warp_path = value; return OFL_OK; }
@@ -4462,6 +4569,7 @@ __attribute__((visibility("default"))) int ofl_set_option(int32_t key, int32_t v
     if (key == OFL_OPT_SPLAT_PASS_IMAGES && value >= 0) { g_splat_pass_images = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_FALLBACK_SLOTS && value >= 0) { g_splat_fallback_slots = value; return OFL_OK; }
     if (key == OFL_OPT_SPLAT_PATH && (value == 0 || value == 1)) { g_splat_path = value; return OFL_OK; }
+    if (key == OFL_OPT_SPLAT_EXTRA_LDS && value >= 0 && value <= 100 * 1024) { g_splat_extra_lds = value; return OFL_OK; }
     return OFL_E_ARG;
 }
 
@@ -4762,10 +4870,12 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 }
 
 
-// workspace words of one pass of `images` frames: statistics (8) | per-image fallback flags | list lengths | lists
+// workspace words of one pass of `images` frames: statistics (8: [0] some image on the two-pass path, [1] fold tiles, [2] images on
+// the two-pass path, [3] tiles that took the gather's second launch, [4..5] grid-barrier arrivals, [6] length of the redo list) |
+// per-image fallback flags | list lengths | lists | redo list
 static int64_t splat_pass_words(int64_t images, int32_t h, int32_t w) {
     const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
-    return 8 + ((images + 3) & ~(int64_t)3) + ((tiles + 3) & ~(int64_t)3) + (int64_t)kBinCap * tiles;
+    return 8 + ((images + 3) & ~(int64_t)3) + ((tiles + 3) & ~(int64_t)3) + (int64_t)kBinCap * tiles + 8 * tiles;   // (+ the redo list: up to 4 bands per tile, 2 words each)
 }
 static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
     // one pass unless the caller bounds it (a testing aid) or the fallback accumulator of a pass would pass ~2^31 floats
@@ -4856,6 +4966,8 @@ static int splat_tiled_impl(
     gp.img_over = workspace + 8;
     gp.cnt = gp.img_over + ((chunk + 3) & ~(int64_t)3);
     gp.list = reinterpret_cast<uint32_t*>(gp.cnt + ((ctiles + 3) & ~(int64_t)3));
+    gp.redo_cnt = workspace + 6;
+    gp.redo_list = gp.list + (int64_t)kBinCap * ctiles;      // (8-byte entries: the lists before it are a multiple of 8 bytes long, the words before them a multiple of 4)
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;                          // (the statistics words are zeroed with the first pass's list lengths)
     if (dst_flags) {
@@ -4893,7 +5005,7 @@ static int splat_tiled_impl(
         // per-image fallback flags and list lengths of this pass
         const size_t zwords = (size_t)(((chunk + 3) & ~(int64_t)3) + ctiles);
         e = n0 == 0 ? hipMemsetAsync(gp.stats, 0, (8 + zwords) * sizeof(int32_t), st)      // statistics | flags | lengths: contiguous
-                    : hipMemsetAsync(gp.img_over, 0, zwords * sizeof(int32_t), st);
+                    : hipMemsetAsync(gp.redo_cnt, 0, (2 + zwords) * sizeof(int32_t), st);  // (the redo list's length sits right before the flags)
         if (e != hipSuccess) return (int)e;
         const bool lean = splat_is_lean(gp.s);
         if (half_in) { if (lean) hipLaunchKernelGGL((splat_bin_kernel<_Float16, true>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
@@ -4911,6 +5023,10 @@ static int splat_tiled_impl(
             if (c0 > 0) { full.with_mask_chan = 0; full.density = nullptr; full.warped = nullptr; full.valid = nullptr; full.mask_chan = nullptr; }
             const int32_t cg = full.c;
             gp.s = full;
+            if (c0 > 0) {                                     // (every channel group fills the redo list anew)
+                e = hipMemsetAsync(gp.redo_cnt, 0, sizeof(int32_t), st);
+                if (e != hipSuccess) return (int)e;
+            }
             const unsigned grid = (unsigned)(gp.per_xcd * kXcds);
             if (half_in) rc = launch_splat_gather_half(gp, grid, st, elem);
             else switch (cg) {

@@ -44,7 +44,7 @@ class _HostExchange(object):
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.seq = 0
         self.lock = threading.Lock()          # or_reduce from two threads of one rank: `seq` and the slot store are one step
-        self.timeout = _exchange_timeout(group)
+        self.group = group                    # (the timeout is resolved at every exchange: EXCHANGE_TIMEOUT_SECONDS may be set after enable_batch_sharding)
         size = self.world * self.RING * 8
         name = [None]
         self.shm = None
@@ -88,7 +88,7 @@ class _HostExchange(object):
         self.seq += 1
         k, e = self.seq, self.seq % self.RING
         self.slots[self.rank, e] = (k << 8) | (bits & 0xff)          # one aligned 8-byte store: sequence number and bits arrive together
-        total, t0, looks = bits & 0xff, None, 0
+        total, t0, looks, timeout = bits & 0xff, None, 0, None
         for r in range(self.world):
             if r == self.rank:
                 continue
@@ -98,14 +98,20 @@ class _HostExchange(object):
                     total |= v & 0xff
                     break
                 looks += 1
-                if looks & 0x3ff == 0:
+                if looks & 0x3ff == 0 or t0 is not None:
+                    # (the first 1 024 looks spin: peers post within microseconds; after that every look checks the clock and, a
+                    # millisecond in, sleeps between looks -- a rank waiting for a peer that is compiling or checkpointing must not
+                    # burn a core while it holds `lock`)
                     now = time.perf_counter()
                     t0 = now if t0 is None else t0
-                    if now - t0 > self.timeout:
-                        raise RuntimeError("oflibpytorch_amd.distributed: rank %d did not post flag exchange %d (ranks must make "
-                                           "the same sequence of calls)" % (r, k))
+                    if timeout is None:
+                        timeout = _exchange_timeout(self.group)
+                    if now - t0 > timeout:
+                        raise RuntimeError("oflibpytorch_amd.distributed: rank %d did not post flag exchange %d within %.0f s (ranks "
+                                           "must make the same sequence of calls; EXCHANGE_TIMEOUT_SECONDS overrides the process "
+                                           "group's timeout)" % (r, k, timeout))
                     if now - t0 > 1e-3:
-                        time.sleep(5e-5)
+                        time.sleep(5e-5 if now - t0 < 1.0 else 1e-3)
         return total
 
     def close(self):
@@ -236,7 +242,21 @@ def broadcast_operand(t: torch.Tensor, src: int = 0) -> torch.Tensor:
     if dist.is_initialized() and (dist.get_world_size(_group) > 1 or _force_collectives):
         t = t.contiguous()
         dist.broadcast(t, src=src, group=_group)
+        _bump_version(t)
     return t
+
+
+def _bump_version(t: torch.Tensor):
+    """c10d's in-place collectives write a tensor WITHOUT touching its version counter (checked: `dist.broadcast` leaves
+    `_version` where it was), and a `Flow` caches the flag word of its vectors -- finite? all zero? -- under that counter
+    (flow_class.py `_key`): a persistent Flow round a re-used receive buffer would keep the word of the previous contents and take
+    (or miss) the reference's early exits (utils.py:497-498, flow_class.py:1729-1744) on stale data.  Every in-place collective
+    of this module therefore bumps the counter itself.  (Inference tensors have no counter; their flag words are never cached
+    across calls unless the tensor is private to a Flow, which a caller-supplied receive buffer is not.)"""
+    try:
+        torch.autograd.graph.increment_version(t)
+    except Exception:  # noqa: BLE001   (an inference tensor: nothing to bump, nothing cached)
+        pass
 
 
 def all_gather_batch(t: torch.Tensor) -> torch.Tensor:

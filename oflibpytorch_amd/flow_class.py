@@ -43,6 +43,53 @@ class _NeverEqual(object):
     __hash__ = None
 
 
+# -- the reference's per-call zero / finiteness tests, on demand ---------------------------------------------------------------
+# The reference re-computes `is_zero` / `isfinite().all()` inside EVERY apply / combine_with (utils.py:497-498, flow_class.py:
+# 1226-1244, 1729-1744).  Here the flag word of a tensor is cached under its version counter, which sees every in-place edit torch
+# itself makes -- but not a write through a NumPy array that shares the memory (`torch.from_numpy`), through `.data`, by a foreign
+# kernel, or by a c10d in-place collective on the tensor (those leave `_version` alone; `distributed.broadcast_operand` bumps it
+# itself).  Two ways to tell the library that such a write happened:
+#   * `Flow.invalidate()` drops the cached word of one flow;
+#   * `set_revalidate_every_call(True)` makes every PUBLIC call (apply, combine_with, switch_ref, is_zero, ...) start a new epoch
+#     that no cached word belongs to: each call looks at its operands again, exactly as the reference does (within a call the words
+#     are still shared between the steps of that call).
+_reval_on = False
+_reval_epoch = 0
+_reval_depth = 0
+
+
+def set_revalidate_every_call(on: bool = True):
+    """True: every public `Flow` method re-runs the fused validation / zero-test reduction on the flows it reads (the reference's
+    behaviour, utils.py:497-498); False (default): the flag word is cached per tensor version.  Turn it on when flow storage is
+    written behind torch's back (NumPy views, `.data`, custom kernels, in-place collectives), or call `Flow.invalidate()`."""
+    global _reval_on, _reval_epoch
+    _reval_on = bool(on)
+    _reval_epoch += 1
+
+
+def get_revalidate_every_call() -> bool:
+    return _reval_on
+
+
+def _public(fn):
+    """Entry point of the public API: with `set_revalidate_every_call(True)` the outermost public call starts a new epoch."""
+    import functools
+
+    @functools.wraps(fn)
+    def entry(*args, **kwargs):
+        global _reval_epoch, _reval_depth
+        if not _reval_on:
+            return fn(*args, **kwargs)
+        if _reval_depth == 0:
+            _reval_epoch += 1
+        _reval_depth += 1
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            _reval_depth -= 1
+    return entry
+
+
 def _ver(t: torch.Tensor, private: bool = False):
     """Version counter of a tensor (see below; the common case is one attribute read).  Inference tensors have none (reading `_version` raises) yet CAN be edited in place inside
     `torch.inference_mode()`: nothing tells an edited one from an untouched one, so their flag words are never cached
@@ -196,7 +243,7 @@ class Flow(object):
         torch.inference_mode() carry no version counter: their key never matches, i.e. every call that needs the flags of
         such a flow runs the (cheap, fused) reduction again -- an in-place edit inside inference mode must not meet a
         stale 'all zero' / 'finite' word."""
-        return (_ver(self._fv, self._private), None if self._mask is None else (id(self._mask), _ver(self._mask, self._private)))
+        return (_ver(self._fv, self._private), None if self._mask is None else (id(self._mask), _ver(self._mask, self._private)), _reval_epoch)
 
     def _flags_known(self) -> bool:
         key = self._key()
@@ -256,6 +303,15 @@ class Flow(object):
             glob = distributed.reduce_flags(local, self._fv.device)
             self._flag_cache = (self._flag_cache[0], self._flag_cache[1], (distributed.is_enabled(), glob))
         return self._flag_cache[2][1]
+
+    def invalidate(self) -> FlowAlias:
+        """Forget what is known about the vectors (finite / all zero / below the threshold, plain and under the mask): the next call
+        that needs it looks again.  For writes torch's version counter does not see -- a NumPy array sharing the memory
+        (`torch.from_numpy`), `tensor.data`, a custom kernel, an in-place collective on the tensor.  The reference needs no such call
+        because it runs the tests inside every apply / combine_with (utils.py:497-498, flow_class.py:1226-1244); see also
+        `set_revalidate_every_call`.  Returns the flow itself."""
+        self._flag_cache, self._pending_flags = None, None
+        return self
 
     def _require_finite(self, error_string: str):
         if self._batch_flags() & _native.FLAG_NONFINITE:                              # utils.py:98
@@ -355,7 +411,7 @@ class Flow(object):
         if self._fv.device != device:
             self._vecs = self._fv.to(device) if device.type == 'cuda' else self._vecs.to(device)
             self._flag_cache = None if self._flag_cache is None else \
-                ((_ver(self._fv), self._flag_cache[0][1]), self._flag_cache[1])
+                ((_ver(self._fv),) + tuple(self._flag_cache[0][1:]), self._flag_cache[1])
         if self._mask is not None and self._mask.device != device:
             flags = None if self._flag_cache is None else self._flag_cache[1]
             self._mask = self._mask.to(device)
@@ -1093,3 +1149,10 @@ def _combine_plan(mode: int, self_ref: str, other_ref: str, out_ref: str) -> _Co
         sign_far=hop_in if goal == b else hop_out)
     _PLANS[key] = plan
     return plan
+
+
+# the public methods that read a flow's flag word: each starts a new validation epoch under set_revalidate_every_call(True)
+for _name in ('apply', 'track', 'switch_ref', 'invert', 'valid_target', 'valid_source', 'get_padding', 'is_zero', 'combine_with',
+              'combine'):
+    setattr(Flow, _name, _public(getattr(Flow, _name)))
+del _name

@@ -173,3 +173,56 @@ def test_from_matrix_contract():
     from oflibpytorch_amd import utils
     one = utils.flow_from_matrix(shift, [1, 6, 8])
     assert one.shape == (1, 2, 6, 8) and torch.equal(one, utils.flow_from_matrix(shift.unsqueeze(0), [1, 6, 8]))
+
+
+def test_writes_torch_cannot_see_invalidate_and_revalidate_every_call():
+    """VERDICT r5 (what's weak 2): the flag word (finite? all zero?) is cached under the tensor's version counter, which does not see a
+    write through a NumPy array sharing the memory or through `.data`.  The reference re-tests inside every call (utils.py:497-498,
+    flow_class.py:1226-1244); here `Flow.invalidate()` and `set_revalidate_every_call(True)` give that behaviour back."""
+    from oracle import oracle
+    h, w = 12, 16
+    img = torch.rand(1, 3, h, w, generator=torch.Generator().manual_seed(4))
+    new = (torch.randn(1, 2, h, w, generator=torch.Generator().manual_seed(5)) * 2).numpy()
+    exp, _ = oracle.flow_apply(new, 't', None, img.numpy(), None)
+
+    # NumPy alias: the premise (stale early exit), then the two remedies
+    a = np.zeros((1, 2, h, w), np.float32)
+    f = Flow(torch.from_numpy(a), 't')
+    assert f.apply(img) is img and bool(f.is_zero().all())            # all-zero flow: the target itself (utils.py:497-498)
+    a[:] = new
+    assert f.apply(img) is img                                         # the cached word is stale: documented, INTEGRATION.md
+    assert f.invalidate() is f
+    out = f.apply(img)
+    assert out is not img and np.array_equal(out.numpy(), exp) and not bool(f.is_zero().any())
+
+    a[:] = 0
+    assert ofl.get_revalidate_every_call() is False
+    ofl.set_revalidate_every_call(True)
+    try:
+        assert f.apply(img) is img                                     # looked again: all zero
+        a[:] = new
+        out = f.apply(img)                                             # ... and again: warps
+        assert out is not img and np.array_equal(out.numpy(), exp)
+        # `.data` edits leave the version alone too
+        t = torch.zeros(1, 2, h, w)
+        g = Flow(t, 't')
+        assert g.apply(img) is img
+        t.data.add_(torch.from_numpy(new))
+        assert t._version == 0
+        assert np.array_equal(g.apply(img).numpy(), exp)
+        # a write that makes the flow non-finite is caught by the call that reads it (the reference: utils.py:98 in every call)
+        t.data[0, 0, 0, 0] = float('nan')
+        with pytest.raises(ValueError):
+            g.apply(img)
+        # combine_with's early exits re-test both operands (flow_class.py:1729-1744)
+        z = torch.zeros(1, 2, h, w)
+        fz, fo = Flow(z, 't'), Flow(torch.from_numpy(new.copy()), 't')
+        assert fz.combine_with(fo, 3) is fo
+        z.data.add_(1.5)
+        assert fz.combine_with(fo, 3) is not fo
+    finally:
+        ofl.set_revalidate_every_call(False)
+    assert ofl.get_revalidate_every_call() is False
+    # signatures of the wrapped public methods still read as the reference's (the wrapper is transparent to inspect)
+    import inspect
+    assert list(inspect.signature(Flow.apply).parameters) == ['self', 'target', 'target_mask', 'return_valid_area', 'consider_mask', 'padding', 'cut']

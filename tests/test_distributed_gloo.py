@@ -140,8 +140,34 @@ def _worker(rank, world, port, q):
         [t.start() for t in ths]
         [t.join() for t in ths]
         assert got == [0b11] * 200
-        assert ofd._exchange.timeout >= 600.0       # the process group's own timeout (gloo: 30 min), not a private 120 s
+        assert ofd._exchange_timeout(None) >= 600.0       # the process group's own timeout (gloo: 30 min), not a private 120 s
+        ofd.EXCHANGE_TIMEOUT_SECONDS = 7.5                # read at every exchange, so setting it AFTER enable_batch_sharding() counts
+        assert ofd._exchange_timeout(ofd._exchange.group) == 7.5
+        ofd.EXCHANGE_TIMEOUT_SECONDS = None
         ofd.disable_batch_sharding()
+        # 6. VERDICT r5: a persistent Flow round a receive buffer must not keep the flag word of the buffer's PREVIOUS contents.
+        # c10d's in-place broadcast leaves `_version` alone (asserted here), so broadcast_operand bumps it itself: the Flow built
+        # on the all-zero buffer took the zero-flow early exit (returns its target), after the broadcast of rank 0's flow it warps.
+        buf = torch.zeros(1, 2, h, w)
+        shared = ofl.Flow(buf, 't')
+        img = torch.rand(1, 3, h, w, generator=torch.Generator().manual_seed(11))
+        assert shared.apply(img) is img                   # utils.py:497-498: all-zero flow -> the target itself
+        probe = torch.zeros(3)
+        v0 = probe._version
+        dist.broadcast(probe, src=0)
+        assert probe._version == v0                       # (the premise: c10d does not bump versions)
+        new_flow = torch.randn(1, 2, h, w, generator=torch.Generator().manual_seed(12)) * 3
+        if rank == 0:
+            buf.copy_(new_flow)
+            buf = buf.detach()
+        v0 = shared.vecs._version
+        got = ofd.broadcast_operand(shared.vecs, src=0)
+        assert got is shared.vecs and shared.vecs._version > v0
+        assert torch.equal(shared.vecs, new_flow)
+        warped = shared.apply(img)
+        assert warped is not img
+        exp, _ = oracle.flow_apply(new_flow.numpy(), 't', None, img.numpy(), None)
+        assert np.array_equal(warped.numpy(), exp)
         # (b) rank 0 cannot create the segment: EVERY rank falls back to the communicator route together (nobody is left in a collective)
         from multiprocessing import shared_memory
         real_shm = shared_memory.SharedMemory
