@@ -3536,9 +3536,12 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
         redo_n = __builtin_amdgcn_readfirstlane(p.redo_cnt[0]);
         if (tid == 0 && blockIdx.x == 0 && redo_n != 0) atomicAdd(&p.stats[3], redo_n);     // statistics: tiles that took the second launch
     }
+    // (REDO: the units of the list are handed out one at a time through a counter -- they differ by an order of magnitude in work, and
+    // with a fixed stride the launch lasted as long as its unluckiest block)
+    __shared__ int next_unit;
     int ri = (int)blockIdx.x;
     if (REDO && ri >= redo_n) return;
-    do {                                                              // (REDO: the tiles of the list, gridDim.x apart; else once)
+    do {                                                              // (REDO: units of the list until it is empty; else once)
     int tx, ty, n, ua = 0, ub = kSpTH;
     uint32_t tile;
     if (REDO) {
@@ -3878,8 +3881,9 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
         block_flag_or(&s.dst_flags[n], dflags);              // one access per block on the image's word (see block_flag_or)
     }
     if (!REDO) break;
-    __syncthreads();                                          // (the next tile of the list re-uses the LDS)
-    ri += (int)gridDim.x;
+    if (tid == 0) next_unit = (int)gridDim.x + atomicAdd(&p.redo_cnt[1], 1);
+    __syncthreads();                                          // (also: the next unit re-uses the LDS)
+    ri = __builtin_amdgcn_readfirstlane(next_unit);
     } while (ri < redo_n);
 #undef s
 #undef p
@@ -5024,7 +5028,7 @@ static int splat_tiled_impl(
             const int32_t cg = full.c;
             gp.s = full;
             if (c0 > 0) {                                     // (every channel group fills the redo list anew)
-                e = hipMemsetAsync(gp.redo_cnt, 0, sizeof(int32_t), st);
+                e = hipMemsetAsync(gp.redo_cnt, 0, 2 * sizeof(int32_t), st);     // (its length and the second launch's hand-out counter)
                 if (e != hipSuccess) return (int)e;
             }
             const unsigned grid = (unsigned)(gp.per_xcd * kXcds);

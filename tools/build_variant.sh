@@ -6,5 +6,5 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$root/tools/microbench/var"
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fvisibility=hidden "$@" \
-  -I "$root/include" -o "$root/tools/microbench/var/$name.so" "$root/oflibpytorch_amd/csrc/ofl_kernels.hip" "$root/oflibpytorch_amd/csrc/ofl_aux_kernels.hip" "$root/oflibpytorch_amd/csrc/ofl_warp_wide.hip"
+  -I "$root/include" -o "$root/tools/microbench/var/$name.so" "$root/oflibpytorch_amd/csrc/ofl_kernels.hip" "$root/oflibpytorch_amd/csrc/ofl_aux_kernels.hip" "$root/oflibpytorch_amd/csrc/ofl_warp_wide.hip" "$root/oflibpytorch_amd/csrc/ofl_splat_gather.hip"
 echo "$root/tools/microbench/var/$name.so"
