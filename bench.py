@@ -270,6 +270,30 @@ def _sharded_child(route, steps):
         return None
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child, relay the JSON line rank 0
+    prints, return the child's exit code (with its stderr on failure).  Nothing here touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or not lines:
+        sys.stderr.write(res.stderr[-8000:])
+        sys.stderr.write("\nbench.py: the %d-rank child (%s) failed with exit code %d\n" % (n, " ".join(cmd), res.returncode))
+        return res.returncode if res.returncode != 0 else 1
+    print(lines[-1])
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,8 +302,13 @@ def main():
     ap.add_argument("--blocks", type=int, default=0,
                     help="timed blocks of EXACTLY --steps steps each (0: max(5, 500 / steps)); `value` is the median block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (BASELINE configs 2, 3, 5)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: strong (a global batch of --batch, BASELINE configs[3]) at N > 1, weak at N = 1 (the same job there)")
     ap.add_argument("--batch", type=int, default=64, help="batch elements per GPU (weak) / in the whole job (strong)")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks as child processes even at --gpus 1 (what `--gpus N`, N > 1, does when RANK is not in the environment)")
+    ap.add_argument("--n1-ms", type=float, default=None, help="ms_per_step of the N = 1 run of the same job: adds speedup_vs_n1")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1, strong scaling: skip the weak-scaling figure (B = --batch per GPU)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -300,9 +329,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if (args.gpus > 1 or args.self_launch) and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as FRESH child processes, before this process has made
+        # any GPU call (a process that has touched the GPU must never be replaced), and relay rank 0's line
+        sys.exit(_self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d is running under WORLD_SIZE=%d: launch it with torch.distributed.run --nproc-per-node %d, "
+                 "or without RANK / WORLD_SIZE in the environment (it then starts its ranks itself)" % (args.gpus, world, args.gpus))
+    if args.scaling is None:
+        # N > 1 measures BASELINE.json configs[3] as north_star states it: a GLOBAL batch of 64 sharded over the GPUs (strong
+        # scaling, 8 elements per GPU at N = 8; utils.py:527-537, flow_class.py:896-897 partition on the batch axis) -- the
+        # weak-scaling figure (B = 64 per GPU) rides along as `weak_scaling`.  N = 1: both are the same job.
+        args.scaling = "strong" if world > 1 else "weak"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -369,12 +407,14 @@ def main():
         if args.shared_image and rank != 0:
             torch.cuda.synchronize()
             assert torch.equal(img, own_img) and torch.equal(tm, own_tm), "broadcast_operand did not deliver rank 0's operand"
+        ranks_seen = 1
         for _ in range(blocks):
             barrier()
             t0 = time.perf_counter()
             share()                                                     # (inside the timed region, once per block)
             for _ in range(steps):                                      # EXACTLY `steps` timed steps per block
                 step_streaming()
+            ranks_seen = dist.get_world_size() if dist.is_initialized() else 1      # the communicator as seen INSIDE the timed region
             barrier()
             stream_s.append(time.perf_counter() - t0)
         # the same step on pre-built objects (validation cached per tensor version)
@@ -407,7 +447,12 @@ def main():
         ta = sorted(e[0].elapsed_time(e[1]) for e in ev)
         tc = sorted(e[1].elapsed_time(e[2]) for e in ev)
         bms = sorted(e0.elapsed_time(e1) for e0, e1 in bcast_ev[1:]) if len(bcast_ev) > 1 else []
+        flow2.apply(img, target_mask=tm, return_valid_area=True)
+        kernel_apply = _native.last_kernel_name()                  # the instantiation the launcher picked for THIS launch
+        flow1.combine_with(flow2, 3)
+        kernel_comb = _native.last_kernel_name()
         return {"stream_s": stream_s, "cached_s": cached_s, "launches": k, "broadcast_ms": (bms[len(bms) // 2] if bms else None),
+                "rccl_ranks": ranks_seen, "kernel_apply": kernel_apply, "kernel_combine3": kernel_comb,
                 "apply_ms": sum(ta) / k, "comb_ms": sum(tc) / k, "apply_ms_median": ta[k // 2], "comb_ms_median": tc[k // 2],
                 "apply_ms_min": ta[0], "comb_ms_min": tc[0]}
 
@@ -423,6 +468,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         stream_blocks, cached_blocks = [float(v) for v in t[0].tolist()], [float(v) for v in t[1].tolist()]
     elapsed, el_cached = med(stream_blocks), med(cached_blocks)          # the median block is the reported one
+
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak and not args.shared_image:
+        # the weak-scaling figure beside the headline: B = --batch on EVERY GPU (a job `world` times as large)
+        wk = measure(args.batch, args.steps, args.warmup, 100 + rank, max(3, blocks // 2))
+        t = torch.tensor(wk["stream_s"], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wms = med([float(v) for v in t.tolist()]) / args.steps * 1e3
+        weak = {"scaling": "weak", "batch_per_gpu": args.batch, "global_batch": args.batch * world, "ms_per_step": round(wms, 4),
+                "value": round(args.batch * world * h * w / (wms * 1e-3) / 1e6, 1), "unit": "Mpix/s"}
 
     probe = None
     if world == 1 and not args.no_probe and not args.shared_image and (n, h, w) == (64, 1080, 1920):
@@ -466,12 +521,23 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     copy_gbs = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del a, b
+    # a stream with the apply kernel's byte mix -- 22 bytes read for 13 written (flow 8 + image 12 + two masks | image 12 + mask 1) --
+    # as plain torch elementwise work: out[13 parts] = f(in[22 parts]) over 1 GiB; what a streaming kernel of this mix reaches here
+    parts = a.numel() // 22
+    src22, dst13 = a[:22 * parts].view(22, parts), b[:13 * parts].view(13, parts)
+    torch.add(src22[:13], src22[9:22], out=dst13)                       # (reads all 22 rows -- rows 9..12 twice, from cache -- writes 13)
+    e0.record()
+    for _ in range(5):
+        torch.add(src22[:13], src22[9:22], out=dst13)
+    e1.record()
+    torch.cuda.synchronize()
+    mix_gbs = 5 * 35 * parts * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b, src22, dst13
 
     if rank == 0:
         traffic_source = "--traffic-bytes" if args.traffic_bytes is not None else None
         if args.traffic_bytes is None and not args.shared_image and (n, h, w) == (64, 1080, 1920):
-            for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # PMC passes are separate runs (tools/refresh_profiles_r5.sh)
+            for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):   # PMC passes are separate runs (tools/refresh_profiles_r5.sh)
                 tj = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tj):
                     with open(tj) as fh:
@@ -507,7 +573,7 @@ def main():
                        "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
                        "ms_per_step_max": round(per_step[-1], 4),
                        "value_min": round(gpx / (per_step[-1] * 1e-3) / 1e6, 1), "value_max": round(gpx / (per_step[0] * 1e-3) / 1e6, 1)},
-            "roofline": {"bound": "hbm", "kernel": "warp_bwd_rows_kernel<4,3,valid> (Flow.apply 't': four-tile columns of 64 x 16 tiles, per-row extents of the staged box)",
+            "roofline": {"bound": "hbm", "kernel": r["kernel_apply"] + " (Flow.apply 't'; the name the library reports for the launch: ofl_last_kernel_name)",
                          "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4),
                          "traffic": args.traffic_bytes,
@@ -515,14 +581,23 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_apply * px),
                          "avg_launch_ms": round(t_apply, 4), "median_launch_ms": round(r["apply_ms_median"], 4),
                          "min_launch_ms": round(r["apply_ms_min"], 4), "launches_timed": r["launches"],
-                         "device_copy_GBs": round(copy_gbs, 1), "frac_of_device_copy": round(ach / copy_gbs, 4)},
-            "kernels": {"apply_ms": round(t_apply, 4), "apply_GBs": round(ach, 1),
+                         "device_copy_GBs": round(copy_gbs, 1),
+                         "read_mostly_stream_GBs": round(mix_gbs, 1),
+                         "read_mostly_stream_note": "torch.add over 1 GiB with the apply kernel's byte mix (22 B read : 13 B written); a same-box "
+                                                    "reference point for a streaming kernel of that mix, not a ceiling"},
+            "rccl_ranks": r["rccl_ranks"],
+            "kernels": {"apply_kernel": r["kernel_apply"], "combine3_kernel": r["kernel_combine3"],
+                        "apply_ms": round(t_apply, 4), "apply_GBs": round(ach, 1),
                         "combine3_ms": round(t_comb, 4), "combine3_ms_median": round(r["comb_ms_median"], 4),
                         "combine3_GBs": round(BYTES_COMBINE * px / (t_comb * 1e-3) / 1e9, 1),
                         "combine3_frac": round(BYTES_COMBINE * px / (t_comb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "validation_ms_per_step": round(ms_step - el_cached / args.steps * 1e3, 4)},
             "value_cached_flow_objects": round(gpx / (el_cached / args.steps) / 1e6, 1),
         }
+        if args.n1_ms is not None:
+            out["speedup_vs_n1"] = round(args.n1_ms / ms_step, 3)
+        if weak is not None:
+            out["weak_scaling"] = weak
         if args.shared_image:
             out["broadcast_ms"] = None if r["broadcast_ms"] is None else round(r["broadcast_ms"], 4)
             out["broadcast_note"] = ("median HIP-event time of the two broadcasts (image 3 x H x W fp32 + mask H x W bytes) per timed block; "

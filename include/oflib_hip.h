@@ -85,6 +85,10 @@ int ofl_version(void);
  *   lowers the blocks a CU holds (28 672: two, 65 536: one) without changing a single instruction (tools/splat_occupancy.py). */
 #define OFL_OPT_SPLAT_EXTRA_LDS 7
 int ofl_set_option(int32_t key, int32_t value);
+/* the (mangled) name of the kernel the library launched LAST, as the loaded code object spells it ("" before the first launch) --
+ * a diagnostic: bench.py reports the instantiation the launchers actually picked for its roofline kernel.  Process-global, like
+ * the options; the pointer stays valid while the library is loaded. */
+const char* ofl_last_kernel_name(void);
 
 /* rounding applied to the warped channels before the store (apply_flow utils.py:613-618,
  * Flow.apply flow_class.py:943-946): 0 none, 1 round-half-even, 2 round then clamp to [0,255] */

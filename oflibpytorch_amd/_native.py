@@ -26,7 +26,7 @@ _SYMBOLS = ("ofl_version", "ofl_set_option", "ofl_warp_bwd_f32", "ofl_splat_fwd_
             "ofl_splat_tiled_f32", "ofl_flow_flags_f32", "ofl_warp_bwd_u8", "ofl_flow_from_f16",
             "ofl_warp_bwd_grad_f32", "ofl_splat_grad_f32", "ofl_sample_pts_f32", "ofl_sample_pts_grad_f32",
             "ofl_flow_extents_f32", "ofl_flag_words_or_i32", "ofl_splat_sum_f32", "ofl_warp_bwd_win_f32", "ofl_splat_tiled_win_f32", "ofl_splat_tiled_f16",
-            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32", "ofl_resize_bilinear_f32", "ofl_splat_tile_geometry", "ofl_splat_gather_info")
+            "ofl_warp_bwd_h_f32", "ofl_flow_flags_host", "ofl_host_words_alloc", "ofl_host_words_free", "ofl_flow_from_matrix_f32", "ofl_splat_tiled_fallback_images", "ofl_warp_valid_f32", "ofl_resize_bilinear_f32", "ofl_splat_tile_geometry", "ofl_splat_gather_info", "ofl_last_kernel_name")
 _lib = None
 
 
@@ -102,6 +102,8 @@ def load_library(path: str = None):
     for name in _SYMBOLS:
         getattr(lib, name).restype = ctypes.c_int
     lib.ofl_splat_tiled_workspace_ints.restype = ctypes.c_int64
+    lib.ofl_last_kernel_name.restype = ctypes.c_char_p
+    lib.ofl_last_kernel_name.argtypes = []
     lib.ofl_splat_tiled_pass_images.restype = ctypes.c_int64
     lib.ofl_splat_tiled_fallback_images.restype = ctypes.c_int64
     _lib = lib
@@ -578,6 +580,21 @@ def set_splat_gather_kernel(which: int):
     """Gather splat: 0 = the round-6 kernel (compact records, three blocks per CU; default), 1 = round 5's kernel.  The same sums
     in the same order -- bit-identical results; tests compare the two, tools time them against each other."""
     _check(load_library().ofl_set_option(6, int(which)), "ofl_set_option")
+
+
+def last_kernel_name(demangle: bool = True) -> str:
+    """Name of the kernel the library launched last (the instantiation its launchers picked), demangled when c++filt is about."""
+    name = (load_library().ofl_last_kernel_name() or b"").decode()
+    if demangle and name:
+        import shutil
+        import subprocess
+        tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+        try:
+            name = subprocess.run([tool, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+        except Exception:  # noqa: BLE001
+            pass
+        name = name.replace("(anonymous namespace)::", "")
+    return name
 
 
 def set_splat_extra_lds(nbytes: int):

@@ -28,6 +28,11 @@ int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream);
 // the gather splat's diet kernel (ofl_splat_gather.hip: this file compiled with OFL_SPLAT_TU); `params` = a GatherParams; elem: 0 fp32, 1 fp16 in / fp32 out, 2 fp16 in and out
 int ofl_splat_launch_gather_diet(const void* params, int nc, int mch, int elem, unsigned grid, void* stream, int extra_lds);   // extra_lds: bytes of dynamic LDS added to the launch (OFL_OPT_SPLAT_EXTRA_LDS: occupancy experiments)
 
+// the kernel the library launched LAST, in any of its translation units (ofl_last_kernel_name: bench.py reports the instantiation
+// the launcher actually picked instead of a string literal -- VERDICT r5): every launch goes through OFL_KLAUNCH
+extern const void* g_ofl_last_kernel;
+#define OFL_KLAUNCH(K, ...) do { g_ofl_last_kernel = (const void*)(K); hipLaunchKernelGGL(K, __VA_ARGS__); } while (0)
+
 namespace {
 
 constexpr float kValidThr = 0.99999f;  // flow_class.py:922
@@ -4093,11 +4098,11 @@ static int splat_launch_diet(const GatherParams* gp, unsigned grid, hipStream_t 
         return OFL_OK;
     }
     if (ln) {
-        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), (size_t)extra_lds, st, *gp);
-        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2), true>), dim3(grid < kRedoGrid ? grid : kRedoGrid), dim3(kSpNT2), 0, st, *gp);
+        OFL_KLAUNCH((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), (size_t)extra_lds, st, *gp);
+        OFL_KLAUNCH((splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2), true>), dim3(grid < kRedoGrid ? grid : kRedoGrid), dim3(kSpNT2), 0, st, *gp);
     } else {
-        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), (size_t)extra_lds, st, *gp);
-        hipLaunchKernelGGL((splat_gather2_kernel<NC, MCH, TF, TO, false, true>), dim3(grid < kRedoGrid ? grid : kRedoGrid), dim3(kSpNT2), 0, st, *gp);
+        OFL_KLAUNCH((splat_gather2_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), (size_t)extra_lds, st, *gp);
+        OFL_KLAUNCH((splat_gather2_kernel<NC, MCH, TF, TO, false, true>), dim3(grid < kRedoGrid ? grid : kRedoGrid), dim3(kSpNT2), 0, st, *gp);
     }
     return (int)hipGetLastError();
 }
@@ -4149,7 +4154,7 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     if (OFL_WARP_ROWS && rows && lean && nc == 2 && (add || q.src_b || q.dst_flags)) {      // the flow-level variants with per-row extents
         const unsigned gr = RT == TT ? g : warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
         const int am = !add ? 0 : (q.add_is_flow ? 1 : 2);
-#define OFL_ROWS_F(V, A, S, D) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, V, A, S, D>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q)
+#define OFL_ROWS_F(V, A, S, D) OFL_KLAUNCH((warp_bwd_rows_kernel<RT, 2, V, A, S, D>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q)
         if (q.src_b) { if (!valid || add || q.dst_flags) return (int)hipErrorInvalidValue; OFL_ROWS_F(true, 0, true, false); }          // mode 1 't': src - src_b
         else if (q.dst_flags) {                                    // (host: only with a valid mask)
             if (!valid) return (int)hipErrorInvalidValue;
@@ -4162,8 +4167,8 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     if (OFL_WARP_ROWS && rows && lean && !add) {                  // per-row extents instead of one sheared rectangle (warp_bwd_rows_kernel)
         const unsigned gr = RT == TT ? g : warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
 #define OFL_ROWS_CASE(NC)                                                                                                    \
-        if (valid) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);   \
-        else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, false>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_rows_kernel<RT, NC, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);   \
+        else OFL_KLAUNCH((warp_bwd_rows_kernel<RT, NC, false>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, st, q);
         switch (nc) {
             case 1: OFL_ROWS_CASE(1) break;
             case 2: OFL_ROWS_CASE(2) break;
@@ -4174,13 +4179,13 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
     }
 #if OFL_WARP_COL_ADD >= 2
     if (add && OFL_WARP_REUSE && q.add_is_flow) {
-        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
     }
     if (add) {                                     // (the fused composition: 2 channels)
-        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
     }
 #else
@@ -4188,10 +4193,10 @@ int ofl_wide_launch_column(const void* params, int nc, int valid, int add, int r
 #endif
 #define OFL_WIDE_CASE(NC)                                                                                                                   \
     if (lean) {                                                                                                                              \
-        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);   \
-        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);        \
-    } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);      \
-    else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, NC, true, false, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);   \
+        else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, NC, false, false, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);        \
+    } else if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);      \
+    else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
     switch (nc) {
         case 1: OFL_WIDE_CASE(1) break;
         case 2: OFL_WIDE_CASE(2) break;
@@ -4210,7 +4215,7 @@ int ofl_wide_launch_rows_small(const void* params, int nc, int valid, int add, i
     hipStream_t st = (hipStream_t)stream;
     if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.src_b || q.dst_flags || nc < 1 || nc > 3 || (add && !(nc == 2 && q.add_is_flow))) return (int)hipErrorInvalidValue;
     const unsigned gs = warp_geometry(q, kLdsTWQ * 4, (tiles == 1 ? 1 : 2) * kLdsTH);
-#define OFL_ROWS_S(T_, NC, V, A) hipLaunchKernelGGL((warp_bwd_rows_kernel<T_, NC, V, A>), dim3(gs), dim3(kLdsNT), kRowsLdsBytes, st, q)
+#define OFL_ROWS_S(T_, NC, V, A) OFL_KLAUNCH((warp_bwd_rows_kernel<T_, NC, V, A>), dim3(gs), dim3(kLdsNT), kRowsLdsBytes, st, q)
 #define OFL_ROWS_ST(T_)                                                                                   \
     if (add) { if (valid) OFL_ROWS_S(T_, 2, true, 1); else OFL_ROWS_S(T_, 2, false, 1); }                \
     else if (nc == 2) { if (valid) OFL_ROWS_S(T_, 2, true, 0); else OFL_ROWS_S(T_, 2, false, 0); }       \
@@ -4228,8 +4233,8 @@ int ofl_wide_launch_rows_h(const void* params, void* stream) {
     constexpr int RT = OFL_ROWS_T;
     const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
     if (!OFL_WARP_ROWS || !warp_is_lean(q) || !q.valid || q.addend || q.dst_flags) return (int)hipErrorInvalidValue;
-    if (q.src_b) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, 0, true, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, 2, true, 0, false, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
+    if (q.src_b) OFL_KLAUNCH((warp_bwd_rows_kernel<RT, 2, true, 0, true, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
+    else OFL_KLAUNCH((warp_bwd_rows_kernel<RT, 2, true, 0, false, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
 // the gradient with respect to the flow (ofl_warp_bwd_grad_f32), large launches with W % 4 == 0: the row-table kernel
@@ -4240,7 +4245,7 @@ int ofl_wide_launch_rows_grad(const void* params, int nc, int tiles, void* strea
     const int tt = tiles == 1 ? 1 : (tiles == 2 ? 2 : RT);
     const unsigned gr = warp_geometry(q, kLdsTWQ * 4, tt * kLdsTH);
     if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.valid || q.src_b || q.dst_flags) return (int)hipErrorInvalidValue;
-#define OFL_ROWS_G(T_, NC) hipLaunchKernelGGL((warp_bwd_rows_kernel<T_, NC, false, 0, false, false, float, float, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
+#define OFL_ROWS_G(T_, NC) OFL_KLAUNCH((warp_bwd_rows_kernel<T_, NC, false, 0, false, false, float, float, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
 #define OFL_ROWS_GT(T_) switch (nc) { case 1: OFL_ROWS_G(T_, 1); break; case 2: OFL_ROWS_G(T_, 2); break; default: OFL_ROWS_G(T_, 3); break; }
     if (tt == 1) { OFL_ROWS_GT(1) } else if (tt == 2) { OFL_ROWS_GT(2) } else { OFL_ROWS_GT(RT) }
 #undef OFL_ROWS_GT
@@ -4254,7 +4259,7 @@ int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* str
     constexpr int RT = OFL_ROWS_T;
     const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
     if (!OFL_WARP_ROWS || (q.w & 3) != 0 || q.flow_flags || q.addend || q.src_b || q.dst_flags || !(nc == 1 || nc == 3)) return (int)hipErrorInvalidValue;
-#define OFL_ROWS_U8(NC, V, TD) hipLaunchKernelGGL((warp_bwd_rows_kernel<RT, NC, V, 0, false, false, uint8_t, TD, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
+#define OFL_ROWS_U8(NC, V, TD) OFL_KLAUNCH((warp_bwd_rows_kernel<RT, NC, V, 0, false, false, uint8_t, TD, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
     if (dst_is_u8) {
         if (nc == 1) { if (q.valid) OFL_ROWS_U8(1, true, uint8_t); else OFL_ROWS_U8(1, false, uint8_t); }
         else { if (q.valid) OFL_ROWS_U8(3, true, uint8_t); else OFL_ROWS_U8(3, false, uint8_t); }
@@ -4282,24 +4287,24 @@ int ofl_wide_launch_chan(const void* params, int valid, int rows, void* stream) 
             attr_set = true;
         }
         if (warp_is_lean(q3)) {
-            if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
-            else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
-        } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, false, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
-        else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, false, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+            if (valid) OFL_KLAUNCH((warp_bwd_lds_chan_kernel<true, true, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+            else OFL_KLAUNCH((warp_bwd_lds_chan_kernel<false, true, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+        } else if (valid) OFL_KLAUNCH((warp_bwd_lds_chan_kernel<true, false, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
+        else OFL_KLAUNCH((warp_bwd_lds_chan_kernel<false, false, S>), dim3(g3), dim3(kLdsNT * S), S * kLdsBytes, (hipStream_t)stream, q3);
         return (int)hipGetLastError();
     }
 #endif
     const unsigned g1 = warp_geometry(q, kLdsTWQ * 4, kLdsTH);
     if (OFL_WARP_ROWS && OFL_WARP_CHAN_SUBS == 1 && rows && warp_is_lean(q)) {
-        if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true, 1, true>), dim3(g1), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
-        else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true, 1, true>), dim3(g1), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_lds_chan_kernel<true, true, 1, true>), dim3(g1), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
+        else OFL_KLAUNCH((warp_bwd_lds_chan_kernel<false, true, 1, true>), dim3(g1), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
         return (int)hipGetLastError();
     }
     if (warp_is_lean(q)) {
-        if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
-        else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
-    } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
-    else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+        else OFL_KLAUNCH((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+    } else if (valid) OFL_KLAUNCH((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
+    else OFL_KLAUNCH((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
 #else
@@ -4320,12 +4325,12 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
             constexpr int TT = kLdsT > 2 ? kLdsT : 3;
             if (gc >= 6912u) {
                 if (OFL_WARP_ROWS_FLOWOPS && warp_is_lean(q) && g_warp_path != 6) return ofl_wide_launch_column(&p, 2, 1, 0, 1, (void*)st);   // 64 x 16 tiles, per-row extents
-                if (warp_is_lean(q)) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2, float, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
-                else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                if (warp_is_lean(q)) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2, float, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, NC == 2>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
                 return (int)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+        OFL_KLAUNCH((warp_bwd_lds_kernel<NC, true, false, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         return (int)hipGetLastError();
     }
     if (NC == 2 && p.dst_flags) {                          // (host: only with a valid mask)
@@ -4333,8 +4338,8 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
             WarpParams q = p;
             if (warp_is_lean(q) && warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) >= 6912u) return ofl_wide_launch_column(&p, 2, 1, add ? 1 : 0, 1, (void*)st);
         }
-        if (add) hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, true, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
-        else hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+        if (add) OFL_KLAUNCH((warp_bwd_lds_kernel<NC, true, true, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+        else OFL_KLAUNCH((warp_bwd_lds_kernel<NC, true, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         return (int)hipGetLastError();
     }
     // (the fused composition -- ADD -- keeps the pair kernel: as a column its re-used flow registers spill, 1.03 instead of 0.92 ms)
@@ -4351,19 +4356,19 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         }
         if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
             if (warp_is_lean(q)) {
-                if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-                else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-            } else if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+                if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+                else OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            } else if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            else OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, false, true, false, false, float, float, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
             return (int)hipGetLastError();
         }
         if (warp_is_lean(q)) {                     // (the addend is another flow: the outer `flow - (...)` of modes 1-2, Flow.combine's cells)
-            if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+            else OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true, false, false, float, float, false, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
             return (int)hipGetLastError();
         }
-        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
     }
     // a plain warp (Flow.apply 't' of an image or a flow): columns of kLdsT tiles -- unless the launch is SMALL: a column block
@@ -4387,14 +4392,14 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         }
         if (g_warp_path == 4 || (g_warp_path != 3 && g1 < kColumnMinGroups)) {
             if (warp_is_lean(q1) && valid) {            // (the lean twins of the two instantiations with a valid mask: BASELINE configs[1] is one of them)
-                if (add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, true, false, false, float, float, false, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
-                else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, false, false, false, float, float, false, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+                if (add) OFL_KLAUNCH((warp_bwd_lds_column_kernel<1, NC, true, true, false, false, float, float, false, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+                else OFL_KLAUNCH((warp_bwd_lds_column_kernel<1, NC, true, false, false, false, float, float, false, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
                 return (int)hipGetLastError();
             }
-            if (valid && add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
-            else if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, true, false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
-            else if (add) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
-            else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<1, NC, false, false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            if (valid && add) OFL_KLAUNCH((warp_bwd_lds_column_kernel<1, NC, true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            else if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<1, NC, true, false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            else if (add) OFL_KLAUNCH((warp_bwd_lds_column_kernel<1, NC, false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
+            else OFL_KLAUNCH((warp_bwd_lds_column_kernel<1, NC, false, false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q1);
             return (int)hipGetLastError();
         }
     }
@@ -4402,13 +4407,13 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
     const unsigned g = (kLdsT > 2 && !add && !p.flow_flags) ? warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH) : 0u;
     if (g >= kColumnMinGroups && g_warp_path != 3) {
         if (OFL_WARP_WIDE) return ofl_wide_launch_column(&p, NC, valid ? 1 : 0, 0, g_warp_path != 6, (void*)st);    // 64 x 16 tiles: -1.9 % (see kLdsNT)
-        if (valid) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
-        else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
+        else OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, false>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
     }
 #define OFL_LAUNCH_L(V, A)                                                                                       \
     if (valid == V && add == A) {                                                                                \
-        hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, V, A>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);          \
+        OFL_KLAUNCH((warp_bwd_lds_kernel<NC, V, A>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);          \
         return (int)hipGetLastError();                                                                           \
     }
     OFL_LAUNCH_L(false, false) OFL_LAUNCH_L(true, false) OFL_LAUNCH_L(false, true) OFL_LAUNCH_L(true, true)
@@ -4419,8 +4424,8 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
 // 8-bit images: uint8 source planes, float or uint8 destination (no addend, no flag words)
 template <int NC, typename TD>
 int launch_warp_lds_u8(const WarpParams& p, unsigned grid, hipStream_t st) {
-    if (p.valid) hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, true, false, false, false, uint8_t, TD>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
-    else hipLaunchKernelGGL((warp_bwd_lds_kernel<NC, false, false, false, false, uint8_t, TD>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+    if (p.valid) OFL_KLAUNCH((warp_bwd_lds_kernel<NC, true, false, false, false, uint8_t, TD>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
+    else OFL_KLAUNCH((warp_bwd_lds_kernel<NC, false, false, false, false, uint8_t, TD>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
     return (int)hipGetLastError();
 }
 
@@ -4446,18 +4451,18 @@ void launch_flow_flags(const float* flow, int64_t flow_bs, const uint8_t* mask, 
         fh.total_blocks = (int32_t)(bx * n);
         const bool nt = 9 * hw * n >= ((int64_t)256 << 20);
         if (fhp) {
-            if (nt) hipLaunchKernelGGL((flow_flags_kernel<true, true, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
-            else hipLaunchKernelGGL((flow_flags_kernel<true, false, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+            if (nt) OFL_KLAUNCH((flow_flags_kernel<true, true, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+            else OFL_KLAUNCH((flow_flags_kernel<true, false, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
         } else {
-            if (nt) hipLaunchKernelGGL((flow_flags_kernel<true, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
-            else hipLaunchKernelGGL((flow_flags_kernel<true, false>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+            if (nt) OFL_KLAUNCH((flow_flags_kernel<true, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+            else OFL_KLAUNCH((flow_flags_kernel<true, false>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
         }
     } else {
         int64_t bx = (hw + 255) / 256;
         if (bx > 512) bx = 512;
         fh.total_blocks = (int32_t)(bx * n);
-        if (fhp) hipLaunchKernelGGL((flow_flags_kernel<false, false, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
-        else hipLaunchKernelGGL((flow_flags_kernel<false>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+        if (fhp) OFL_KLAUNCH((flow_flags_kernel<false, false, true>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
+        else OFL_KLAUNCH((flow_flags_kernel<false>), dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, flow, flow_bs, mask, mask_bs, flags, hw, fh);
     }
 }
 
@@ -4466,7 +4471,7 @@ int launch_warp(const WarpParams& p, unsigned grid, hipStream_t st) {
     const bool valid = p.valid != nullptr, add = p.addend != nullptr, flags = p.flow_flags != nullptr;
 #define OFL_LAUNCH_W(V, A, F)                                                                  \
     if (valid == V && add == A && flags == F) {                                                \
-        hipLaunchKernelGGL((warp_bwd_kernel<CT, V, A, F>), dim3(grid), dim3(256), 0, st, p);    \
+        OFL_KLAUNCH((warp_bwd_kernel<CT, V, A, F>), dim3(grid), dim3(256), 0, st, p);    \
         return (int)hipGetLastError();                                                         \
     }
     OFL_LAUNCH_W(false, false, false) OFL_LAUNCH_W(true, false, false)
@@ -4506,8 +4511,8 @@ template <int NC, bool MCH, typename TF = float, typename TO = float>
 int launch_splat_gather2(const GatherParams& gp, unsigned grid, hipStream_t st) {
     // round 6: the diet kernel (3 blocks per CU) unless the tests / an A-B ask for round 5's (32-byte records, 2 blocks per CU)
     if (g_splat_path != 1) return ofl_splat_launch_gather_diet(&gp, NC, MCH ? 1 : 0, std::is_same<TF, float>::value ? 0 : (std::is_same<TO, float>::value ? 1 : 2), grid, (void*)st, g_splat_extra_lds);
-    if (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp.s)) hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
-    else hipLaunchKernelGGL((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    if (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp.s)) OFL_KLAUNCH((splat_gather_kernel<NC, MCH, TF, TO, (NC >= 2)>), dim3(grid), dim3(kSpNT2), 0, st, gp);
+    else OFL_KLAUNCH((splat_gather_kernel<NC, MCH, TF, TO>), dim3(grid), dim3(kSpNT2), 0, st, gp);
     return (int)hipGetLastError();
 }
 
@@ -4553,9 +4558,9 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
         }
     }
     switch (c) {
-        case 1: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 1, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
-        case 2: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
-        default: hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 3, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
+        case 1: OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 1, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
+        case 2: OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
+        default: OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 3, false, false, false, false, float, float, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p); break;
     }
     return (int)hipGetLastError();
 }
@@ -4564,6 +4569,13 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+}  // extern "C"
+const void* g_ofl_last_kernel = nullptr;
+extern "C" {
+__attribute__((visibility("default"))) const char* ofl_last_kernel_name(void) {
+    return g_ofl_last_kernel ? hipKernelNameRefByPtr(g_ofl_last_kernel, nullptr) : "";
+}
 
 __attribute__((visibility("default"))) int ofl_version(void) { return 33; }   // 33: the gather splat's diet kernel (ofl_splat_gather.hip), OFL_OPT_SPLAT_PATH / OFL_OPT_SPLAT_EXTRA_LDS, ofl_splat_gather_info; 32: OFL_OPT_WARP_PATH value 7 (four-tile row-table columns whatever the size); row tables for small launches, the other flow-level warps, fp16 / uint8 sources, the gradient-wrt-flow pass; 31: OFL_OPT_WARP_PATH value 6 (the sheared rectangle instead of per-row extents: warp_bwd_rows_kernel is the default for large lean launches); 30: OFL_OPT_WARP_PATH value 5 (more than 3 channels as launches of 3; the default is ONE launch that loops over the channels); 29: ofl_splat_tile_geometry (64 x 16 destination tiles); 28: ofl_resize_bilinear_f32; 27: ofl_warp_valid_f32 (ofl_aux_kernels.hip); 26: bounded fallback accumulator of the gather splat (ofl_splat_tiled_fallback_images); 25: ofl_flow_flags_host with sharded arrival counters and {serial, word} pairs, ofl_flow_from_matrix_f32; 24: ofl_flow_flags_host (+ ofl_host_words_alloc / _free); 23: scratch argument of ofl_splat_grad_f32; 22: ofl_splat_sum_f32; 21: ofl_flag_words_or_i32, splat workspace without the fold-tile list; 20: fp16-stored flows read directly (ofl_splat_tiled_f16, ofl_warp_bwd_h_f32, flags-only ofl_flow_from_f16); 19: gather-formulation splat (workspace layout), ofl_warp_bwd_win_f32 / ofl_splat_tiled_win_f32 (padded apply); 18: ofl_aux_kernels.hip (backward passes, point sampler, extents); 13: dst_flags in ofl_warp_bwd_f32 / ofl_splat_tiled_f32, fixed-address splat queues; 14: data_b; 15: src_b; 16: ofl_warp_bwd_u8; 17: ofl_flow_from_f16
 
@@ -4637,10 +4649,10 @@ static int warp_bwd_impl(
             const bool rows_chan = OFL_WARP_ROWS && g_warp_path != 6 && c >= 7 && warp_is_lean(q);
             if (OFL_WARP_CHAN_WIDE && (g1 >= OFL_WARP_CHAN_WIDE_MIN || rows_chan)) return ofl_wide_launch_chan(&p, p.valid ? 1 : 0, rows_chan ? 1 : 0, (void*)st);   // (row extents from two channel groups on: with one group their set-up is not amortised -- C = 4: 0.148 against 0.138 ms)
             if (warp_is_lean(q)) {
-                if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
-                else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
-            } else if (q.valid) hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
-            else hipLaunchKernelGGL((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+                if (q.valid) OFL_KLAUNCH((warp_bwd_lds_chan_kernel<true, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+                else OFL_KLAUNCH((warp_bwd_lds_chan_kernel<false, true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+            } else if (q.valid) OFL_KLAUNCH((warp_bwd_lds_chan_kernel<true>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
+            else OFL_KLAUNCH((warp_bwd_lds_chan_kernel<false>), dim3(g1), dim3(kLdsNT), kLdsBytes, st, q);
             return (int)hipGetLastError();
         }
         // otherwise groups of 3 (the staged box holds 3 channels + the mask channel); the valid mask and the
@@ -4785,16 +4797,16 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_h_f32(
         if (gc >= 6912u) {
             const bool lean = warp_is_lean(q);
             if (OFL_WARP_ROWS_FLOWOPS && lean && g_warp_path != 6) return ofl_wide_launch_rows_h(&p, stream);      // 64 x 16 tiles, per-row extents
-            if (src_b) { if (lean) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
-                         else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
-            else { if (lean) hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
-                   else hipLaunchKernelGGL((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
+            if (src_b) { if (lean) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                         else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
+            else { if (lean) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
+                   else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
             return (int)hipGetLastError();
         }
     }
     const unsigned g = warp_geometry(p, kLdsTWQ * 4, 2 * kLdsTH);
-    if (src_b) hipLaunchKernelGGL((warp_bwd_lds_kernel<2, true, false, false, true, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
-    else hipLaunchKernelGGL((warp_bwd_lds_kernel<2, true, false, false, false, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
+    if (src_b) OFL_KLAUNCH((warp_bwd_lds_kernel<2, true, false, false, true, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
+    else OFL_KLAUNCH((warp_bwd_lds_kernel<2, true, false, false, false, _Float16, float>), dim3(g), dim3(kLdsNT), kLdsBytes, st, p);
     return (int)hipGetLastError();
 }
 
@@ -4836,11 +4848,11 @@ __attribute__((visibility("default"))) int ofl_splat_fwd_f32(
     p.flow_sign = flow_sign; p.xs = xs; p.ys = ys; p.xy_bs = xy_bs; p.accum = accum;
     hipStream_t st = (hipStream_t)stream;
     switch (c) {
-        case 1: hipLaunchKernelGGL(splat_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(splat_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL(splat_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
-        case 4: hipLaunchKernelGGL(splat_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL(splat_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, p); break;
+        case 1: OFL_KLAUNCH(splat_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+        case 2: OFL_KLAUNCH(splat_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+        case 3: OFL_KLAUNCH(splat_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+        case 4: OFL_KLAUNCH(splat_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+        default: OFL_KLAUNCH(splat_fwd_kernel<0>, dim3(grid), dim3(256), 0, st, p); break;
     }
     return (int)hipGetLastError();
 }
@@ -4864,11 +4876,11 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
     p.round_mode = round_mode;
     hipStream_t st = (hipStream_t)stream;
     switch (c) {
-        case 1: hipLaunchKernelGGL(splat_finalize_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL(splat_finalize_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL(splat_finalize_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
-        case 4: hipLaunchKernelGGL(splat_finalize_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
-        default: hipLaunchKernelGGL(splat_finalize_kernel<0>, dim3(grid), dim3(256), 0, st, p); break;
+        case 1: OFL_KLAUNCH(splat_finalize_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+        case 2: OFL_KLAUNCH(splat_finalize_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+        case 3: OFL_KLAUNCH(splat_finalize_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+        case 4: OFL_KLAUNCH(splat_finalize_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+        default: OFL_KLAUNCH(splat_finalize_kernel<0>, dim3(grid), dim3(256), 0, st, p); break;
     }
     return (int)hipGetLastError();
 }
@@ -5012,10 +5024,10 @@ static int splat_tiled_impl(
                     : hipMemsetAsync(gp.redo_cnt, 0, (2 + zwords) * sizeof(int32_t), st);  // (the redo list's length sits right before the flags)
         if (e != hipSuccess) return (int)e;
         const bool lean = splat_is_lean(gp.s);
-        if (half_in) { if (lean) hipLaunchKernelGGL((splat_bin_kernel<_Float16, true>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
-                       else hipLaunchKernelGGL((splat_bin_kernel<_Float16>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp); }
-        else { if (lean) hipLaunchKernelGGL((splat_bin_kernel<float, true>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
-               else hipLaunchKernelGGL((splat_bin_kernel<float>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp); }
+        if (half_in) { if (lean) OFL_KLAUNCH((splat_bin_kernel<_Float16, true>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
+                       else OFL_KLAUNCH((splat_bin_kernel<_Float16>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp); }
+        else { if (lean) OFL_KLAUNCH((splat_bin_kernel<float, true>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp);
+               else OFL_KLAUNCH((splat_bin_kernel<float>), dim3((unsigned)(gp.rper_xcd * kXcds)), dim3(256), 0, st, gp); }
         rc = (int)hipGetLastError();
         if (rc) return rc;
         // more than 3 channels: groups of 3 (a record holds 3 data channels); density and masks come out of the first group
@@ -5064,12 +5076,12 @@ static int splat_tiled_impl(
                 int32_t* arrivals = gp.stats + 4;           // two words, zeroed with the statistics words at the start of the call and left zero by every launch
                 const int64_t cpi = (int64_t)planes * hw;
                 if (half_in) {
-                    if (elem == 2) hipLaunchKernelGGL((splat_fallback_kernel<2, _Float16, _Float16>), dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals);
-                    else hipLaunchKernelGGL((splat_fallback_kernel<2, _Float16, float>), dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals);
+                    if (elem == 2) OFL_KLAUNCH((splat_fallback_kernel<2, _Float16, _Float16>), dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals);
+                    else OFL_KLAUNCH((splat_fallback_kernel<2, _Float16, float>), dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals);
                 } else switch (cg) {
-                    case 1: hipLaunchKernelGGL(splat_fallback_kernel<1>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
-                    case 2: hipLaunchKernelGGL(splat_fallback_kernel<2>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
-                    default: hipLaunchKernelGGL(splat_fallback_kernel<3>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
+                    case 1: OFL_KLAUNCH(splat_fallback_kernel<1>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
+                    case 2: OFL_KLAUNCH(splat_fallback_kernel<2>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
+                    default: OFL_KLAUNCH(splat_fallback_kernel<3>, dim3(g2), dim3(256), 0, st, fb, accum_fallback, cpi, (int32_t)nn, arrivals); break;
                 }
             }
         }
@@ -5163,7 +5175,7 @@ __attribute__((visibility("default"))) int ofl_flow_from_f16(const void* src_f16
     int64_t bx = (hw / 4 + 1023) / 1024, cap = 512 / n;
     cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(flow_f16_kernel<false>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+    OFL_KLAUNCH(flow_f16_kernel<false>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
                        static_cast<const _Float16*>(src_f16), src_bs, mask, mask_bs, dst, flags, hw, FlagsHost{});
     return (int)hipGetLastError();
 }
@@ -5194,7 +5206,7 @@ __attribute__((visibility("default"))) int ofl_flow_flags_host(const void* flow,
     cap = cap < 16 ? 16 : (cap > 256 ? 256 : cap);
     if (bx > cap) bx = cap;
     fh.total_blocks = (int32_t)(bx * n);
-    hipLaunchKernelGGL(flow_f16_kernel<true>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st,
+    OFL_KLAUNCH(flow_f16_kernel<true>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st,
                        static_cast<const _Float16*>(flow), flow_bs, mask, mask_bs, (float*)nullptr, work, hw, fh);
     return (int)hipGetLastError();
 }

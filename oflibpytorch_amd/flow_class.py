@@ -690,6 +690,13 @@ class Flow(object):
         else:
             warped, valid, dflags = self._warp_padded(t, tmask, need_valid, consider_mask, rm, padding)
 
+        if padding is not None and not cut and need_valid and self._ref == 't' and warped.shape[0] < self.shape[0]:
+            # an all-zero 't' flow of batch N, padded and NOT cut, over a batch-1 target: the reference's mask is still batch 1 (the target
+            # went through apply_flow untouched, utils.py:497-498) when it assigns the batch-N `tmp & self._mask` into its flow-area
+            # window (flow_class.py:929-932) -- torch refuses, with this message (found by tests/golden/fuzz_vs_reference.py)
+            raise RuntimeError("The expanded size of the tensor (%d) must match the existing size (%d) at non-singleton dimension 0.  "
+                               "Target sizes: [%d, %d, %d].  Tensor sizes: [%d, %d, %d]"
+                               % (warped.shape[0], self.shape[0], warped.shape[0], self.shape[1], self.shape[2], self.shape[0], self.shape[1], self.shape[2]))
         if padding is not None and cut:
             win = (slice(padding[0], padding[0] + self.shape[1]), slice(padding[2], padding[2] + self.shape[2]))
             warped = warped[..., win[0], win[1]]
@@ -698,6 +705,11 @@ class Flow(object):
             dflags = None                                # (they describe the whole padded frame)
 
         if return_flow:
+            if valid is not None and valid.shape[0] != warped.shape[0]:
+                # an all-zero 't' flow of batch N over a batch-1 Flow target: apply_flow hands the batch-1 target through
+                # (utils.py:497-498) while the mask is ANDed with this flow's N masks (:934) -- the reference's Flow(...) of the two
+                # (:938) then fails in its mask setter, with this message (found by tests/golden/fuzz_vs_reference.py)
+                raise ValueError("Error setting flow mask: Input shape does not match the desired shape")
             return Flow._wrap(warped, target._ref, valid, self._device, flags=dflags, made_from=(t, tmask, self._mask))
         if not return_dtype.is_floating_point:
             if not get_pure_pytorch():
@@ -715,6 +727,13 @@ class Flow(object):
         `ofl_splat_tiled_win_f32`): no padded copy of the flow or its mask is made.  The all-zero early exit, narrow frames
         the gather kernels do not take, and tensors that want a gradient go through the padded copy (rare / plumbing)."""
         window = (padding[0], padding[2])
+        # The reference's padded 's' branch walks the TARGET's batch (flow_class.py:884-894: `for i in range(mask.shape[0])`): with a
+        # batch-1 target under a batch-N flow it ANDs element 0's flow mask -- and only that one -- into the mask channel, which every
+        # element of the flow then warps; and because `mask` keeps batch 1 the target is not expanded (:896-897), so an all-zero flow
+        # hands the batch-1 target (and that batch-1 mask) straight through (utils.py:497-498).  Reproduced: results are what the
+        # reference returns on the same inputs, quirk included (fixtures tests/golden/padbc.npz).
+        quirk = self._ref == 's' and need_valid and t.shape[0] < self.shape[0]
+        chan_b = self._mask if not quirk else self.mask[:1]
         direct = not self._all_zero(_native.FLAG_NZ_THR) and \
             not _native._wants_grad(self._vecs, t) and (self._ref == 't' or get_pure_pytorch())
         if direct:
@@ -725,24 +744,27 @@ class Flow(object):
                                                      round_mode=round_mode)
                 return warped.to(self._device), (None if valid is None else valid.to(self._device)), None
             res = _native.splat_fwd_win(self._vecs, t, window, weight_mask=self.mask if consider_mask else None,
-                                        chan_mask_a=tmask, chan_mask_b=self._mask, want_valid=need_valid, occlude=True,
+                                        chan_mask_a=tmask, chan_mask_b=chan_b, want_valid=need_valid, occlude=True,
                                         round_mode=round_mode)
             if res is not None:
                 return res[0].to(self._device), (None if res[1] is None else res[1].to(self._device)), None
         # 't': zero padding is irrelevant outside the flow area; 's': replicate avoids artefacts at the border of the flow area
         # (flow_class.py:906-913).  The padded mask is False, so the un-padded formulas hold for the padded flow as they stand.
         flow = self.pad(padding, mode='constant' if self._ref == 't' else 'replicate')
+        if quirk:
+            return flow._warp(t, tmask, need_valid, consider_mask, round_mode, mask_chan_b=flow.mask[:1])
         return flow._warp(t, tmask, need_valid, consider_mask, round_mode)
 
     def _warp(self, t: torch.Tensor, tmask, need_valid: bool, consider_mask: bool, round_mode: int = 0,
-              flow_sign: float = 1.0, data_sign: float = 1.0, t_minus: torch.Tensor = None):
+              flow_sign: float = 1.0, data_sign: float = 1.0, t_minus: torch.Tensor = None, mask_chan_b: torch.Tensor = None):
         """Core of `apply`: t [Nt,C,H,W] any dtype, tmask [Nt,H,W] bool or None (all True).
         Returns (warped fp32 [N,C,H,W], valid bool [N,H,W] | None) on self.device.
         `flow_sign` / `data_sign` = -1 (forward flows only) restate `(-self)` as the warper / `-t` as the target inside the
         kernel (exact negations; finiteness and zero tests do not depend on the sign), so that switch_ref / invert need
         no negated copy and no second flag reduction.  `t_minus` (past the early exit only): the target is t - t_minus,
         subtracted inside the kernel (modes 1 't' / 2 's': target `flow - self`; `tmask` / the two channel masks carry
-        m_flow & m_self)."""
+        m_flow & m_self).  `mask_chan_b` ('s' only; the padded batch-1-target case of `_warp_padded`): the batch-1 flow mask
+        that goes into the mask channel instead of this flow's own, and keeps an all-zero flow's result at batch 1."""
         if self._ref == 's' and not get_pure_pytorch():
             _griddata_unavailable("Flow.apply(ref='s')")
         batch_flags = self._batch_flags()                                             # (one look at the cached word for both tests)
@@ -758,7 +780,9 @@ class Flow(object):
             if need_valid:
                 valid = torch.ones((t.shape[0],) + tuple(t.shape[2:]), dtype=torch.bool, device=self._device) \
                     if tmask is None else tmask.to(self._device)
-                if self._ref == 's':                                  # mask & self._mask before the warp (:895)
+                if self._ref == 's' and mask_chan_b is not None:      # padded, batch-1 target: element 0's mask only, batch stays 1 (:884-897)
+                    valid = valid & mask_chan_b.to(self._device)
+                elif self._ref == 's':                                # mask & self._mask before the warp (:895)
                     valid = valid & self.mask if self._mask is not None or valid.shape[0] < self.shape[0] else valid
                 if valid.shape[0] != warped.shape[0]:                 # :896-897
                     warped = warped.expand(valid.shape[0], -1, -1, -1)
@@ -780,7 +804,7 @@ class Flow(object):
             # by-product, so that using the result as a warper needs no validation pass of its own
             want_f = need_valid and t.shape[1] == 2 and round_mode == 0
             res = _native.splat_fwd(self._fv, t, weight_mask=self._mask if consider_mask else None,
-                                    chan_mask_a=tmask, chan_mask_b=self._mask,
+                                    chan_mask_a=tmask, chan_mask_b=self._mask if mask_chan_b is None else mask_chan_b,
                                     want_valid=need_valid, occlude=True, round_mode=round_mode,
                                     flow_sign=flow_sign, data_sign=data_sign, want_dst_flags=want_f, data_b=t_minus,
                                     out_half=get_half_flow_outputs())

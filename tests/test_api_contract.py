@@ -226,3 +226,25 @@ def test_writes_torch_cannot_see_invalidate_and_revalidate_every_call():
     # signatures of the wrapped public methods still read as the reference's (the wrapper is transparent to inspect)
     import inspect
     assert list(inspect.signature(Flow.apply).parameters) == ['self', 'target', 'target_mask', 'return_valid_area', 'consider_mask', 'padding', 'cut']
+
+
+def test_reference_failures_found_by_the_differential_fuzzer_are_reproduced():
+    """tests/golden/fuzz_vs_reference.py (round 6: 5 500 random API calls against the imported reference) found two corners where the
+    REFERENCE raises and this package used to return a result; both are an all-zero 't' flow of batch N over a batch-1 target, whose
+    early exit hands the batch-1 target through (utils.py:497-498) into code that expects batch N."""
+    h, w = 9, 11
+    z3 = Flow(torch.zeros(3, 2, h, w), 't', torch.rand(3, h, w, generator=torch.Generator().manual_seed(1)) > 0.2)
+    # (a) a Flow target: Flow(warped[:, :2] (batch 1), ref, mask (batch 3)) fails in the mask setter (flow_class.py:934-938)
+    tgt = Flow(torch.rand(1, 2, h, w, generator=torch.Generator().manual_seed(2)), 's')
+    with pytest.raises(ValueError, match="Error setting flow mask: Input shape does not match the desired shape"):
+        z3.apply(tgt)
+    # ... while a non-zero flow broadcasts as usual
+    nz3 = Flow(torch.rand(3, 2, h, w, generator=torch.Generator().manual_seed(3)) * 3, 't')
+    assert nz3.apply(tgt).shape == (3, h, w)
+    # (b) padded, not cut, valid area wanted: the batch-1 mask is assigned a batch-3 value (flow_class.py:929-932)
+    pad = [1, 2, 0, 2]
+    img = torch.rand(1, 2, h + 3, w + 2, generator=torch.Generator().manual_seed(4))
+    with pytest.raises(RuntimeError, match=r"The expanded size of the tensor \(1\) must match the existing size \(3\)"):
+        z3.apply(img, return_valid_area=True, padding=pad, cut=False)
+    out, valid = z3.apply(img, return_valid_area=True, padding=pad, cut=True)     # cut: no assignment, the reference returns batch 1 / batch 3
+    assert out.shape[0] == 1 and valid.shape[0] == 3

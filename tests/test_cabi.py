@@ -20,7 +20,7 @@ def test_library_builds_and_loads():
 
 def test_header_and_library_agree_on_symbols():
     header = open(os.path.join(ROOT, 'include', 'oflib_hip.h')).read()
-    declared = set(re.findall(r'^(?:int|int64_t) (ofl_\w+)\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|int64_t|const char\*) (ofl_\w+)\(', header, flags=re.M))
     assert declared == set(_native.exported_symbols())
     lib = ctypes.CDLL(_build.LIB_PATH)
     for name in declared:

@@ -297,6 +297,29 @@ def test_bench_runs_under_torch_distributed_run_with_one_rank(dev):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["launcher"] == "torch.distributed (nccl)"
 
 
+def test_bench_starts_its_own_ranks_when_not_under_a_launcher(dev):
+    """plain `python bench.py --gpus N` (no RANK in the environment) must start its ranks itself -- fresh child processes
+    through torch.distributed.run, before the parent touches the GPU -- and relay rank 0's line.  One GPU here: `--self-launch`
+    takes the same path at N = 1 (N > 1 takes it by itself); the line must say so, carry the communicator size seen inside the timed
+    region and the kernel the launcher really picked."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--self-launch", "--steps", "3", "--warmup", "1", "--batch", "4",
+           "--no-cpu-baseline", "--no-probe", "--no-secondary", "--blocks", "1", "--n1-ms", "1.0"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    import json
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # exactly ONE JSON line reaches the caller
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["launcher"] == "torch.distributed (nccl)"
+    assert out["rccl_ranks"] == 1 and out["speedup_vs_n1"] > 0
+    assert "warp_bwd" in out["roofline"]["kernel"] and "warp_bwd" in out["kernels"]["combine3_kernel"]
+    # a child that fails must fail the parent, with the child's stderr
+    bad = subprocess.run(cmd + ["--height", "-5"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and "failed with exit code" in bad.stderr
+
+
 def test_bench_shared_image_and_ragged_strong_scaling_under_torch_distributed_run(dev):
     """`bench.py --shared-image` drives the reference's 1 <-> N broadcast case (utils.py:527-537; flow_class.py:896-897)
     through the only data-path collective the path has -- a B = 1 image + target mask broadcast from rank 0 (RCCL, forced on at one
