@@ -38,25 +38,40 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # gather kernel has 16 instantiations), then linked
     import tempfile
     compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    # (the link line is derived from the same list: what is not a code-generation or language option of the compile step)
+    link_flags = [f for f in HIPCC_FLAGS if f.startswith("--offload-arch") or f in ("-shared", "-fPIC", "-fvisibility=hidden")]
     with tempfile.TemporaryDirectory(prefix="ofl_build_") as tmp:
         objs, procs = [], []
-        for src in SOURCES:
-            obj = os.path.join(tmp, os.path.splitext(os.path.basename(src))[0] + ".o")
-            cmd = [hipcc_path()] + compile_flags + ["-I", os.path.join(_ROOT, "include"), "-c", "-o", obj, src]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            objs.append(obj)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-        for src, pr in procs:
-            out, err = pr.communicate()
-            if pr.returncode != 0:
-                raise RuntimeError("oflibpytorch_amd: hipcc failed on %s\n%s%s" % (src, out, err))
-        link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", LIB_PATH] + objs
+        try:
+            for src in SOURCES:
+                obj = os.path.join(tmp, os.path.splitext(os.path.basename(src))[0] + ".o")
+                cmd = [hipcc_path()] + compile_flags + ["-I", os.path.join(_ROOT, "include"), "-c", "-o", obj, src]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                objs.append(obj)
+                procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+            for src, pr in procs:
+                out, err = pr.communicate()
+                if pr.returncode != 0:
+                    raise RuntimeError("oflibpytorch_amd: hipcc failed on %s\n%s%s" % (src, out, err))
+        finally:
+            # a failed translation unit must not leave its siblings writing into a directory that is being deleted
+            for _, pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                    pr.communicate()
+        # linked next to the library and moved over it in ONE step: ranks that start together with a stale library may each rebuild
+        # it, but none of them ever dlopens a half-written file (os.replace is atomic within a directory)
+        tmp_lib = "%s.%d.tmp" % (LIB_PATH, os.getpid())
+        link = [hipcc_path()] + link_flags + ["-o", tmp_lib] + objs
         if verbose:
             print(" ".join(link), flush=True)
         res = subprocess.run(link, capture_output=True, text=True)
         if res.returncode != 0:
+            if os.path.exists(tmp_lib):
+                os.remove(tmp_lib)
             raise RuntimeError("oflibpytorch_amd: hipcc (link) failed\n" + res.stdout + res.stderr)
+        os.replace(tmp_lib, LIB_PATH)
     return LIB_PATH
 
 

@@ -1084,6 +1084,8 @@ __global__ __launch_bounds__(kLdsNT, 3) void warp_bwd_lds_column_kernel(const Wa
 #endif
 constexpr int kRowChunks = kLdsIters * kLdsNT - 16;             // chunks (4 pixels, one 16-byte slot each) a block stages per tile (3 blocks per CU: 53.3 KB with the tables below)
 constexpr int kRowsLdsBytes = 16 * (2 + 4 * kRowChunks);        // slot 0 (zeros: invalid taps) + the packed rows + a spare slot (rows_extra)
+static_assert(kRowChunks % 4 == 0, "clear_starts zeroes the chunk map a dword at a time");
+static_assert(16 * (1 + 4 * kRowChunks + 128 + 256) < 65536, "a row entry packs a biased byte address and 16 x length in 16 bits each");
 constexpr int kRowMargin = 8;
 struct RowTabs { int tmin[2][kRowTab + 1]; int tmax[2][kRowTab + 1]; uint32_t ent[2][kRowTab]; uint8_t start[2][kRowChunks]; };   // ([kRowTab]: "a post was dropped"; start[i]: 1 + the row whose first chunk is chunk i, else 0)
 struct RowGeo { int org, cxo, tot; bool interior; };            // wave-uniform
@@ -1232,6 +1234,7 @@ __device__ __forceinline__ void rows_map(const WP& p, const RowGeo& G, const Row
 
 // the first kRowIters * kLdsNT chunks are staged through registers, in flight while the previous tile is gathered ...
 constexpr int kRowIters = 2;
+static_assert(kRowChunks <= (kRowIters + 1) * kLdsNT, "rows_extra stages exactly ONE round beyond the kRowIters rounds that go through registers");
 template <int NC> struct RowStage { int slot[kRowIters]; f4 q[kRowIters][NC]; uint32_t mq[kRowIters]; };
 template <int NC, bool VALID, bool SUB = false, typename TS = float, typename WP>
 __device__ __forceinline__ void rows_issue(const WP& p, const TS* __restrict__ sb, const uint8_t* __restrict__ sm, uint32_t hw,
@@ -1550,6 +1553,7 @@ __global__ __launch_bounds__(kLdsNT * SUBS, 3) void warp_bwd_lds_chan_kernel(con
     constexpr int NW = kLdsNT / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     __shared__ int red_all[SUBS][NW][4];
+    static_assert(!ROWS || kLdsNT != 256 || kRowsLdsBytes + (int)sizeof(RowTabs) + (int)sizeof(red_all) <= 53760, "LDS budget of three blocks per CU (ROWS instantiation)");
     int tx, ty, n;
     if (!decode_tile(p, tx, ty, n)) return;
     const int sub = SUBS > 1 ? (int)threadIdx.x / kLdsNT : 0;
@@ -4232,7 +4236,7 @@ int ofl_wide_launch_rows_h(const void* params, void* stream) {
     q.lds_bytes = kLdsBytes;
     constexpr int RT = OFL_ROWS_T;
     const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
-    if (!OFL_WARP_ROWS || !warp_is_lean(q) || !q.valid || q.addend || q.dst_flags) return (int)hipErrorInvalidValue;
+    if (!OFL_WARP_ROWS || !warp_is_lean(q) || !q.valid || q.addend || q.dst_flags) return OFL_E_UNSUPPORTED;     // (not this kernel's launch: the caller takes the column / pair kernel)
     if (q.src_b) OFL_KLAUNCH((warp_bwd_rows_kernel<RT, 2, true, 0, true, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
     else OFL_KLAUNCH((warp_bwd_rows_kernel<RT, 2, true, 0, false, false, _Float16>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q);
     return (int)hipGetLastError();
@@ -4244,7 +4248,7 @@ int ofl_wide_launch_rows_grad(const void* params, int nc, int tiles, void* strea
     constexpr int RT = OFL_ROWS_T;
     const int tt = tiles == 1 ? 1 : (tiles == 2 ? 2 : RT);
     const unsigned gr = warp_geometry(q, kLdsTWQ * 4, tt * kLdsTH);
-    if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.valid || q.src_b || q.dst_flags) return (int)hipErrorInvalidValue;
+    if (!OFL_WARP_ROWS || !warp_is_lean(q) || q.valid || q.src_b || q.dst_flags) return OFL_E_UNSUPPORTED;
 #define OFL_ROWS_G(T_, NC) OFL_KLAUNCH((warp_bwd_rows_kernel<T_, NC, false, 0, false, false, float, float, false, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
 #define OFL_ROWS_GT(T_) switch (nc) { case 1: OFL_ROWS_G(T_, 1); break; case 2: OFL_ROWS_G(T_, 2); break; default: OFL_ROWS_G(T_, 3); break; }
     if (tt == 1) { OFL_ROWS_GT(1) } else if (tt == 2) { OFL_ROWS_GT(2) } else { OFL_ROWS_GT(RT) }
@@ -4258,7 +4262,7 @@ int ofl_wide_launch_rows_u8(const void* params, int nc, int dst_is_u8, void* str
     q.lds_bytes = kLdsBytes;
     constexpr int RT = OFL_ROWS_T;
     const unsigned gr = warp_geometry(q, kLdsTWQ * 4, RT * kLdsTH);
-    if (!OFL_WARP_ROWS || (q.w & 3) != 0 || q.flow_flags || q.addend || q.src_b || q.dst_flags || !(nc == 1 || nc == 3)) return (int)hipErrorInvalidValue;
+    if (!OFL_WARP_ROWS || (q.w & 3) != 0 || q.flow_flags || q.addend || q.src_b || q.dst_flags || !(nc == 1 || nc == 3)) return OFL_E_UNSUPPORTED;
 #define OFL_ROWS_U8(NC, V, TD) OFL_KLAUNCH((warp_bwd_rows_kernel<RT, NC, V, 0, false, false, uint8_t, TD, true>), dim3(gr), dim3(kLdsNT), kRowsLdsBytes, (hipStream_t)stream, q)
     if (dst_is_u8) {
         if (nc == 1) { if (q.valid) OFL_ROWS_U8(1, true, uint8_t); else OFL_ROWS_U8(1, false, uint8_t); }
@@ -4342,7 +4346,8 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         else OFL_KLAUNCH((warp_bwd_lds_kernel<NC, true, false, NC == 2>), dim3(grid), dim3(kLdsNT), kLdsBytes, st, p);
         return (int)hipGetLastError();
     }
-    // (the fused composition -- ADD -- keeps the pair kernel: as a column its re-used flow registers spill, 1.03 instead of 0.92 ms)
+    // the fused composition (an addend): row tables where the launch is lean, else -- large launches only -- the four-tile column kernels
+    // (REUSE / lean twins: no scratch since round 5); small and forced-path launches fall through to the pair / one-tile kernels
     if (OFL_WARP_COL_ADD && kLdsT > 2 && add && NC == 2 && !p.flow_flags) {
         WarpParams q = p;
         const unsigned g = warp_geometry(q, kLdsTWQ * 4, kLdsT * kLdsTH);
@@ -4354,6 +4359,9 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
             WarpParams q1 = p;
             return ofl_wide_launch_rows_small(&p, 2, valid ? 1 : 0, 1, warp_geometry(q1, kLdsTWQ * 4, kLdsTH) < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
         }
+        // the four-tile column kernels below are for LARGE launches on the automatic path (small launches keep the pair /
+        // one-tile kernels further down -- half as many, twice as long blocks lose there -- and OFL_OPT_WARP_PATH 3 / 4 must reach them)
+        if (g >= 6912u && g_warp_path != 3 && g_warp_path != 4) {
         if (OFL_WARP_REUSE && NC == 2 && p.add_is_flow) {
             if (warp_is_lean(q)) {
                 if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), 2, true, true, false, false, float, float, false, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
@@ -4370,6 +4378,7 @@ int launch_warp_lds(const WarpParams& p, unsigned grid, hipStream_t st) {
         if (valid) OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, true, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         else OFL_KLAUNCH((warp_bwd_lds_column_kernel<(kLdsT > 2 ? kLdsT : 3), NC, false, true>), dim3(g), dim3(kLdsNT), kLdsBytes, st, q);
         return (int)hipGetLastError();
+        }
     }
     // a plain warp (Flow.apply 't' of an image or a flow): columns of kLdsT tiles -- unless the launch is SMALL: a column block
     // lives 4 tiles long, and with fewer than ~4.5 blocks per resident slot (256 CUs x 6) the chip idles behind the last
@@ -4551,10 +4560,14 @@ int ofl_internal_warp_grad_flow_lds(const float* flow, int64_t flow_bs, float fl
     const unsigned g = warp_geometry(p, kLdsTWQ * 4, kLdsT * kLdsTH);
     constexpr int TT = kLdsT > 2 ? kLdsT : 3;
     if (OFL_WARP_ROWS_FLOWOPS && warp_is_lean(p) && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) {   // 64 x 16 tiles, per-row extents
-        if (g >= (OFL_WARP_ROWS_SMALL && g_warp_path == 0 ? OFL_ROWS_T4_MIN : 6912u) || g_warp_path == 7) return ofl_wide_launch_rows_grad(&p, c, OFL_ROWS_T, (void*)st);
+        if (g >= (OFL_WARP_ROWS_SMALL && g_warp_path == 0 ? OFL_ROWS_T4_MIN : 6912u) || g_warp_path == 7) {
+            const int rr = ofl_wide_launch_rows_grad(&p, c, OFL_ROWS_T, (void*)st);
+            if (rr != OFL_E_UNSUPPORTED) return rr;
+        }
         if (OFL_WARP_ROWS_SMALL && g_warp_path == 0) {            // small launches (the shapes training runs at): one tile per block for tiny ones, else two
             WarpParams q1 = p;
-            return ofl_wide_launch_rows_grad(&p, c, warp_geometry(q1, kLdsTWQ * 4, kLdsTH) < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
+            const int rr = ofl_wide_launch_rows_grad(&p, c, warp_geometry(q1, kLdsTWQ * 4, kLdsTH) < OFL_ROWS_T1_MAX ? 1 : 2, (void*)st);
+            if (rr != OFL_E_UNSUPPORTED) return rr;
         }
     }
     switch (c) {
@@ -4743,7 +4756,7 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_u8(
         if (c0 > 0) { q.valid = nullptr; q.src_mask = nullptr; }
         if (OFL_WARP_ROWS_FLOWOPS && (nc == 1 || nc == 3) && (w & 3) == 0 && kLdsT > 2 && g_warp_path != 6 && g_warp_path != 3 && g_warp_path != 4) {
             WarpParams qg = q;                           // large launches: 64 x 16 tiles, per-row extents
-            if (warp_geometry(qg, kLdsTWQ * 4, kLdsT * kLdsTH) >= 6912u) { rc = ofl_wide_launch_rows_u8(&q, nc, dst_is_u8, stream); if (rc) return rc; continue; }
+            if (warp_geometry(qg, kLdsTWQ * 4, kLdsT * kLdsTH) >= 6912u) { rc = ofl_wide_launch_rows_u8(&q, nc, dst_is_u8, stream); if (rc == OFL_OK) continue; if (rc != OFL_E_UNSUPPORTED) return rc; }
         }
         if (dst_is_u8) {
             switch (nc) {
@@ -4796,7 +4809,10 @@ __attribute__((visibility("default"))) int ofl_warp_bwd_h_f32(
         constexpr int TT = kLdsT > 2 ? kLdsT : 3;
         if (gc >= 6912u) {
             const bool lean = warp_is_lean(q);
-            if (OFL_WARP_ROWS_FLOWOPS && lean && g_warp_path != 6) return ofl_wide_launch_rows_h(&p, stream);      // 64 x 16 tiles, per-row extents
+            if (OFL_WARP_ROWS_FLOWOPS && lean && g_warp_path != 6) {                                                  // 64 x 16 tiles, per-row extents
+                const int rr = ofl_wide_launch_rows_h(&p, stream);
+                if (rr != OFL_E_UNSUPPORTED) return rr;                                                            // (a launch it declines falls through to the column kernel)
+            }
             if (src_b) { if (lean) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);
                          else OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, true, _Float16, float>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q); }
             else { if (lean) OFL_KLAUNCH((warp_bwd_lds_column_kernel<TT, 2, true, false, false, false, _Float16, float, false, false, true>), dim3(gc), dim3(kLdsNT), kLdsBytes, st, q);

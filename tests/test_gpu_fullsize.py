@@ -54,6 +54,26 @@ def test_combine_mode3_full_frame_bit_exact(frames, dev):
         assert np.array_equal(out.mask.cpu().numpy(), expm), ref
 
 
+def test_configs1_at_its_own_batch_bit_exact(frames, dev):
+    """BASELINE.json configs[1] is B = ONE 1080p frame (only B = 2 was oracle-checked).  4 080 tiles take the
+    one-tile-per-block instantiation of the row-table kernel, B = 2 the two-tiles-per-block one: Flow.apply 't' (C = 3, both masks,
+    valid area) and mode 3 at B = 1, each frame on its own, against the oracle -- and the library must report a row-table kernel."""
+    import oflibpytorch_amd as ofl
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    t, n = frames
+    for i in (0, 1):
+        sl = slice(i, i + 1)
+        warped, valid = ofl.Flow(t["f2"][sl], 't', t["m2"][sl]).apply(t["img"][sl], target_mask=t["tm"][sl], return_valid_area=True)
+        assert "warp_bwd_rows_kernel<1," in _native.last_kernel_name()
+        exp, expv = oracle.flow_apply(n["f2"][sl], 't', n["m2"][sl], n["img"][sl], n["tm"][sl])
+        assert np.array_equal(warped.cpu().numpy(), exp) and np.array_equal(valid.cpu().numpy(), expv)
+        out = ofl.Flow(t["f1"][sl], 't', t["m1"][sl]).combine_with(ofl.Flow(t["f2"][sl], 't', t["m2"][sl]), 3)
+        assert "warp_bwd_rows_kernel<1," in _native.last_kernel_name()
+        exp, expm, _ = oracle.combine_with(n["f1"][sl], n["m1"][sl], n["f2"][sl], n["m2"][sl], 3, 't')
+        assert np.array_equal(out.vecs.cpu().numpy(), exp) and np.array_equal(out.mask.cpu().numpy(), expm)
+
+
 def test_apply_s_full_frame(frames, dev):
     """Smooth flow: the in-order (gather) splat is bit-exact at full size.  Bench flow (folds): masks bit-exact, values within the
     stated tolerance on the tiles that fell back to float atomics -- and bit-exact everywhere else."""

@@ -312,6 +312,19 @@ def test_row_tables_gradient_wrt_flow(kind, c, dev):
         finally:
             _native.set_warp_path(0)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # ... and an INDEPENDENT reference for the first images: torch autograd through the reference's own op sequence (utils.py:541-555,
+    # F.grid_sample) on the device, within the gradient tolerance of tests/test_autograd.py
+    k = 3
+    sign = -1.0 if kind == "blocks" else 1.0
+    fl = flow[:k].clone().requires_grad_(True)
+    gy, gx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')
+    field = (torch.stack((gx, gy), dim=-1).float().unsqueeze(0) - sign * fl.permute(0, 2, 3, 1)) * 2
+    field = torch.stack((field[..., 0] / (w - 1), field[..., 1] / (h - 1)), dim=-1) - 1
+    ref = torch.nn.functional.grid_sample(src[:k], field, align_corners=True)
+    (gref,) = torch.autograd.grad((ref * (0.5 * go[:k])).sum(), fl)
+    scale = float(gref.abs().max())
+    err = float((outs[0][:k].double() - gref.double()).abs().max())
+    assert err <= 2e-4 * max(scale, 1e-6), "grad wrt flow: max |diff| %.3g against a gradient scale of %.3g" % (err, scale)
 
 
 @pytest.mark.parametrize("c", [1, 3])
@@ -350,6 +363,19 @@ def test_row_tables_uint8_images(kind, c, dev):
                 assert (a_ is None) == (b_ is None)
                 if a_ is not None:
                     assert torch.equal(a_, b_)
+        # ... and the ORACLE on the first images (the paths above are four kernels of one library: pinned here, not only through each other)
+        from oracle import oracle
+        k = 3
+        s_ = src[:k].cpu().numpy().astype(np.float32)
+        if kw.get("want_valid"):
+            s_ = np.concatenate([s_, sm[:k].cpu().numpy().astype(np.float32)[:, None]], 1)
+        gref = oracle.G(flow[:k].cpu().numpy(), s_)
+        exp_u8 = np.clip(np.rint(gref[:, :c]), 0, 255).astype(np.uint8)          # torch.round (half to even) + clamp, flow_class.py:943-946
+        assert np.array_equal(outs[0][0][:k].cpu().numpy(), exp_u8)
+        assert np.array_equal(outs[0][-2][:k].cpu().numpy(), gref[:, :c])         # (fp32 out, no rounding: the last two of the tuple)
+        if kw.get("want_valid"):
+            expv = (gref[:, c] > np.float32(0.99999)) & fmk[:k].cpu().numpy()
+            assert np.array_equal(outs[0][1][:k].cpu().numpy(), expv) and np.array_equal(outs[0][-1][:k].cpu().numpy(), expv)
 
 
 @pytest.mark.parametrize("kind", ["waves", "steep_rows", "blocks", "outward"])
@@ -395,6 +421,16 @@ def test_channel_loop_with_row_tables(kind, c, valid, dev):
             assert (a_ is None) == (b_ is None)
             if a_ is not None:
                 assert torch.equal(a_, b_)
+    # ... and the ORACLE on the first images
+    from oracle import oracle
+    k = 2
+    s_ = src[:k].cpu().numpy()
+    if valid:
+        s_ = np.concatenate([s_, sm[:k].cpu().numpy().astype(np.float32)[:, None]], 1)
+    gref = oracle.G(flow[:k].cpu().numpy(), s_)
+    assert np.array_equal(outs[0][0][:k].cpu().numpy(), gref[:, :c], equal_nan=True)
+    if valid:
+        assert np.array_equal(outs[0][1][:k].cpu().numpy(), (gref[:, c] > np.float32(0.99999)) & fmk[:k].cpu().numpy())
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 2, 37, 52), (2, 1, 16, 4), (1, 3, 2, 8), (3, 2, 130, 260),
