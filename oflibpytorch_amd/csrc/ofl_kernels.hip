@@ -2231,7 +2231,11 @@ constexpr int kSpQ = OFL_SP_Q;                               // records the gath
 #endif
 constexpr int kSubW = 16, kSubH = OFL_SP_SUBH;               // source subtiles: 4 lanes x 4 pixels wide, kSubH rows
 constexpr int kSubLanes = 4 * kSubH;                         // lanes per subtile (16: a DPP row; 8: half a row)
-constexpr int kRegH = 16;                                    // a bin block covers a 64 x 16 source region (its wave w: rows 4 w .. 4 w + 3)
+#ifndef OFL_SP_BING
+#define OFL_SP_BING 2
+#endif
+constexpr int kBinG = OFL_SP_BING;                             // 4-pixel groups per lane of the bin kernel
+constexpr int kRegH = 16 * kBinG;                            // a bin block covers a 64 x kRegH source region (its wave w: rows 16 g + 4 w .. + 3 of group g)
 static_assert(kSubH == 1 || kSubH == 2 || kSubH == 4, "subtile height");
 constexpr int kBinCap = (512 / kSubH) * (kSpTW / 32);        // subtiles one destination tile can list (fixed-address lists: 4 * kBinCap bytes per tile)
 constexpr int kBinSpread = 256;                              // destination tiles one subtile may touch
@@ -2406,6 +2410,10 @@ __device__ __forceinline__ void sp_flag_image(const GatherParams& p, int n) {
 
 template <typename TF, bool LEAN = false>
 __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
+    // Round 6: a block covers a 64 x (16 kBinG) source region -- every lane kBinG 4-pixel groups, 16 rows apart, their loads issued
+    // together -- so that the chain load -> LDS ranks -> ONE device-scope atomic per (region, destination tile) -> list stores is paid
+    // once per 2 048 pixels instead of once per 1 024 (the kernel is that chain, not bandwidth: 80 us at 3.9 TB/s of its 9 B/px)
+    constexpr int G = kBinG;
     __shared__ int red[4][2];
     __shared__ int lcount[kBinLocal], lbase[kBinLocal];
     int rx, ry, n;
@@ -2416,40 +2424,47 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     const int sub = lane >> 4, r = (lane >> 2) & 3, c4 = lane & 3;       // subtile of the wave, row and 4-pixel group in it
     const int w = s.w, h = s.h;
     const uint32_t hw = (uint32_t)(h * w);
-    const int sx4 = rx * (4 * kSubW) + sub * kSubW + c4 * 4, sy = ry * kRegH + wave * 4 + r;
-    const bool inimg = (sx4 < w) && (sy < h);
-    SpSrc q;
-    sp_load_src<TF>(s, n, sx4, sy, inimg, (uint32_t)(sy * w + sx4), hw, q);
+    const int sx4 = rx * (4 * kSubW) + sub * kSubW + c4 * 4;
+    int sy[G];
+    SpSrc q[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        sy[g] = ry * kRegH + g * 16 + wave * 4 + r;
+        sp_load_src<TF>(s, n, sx4, sy[g], (sx4 < w) && (sy[g] < h), (uint32_t)(sy[g] * w + sx4), hw, q[g]);
+    }
     if (tid < kBinLocal) lcount[tid] = 0;
     // destination pixels the four corners of this thread's end points touch (clamped corners carry weight 0,
     // utils.py:1106-1111: they touch nothing)
-    int lo = 0x7fff7fff, hi = (int)0xffffffffu;                          // (x, y) = (32767, 32767) / (-1, -1)
     const float wf = (float)w, hf = (float)h;
+    int minx[G], miny[G], maxx[G], maxy[G];
+    bool any[G];
+    int blo_w = 0x7fff7fff, bhi_w = (int)0xffffffffu;                    // union over the wave's subtiles (both groups)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if ((q.on >> k) & 1u) {
-            const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, wf), y0 = (int)__builtin_amdgcn_fmed3f(floorf(q.y[k]), -2.0f, hf);
-            const int xa = max(x0, 0), xb = min(x0 + 1, w - 1), ya = max(y0, 0), yb = min(y0 + 1, h - 1);
-            if (xa <= xb && ya <= yb) {
-                lo = pk_min16(lo, (int)((uint32_t)xa | ((uint32_t)ya << 16)));
-                hi = pk_max16(hi, (int)((uint32_t)xb | ((uint32_t)yb << 16)));
+    for (int g = 0; g < G; ++g) {
+        int lo = 0x7fff7fff, hi = (int)0xffffffffu;                      // (x, y) = (32767, 32767) / (-1, -1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((q[g].on >> k) & 1u) {
+                const int x0 = (int)__builtin_amdgcn_fmed3f(floorf(q[g].x[k]), -2.0f, wf), y0 = (int)__builtin_amdgcn_fmed3f(floorf(q[g].y[k]), -2.0f, hf);
+                const int xa = max(x0, 0), xb = min(x0 + 1, w - 1), ya = max(y0, 0), yb = min(y0 + 1, h - 1);
+                if (xa <= xb && ya <= yb) {
+                    lo = pk_min16(lo, (int)((uint32_t)xa | ((uint32_t)ya << 16)));
+                    hi = pk_max16(hi, (int)((uint32_t)xb | ((uint32_t)yb << 16)));
+                }
             }
         }
-    }
-    lo = row_pk_min_dpp(lo); hi = row_pk_max_dpp(hi);                    // over the subtile
-    const int minx = (int)(short)(lo & 0xffff), miny = lo >> 16, maxx = (int)(short)(hi & 0xffff), maxy = hi >> 16;
-    const bool any = maxx >= minx && maxy >= miny;                       // something of this subtile lands inside the image
-    // destination tiles of the subtile (as packed 16-bit pairs, for the block-wide union)
-    const int tlo = any ? (int)((uint32_t)(minx / kSpTW) | ((uint32_t)(miny / kSpTH) << 16)) : 0x7fff7fff;
-    const int thi = any ? (int)((uint32_t)(maxx / kSpTW) | ((uint32_t)(maxy / kSpTH) << 16)) : (int)0xffffffffu;
-    {
-        int a = __builtin_amdgcn_readlane(tlo, 0), b = __builtin_amdgcn_readlane(thi, 0);
+        lo = row_pk_min_dpp(lo); hi = row_pk_max_dpp(hi);                // over the subtile
+        minx[g] = (int)(short)(lo & 0xffff); miny[g] = lo >> 16; maxx[g] = (int)(short)(hi & 0xffff); maxy[g] = hi >> 16;
+        any[g] = maxx[g] >= minx[g] && maxy[g] >= miny[g];               // something of this subtile lands inside the image
+        // destination tiles of the subtile (as packed 16-bit pairs, for the block-wide union)
+        const int tlo = any[g] ? (int)((uint32_t)(minx[g] / kSpTW) | ((uint32_t)(miny[g] / kSpTH) << 16)) : 0x7fff7fff;
+        const int thi = any[g] ? (int)((uint32_t)(maxx[g] / kSpTW) | ((uint32_t)(maxy[g] / kSpTH) << 16)) : (int)0xffffffffu;
 #pragma unroll
-        for (int l = kSubLanes; l < 64; l += kSubLanes) {
-            a = pk_min16(a, __builtin_amdgcn_readlane(tlo, l)); b = pk_max16(b, __builtin_amdgcn_readlane(thi, l));
+        for (int l = 0; l < 64; l += kSubLanes) {
+            blo_w = pk_min16(blo_w, __builtin_amdgcn_readlane(tlo, l)); bhi_w = pk_max16(bhi_w, __builtin_amdgcn_readlane(thi, l));
         }
-        if (lane == 0) { red[wave][0] = a; red[wave][1] = b; }
     }
+    if (lane == 0) { red[wave][0] = blo_w; red[wave][1] = bhi_w; }
     __syncthreads();
     int blo = red[0][0], bhi = red[0][1];
 #pragma unroll
@@ -2458,22 +2473,29 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     if (btx1 < btx0 || bty1 < bty0) return;                              // nothing of this region lands inside the image (block-uniform)
     const int bntx = btx1 - btx0 + 1, bnt = bntx * (bty1 - bty0 + 1);
     const bool local = bnt <= kBinLocal;                                 // block-uniform
-    const int tx0 = minx / kSpTW, tx1 = maxx / kSpTW, ty0 = miny / kSpTH, ty1 = maxy / kSpTH;
-    const int ntx = tx1 - tx0 + 1, cnt = any ? ntx * (ty1 - ty0 + 1) : 0;
-    const uint32_t subid = (uint32_t)(((ry * 4 + wave) * (4 / kSubH) + r / kSubH) * p.subs_x + rx * 4 + sub);
-    if (cnt > kBinSpread) {                                              // a subtile torn over the whole frame: two-pass path
-        if ((lane & (kSubLanes - 1)) == 0) sp_flag_image(p, n);
-    }
     const int j0 = lane & (kSubLanes - 1);
-    // the common case: at most kSubLanes destination tiles per subtile (one per lane), all inside the region's local grid -- ranks
-    // from LDS atomics, then ONE global atomic per (source region, destination tile) instead of one per (subtile, tile):
-    // device-scope atomics go all the way to memory and cost ~1 us each
-    int lt = -1, rank = 0;
-    const bool fast = local && cnt <= kSubLanes;
-    if (fast && j0 < cnt) {
-        const int jy = j0 / ntx;
-        lt = (ty0 + jy - bty0) * bntx + (tx0 + (j0 - jy * ntx) - btx0);
-        rank = atomicAdd(&lcount[lt], 1);
+    int tx0[G], ty0[G], ntx[G], cnt[G], lt[G], rank[G];
+    uint32_t subid[G];
+    bool fast[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        tx0[g] = minx[g] / kSpTW; ty0[g] = miny[g] / kSpTH;
+        const int tx1 = maxx[g] / kSpTW, ty1 = maxy[g] / kSpTH;
+        ntx[g] = tx1 - tx0[g] + 1; cnt[g] = any[g] ? ntx[g] * (ty1 - ty0[g] + 1) : 0;
+        subid[g] = (uint32_t)((sy[g] / kSubH) * p.subs_x + rx * 4 + sub);
+        if (cnt[g] > kBinSpread) {                                       // a subtile torn over the whole frame: two-pass path
+            if ((lane & (kSubLanes - 1)) == 0) sp_flag_image(p, n);
+        }
+        // the common case: at most kSubLanes destination tiles per subtile (one per lane), all inside the region's local grid -- ranks
+        // from LDS atomics, then ONE global atomic per (source region, destination tile) instead of one per (subtile, tile):
+        // device-scope atomics go all the way to memory and cost ~1 us each
+        lt[g] = -1; rank[g] = 0;
+        fast[g] = local && cnt[g] <= kSubLanes;
+        if (fast[g] && j0 < cnt[g]) {
+            const int jy = j0 / ntx[g];
+            lt[g] = (ty0[g] + jy - bty0) * bntx + (tx0[g] + (j0 - jy * ntx[g]) - btx0);
+            rank[g] = atomicAdd(&lcount[lt[g]], 1);
+        }
     }
     if (local) {
         __syncthreads();
@@ -2485,20 +2507,26 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
             if (start + lcount[tid] > kBinCap) sp_flag_image(p, n);
         }
         __syncthreads();
-        if (lt >= 0) {
-            const int ly_ = lt / bntx;
-            const int64_t d = (int64_t)n * p.tiles_img + (bty0 + ly_) * p.tiles_x + btx0 + (lt - ly_ * bntx);
-            const int pos = lbase[lt] + rank;
-            if (pos < kBinCap) p.list[d * kBinCap + pos] = subid;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (lt[g] >= 0) {
+                const int ly_ = lt[g] / bntx;
+                const int64_t d = (int64_t)n * p.tiles_img + (bty0 + ly_) * p.tiles_x + btx0 + (lt[g] - ly_ * bntx);
+                const int pos = lbase[lt[g]] + rank[g];
+                if (pos < kBinCap) p.list[d * kBinCap + pos] = subid[g];
+            }
         }
     }
-    if (!fast && cnt <= kBinSpread) {                                    // wide spreads: straight to the global counters
-        for (int j = j0; j < cnt; j += kSubLanes) {
-            const int jy = j / ntx;
-            const int64_t d = (int64_t)n * p.tiles_img + (ty0 + jy) * p.tiles_x + tx0 + (j - jy * ntx);
-            const int pos = atomicAdd(&p.cnt[d], 1);
-            if (pos < kBinCap) p.list[d * kBinCap + pos] = subid;
-            else sp_flag_image(p, n);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!fast[g] && cnt[g] <= kBinSpread) {                          // wide spreads: straight to the global counters
+            for (int j = j0; j < cnt[g]; j += kSubLanes) {
+                const int jy = j / ntx[g];
+                const int64_t d = (int64_t)n * p.tiles_img + (ty0[g] + jy) * p.tiles_x + tx0[g] + (j - jy * ntx[g]);
+                const int pos = atomicAdd(&p.cnt[d], 1);
+                if (pos < kBinCap) p.list[d * kBinCap + pos] = subid[g];
+                else sp_flag_image(p, n);
+            }
         }
     }
 }
