@@ -3515,22 +3515,36 @@ __device__ __attribute__((noinline)) void sp2_order_big_cell(f4* recA, uint32_t*
     // 3. lane r gets the index of the r-th record in raster order
     uint32_t sorted = 0;
     if (mine) sorted = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)idx);
-    // 4. lane (class k, channel ch) adds its sum over the records in that order: weight (product of two, rounded) times data, rounded, added
+    // 4. lane (class k, channel ch) adds its sum over the records in that order: weight (product of two, rounded) times data, rounded, added.
+    // FOUR records are fetched before the first is used (two broadcast LDS reads each: part A, part B): fetched one at a time the loop was a
+    // chain of dependent LDS round trips, ~150 cycles per record -- the second launch 402 -> 309 us at sigma 12 (profiles/r6_splat_diet.txt)
     const int k = lane & 3, ch = lane >> 2;
     const bool acc_on = ch < 1 + NCH;
     const bool is_mask = NCH > NC && ch == 1 + NC;
-    const float* recf = reinterpret_cast<const float*>(recA);
     float acc = 0.0f;
-    for (int r = 0; r < cn; ++r) {
-        const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)sorted, r);
-        const float fx = recf[4 * ir], fy = recf[4 * ir + 1];
-        const float wv = ((k & 2) ? fy : 1.0f - fy) * ((k & 1) ? fx : 1.0f - fx);
-        float dv = 1.0f;                                                  // (density: the weight itself -- w * 1 is exact)
-        if (is_mask) dv = (float)(sp2_key<NC>(recA, recB, ir) & 1u);
-        else if (ch == 1) dv = recf[4 * ir + 2];
-        else if (ch == 2) dv = recf[4 * ir + 3];
-        else if (ch == 3 && NC == 3) dv = __uint_as_float(recB[2 * ir]);
-        acc += wv * dv;
+    for (int r0 = 0; r0 < cn; r0 += 4) {
+        f4 av[4];
+        uint32_t b0[4], b1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ir = (uint32_t)__builtin_amdgcn_readlane((int)sorted, min(r0 + j, cn - 1));
+            av[j] = recA[ir];
+            b0[j] = NC >= 2 ? recB[(NC == 3 ? 2 : 1) * ir] : 0u;
+            b1[j] = NC == 3 ? recB[2 * ir + 1] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float fx = av[j][0], fy = av[j][1];
+            const uint32_t kj = NC == 1 ? __float_as_uint(av[j][3]) : (NC == 2 ? b0[j] : b1[j]);
+            const float wv = ((k & 2) ? fy : 1.0f - fy) * ((k & 1) ? fx : 1.0f - fx);
+            float dv = 1.0f;                                              // (density: the weight itself -- w * 1 is exact)
+            if (is_mask) dv = (float)(kj & 1u);
+            else if (ch == 1) dv = av[j][2];
+            else if (ch == 2) dv = av[j][3];
+            else if (ch == 3 && NC == 3) dv = __uint_as_float(b0[j]);
+            const float nxt = acc + wv * dv;
+            acc = r0 + j < cn ? nxt : acc;
+        }
     }
     // 5. the class sums where the cell's readers expect them: part A of the first 1 + NCH records (raster order), on a chain
     const uint32_t mych = (uint32_t)__builtin_amdgcn_ds_bpermute((acc_on ? ch : 0) << 2, (int)sorted);          // (every lane takes part)
