@@ -3426,6 +3426,12 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
 #ifndef OFL_SP_Q2
 #define OFL_SP_Q2 2048
 #endif
+#ifndef OFL_SP_REDOGRID
+#define OFL_SP_REDOGRID 512
+#endif
+#ifndef OFL_SP_BIGBLOCK
+#define OFL_SP_BIGBLOCK 1      // the second launch orders a band's big cells by the whole block (0: a wave per cell, as the first launch)
+#endif
 #ifndef OFL_SP_Q3
 #define OFL_SP_Q3 1792
 #endif
@@ -3556,13 +3562,94 @@ __device__ __attribute__((noinline)) void sp2_order_big_cell(f4* recA, uint32_t*
     if (lane == 0) cellw[c] = (kSp2Sum << 16) | (uint32_t)__builtin_amdgcn_readlane((int)sorted, 0);
 }
 
+// The second launch's way with big cells: ALL of a band's big cells at once, by the whole block.  One wave per cell (above) walks a
+// chain of dependent LDS reads per record and uses 4 x (1 + NCH) of its 64 lanes for the sums -- ~280 cycles per record, and a band
+// inside a compression of the flow holds a hundred such cells: half of the second launch (profiles/r6_splat_diet.txt, 5).  Here:
+//   a. one LANE per cell walks its chain into a contiguous segment of `seg` (every chain of the band side by side);
+//   b. one THREAD per record ranks it among its cell's keys (independent LDS reads) and puts it at its place in `srt`;
+//   c. a GROUP of 4 x (1 + NCH) lanes per cell -- 3 to 5 cells per wave -- adds the class sums in that order, four records fetched
+//      ahead, and leaves them where phase C expects them (as sp2_order_big_cell's step 5).
+// Same sums, same order.  12.9 KB of LDS more than the first launch's kernel has room for: the second launch only.
+template <int NC, int NCH>
+__device__ __forceinline__ void sp2_big_cells_block(f4* recA, uint32_t* recB, uint16_t* link, uint32_t* cellw, const uint16_t* bq, int nbig,
+                                                    uint16_t* seg, uint16_t* srt, uint16_t* segb, uint32_t* bqinfo, int* segtop, int tid) {
+    const int lane = tid & 63;
+    for (int b = tid; b < nbig; b += kSpNT2) {
+        const uint32_t cw = cellw[bq[b]];
+        const int cn = (int)(cw >> 16);
+        const int base = atomicAdd(segtop, cn);
+        bqinfo[b] = (uint32_t)base | ((uint32_t)cn << 16);
+        uint32_t cur = cw & 0xffffu;
+        for (int j = 0; j < cn; ++j) { seg[base + j] = (uint16_t)cur; segb[base + j] = (uint16_t)b; cur = link[cur]; }
+    }
+    __syncthreads();
+    const int nseg = __builtin_amdgcn_readfirstlane(*segtop);
+    for (int i = tid; i < nseg; i += kSpNT2) {
+        const uint32_t info = bqinfo[segb[i]];
+        const int base = (int)(info & 0xffffu), cn = (int)(info >> 16);
+        const uint32_t my = seg[i], mykey = sp2_key<NC>(recA, recB, my);
+        int rank = 0;
+        for (int t = 0; t < cn; t += 4) {
+            uint32_t kk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kk[j] = sp2_key<NC>(recA, recB, seg[base + min(t + j, cn - 1)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rank += (t + j < cn && kk[j] < mykey) ? 1 : 0;
+        }
+        srt[base + rank] = (uint16_t)my;
+    }
+    __syncthreads();
+    constexpr int LG = 4 * (1 + NCH), G = 64 / LG;
+    const int g = lane / LG, wi = lane - g * LG, k = wi & 3, ch = wi >> 2;
+    const bool is_mask = NCH > NC && ch == 1 + NC;
+    for (int bw = (tid >> 6) * G; bw < nbig; bw += (kSpNT2 / 64) * G) {     // (wave-uniform)
+        const int b = bw + g;
+        const bool on = g < G && b < nbig;
+        const uint32_t info = on ? bqinfo[b] : 0u;
+        const int base = (int)(info & 0xffffu), cn = (int)(info >> 16);
+        float acc = 0.0f;
+        for (int r0 = 0; r0 < cn; r0 += 4) {
+            f4 av[4];
+            uint32_t b0[4], b1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t ir = srt[base + min(r0 + j, cn - 1)];
+                av[j] = recA[ir];
+                b0[j] = NC >= 2 ? recB[(NC == 3 ? 2 : 1) * ir] : 0u;
+                b1[j] = NC == 3 ? recB[2 * ir + 1] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float fx = av[j][0], fy = av[j][1];
+                const uint32_t kj = NC == 1 ? __float_as_uint(av[j][3]) : (NC == 2 ? b0[j] : b1[j]);
+                const float wv = ((k & 2) ? fy : 1.0f - fy) * ((k & 1) ? fx : 1.0f - fx);
+                float dv = 1.0f;
+                if (is_mask) dv = (float)(kj & 1u);
+                else if (ch == 1) dv = av[j][2];
+                else if (ch == 2) dv = av[j][3];
+                else if (ch == 3 && NC == 3) dv = __uint_as_float(b0[j]);
+                const float nxt = acc + wv * dv;
+                acc = r0 + j < cn ? nxt : acc;
+            }
+        }
+        // (every lane of the wave has left its loop: the records the sums overwrite have been read)
+        if (on) {
+            const uint32_t mych = srt[base + ch];
+            reinterpret_cast<float*>(recA)[4 * mych + k] = acc;
+            if (k == 0) link[mych] = (uint16_t)(ch < NCH ? (uint32_t)srt[base + ch + 1] : kSp2End);
+            if (wi == 0) cellw[bq[b]] = (kSp2Sum << 16) | (uint32_t)srt[base];
+        }
+    }
+    __syncthreads();
+}
+
 // REDO = false: the kernel every tile runs on -- ONE scan, no bands: a tile whose records overflow the LDS, or that holds a cell of
 // more than 64 records, puts its id on the pass's redo list and leaves.  REDO = true: a second, small launch that walks that list
 // with the whole repertoire (2 or 4 bands of rows, the float-atomics fold).  Splitting the two takes every loop away from round
 // the hot path's phases: with the band loops in place the compiler hoisted each per-thread invariant of the later phases (tile
 // geometry, output offsets) to the top of the kernel and, at 80 registers, spilled ten of them there (profiles/r6_splat_diet.txt).
 template <int NC, bool MCH, typename TF = float, typename TO = float, bool LEAN = false, bool REDO = false>
-__global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(const GatherParams p_by_value_unused) {
+__global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2_kernel(const GatherParams p_by_value_unused) {
     GatherParamsK* pp = (GatherParamsK*)__builtin_amdgcn_kernarg_segment_ptr();
 #define p (*pp)
     constexpr int NCH = NC + (MCH ? 1 : 0);
@@ -3574,6 +3661,10 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
     __shared__ int qcount, lqn, bqn;
     __shared__ uint16_t lq[L::kLongQ];                                // cells with more than two records: phase S works on them lane by lane
     __shared__ uint16_t bq[L::kBigQ];                                 // ... of those, the cells with more than kNet records: a wave each
+    constexpr int kSegN = (REDO && OFL_SP_BIGBLOCK) ? kQ : 1;         // (the second launch: big cells by the whole block -- sp2_big_cells_block)
+    __shared__ uint16_t seg[kSegN], srt[kSegN], segb[kSegN];
+    __shared__ uint32_t bqinfo[(REDO && OFL_SP_BIGBLOCK) ? L::kBigQ : 1];
+    __shared__ int segtop;
     static_assert((size_t)(1 + NCH) * kSpTW * kSpTH * sizeof(float) <= sizeof(raw), "the fold path's accumulators live in the record area");
     f4* recA = reinterpret_cast<f4*>(raw);
     uint32_t* recB = reinterpret_cast<uint32_t*>(raw + 16 * kQ);
@@ -3779,8 +3870,12 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
         if (__builtin_amdgcn_readfirstlane(__syncthreads_or((int)toolong)) != 0) return true;
         const int nbig = __builtin_amdgcn_readfirstlane(bqn);
         if (nbig != 0) {
-            for (int b = tid >> 6; b < nbig; b += kSpNT2 / 64) sp2_order_big_cell<NC, NCH>(recA, recB, link, cellw, bq[b], lane);
-            __syncthreads();
+            if (REDO && OFL_SP_BIGBLOCK) {
+                sp2_big_cells_block<NC, NCH>(recA, recB, link, cellw, bq, nbig, seg, srt, segb, bqinfo, &segtop, tid);
+            } else {
+                for (int b = tid >> 6; b < nbig; b += kSpNT2 / 64) sp2_order_big_cell<NC, NCH>(recA, recB, link, cellw, bq[b], lane);
+                __syncthreads();
+            }
         }
         return false;
     };
@@ -3832,7 +3927,7 @@ __global__ __launch_bounds__(kSpNT2, OFL_SP_MINB2) void splat_gather2_kernel(con
 #pragma unroll
         for (int i = 0; i < kCellRounds; ++i)
             if (tid + i * kSpNT2 < kCellsP) cellw[tid + i * kSpNT2] = kSp2Empty;
-        if (tid == 0) { qcount = 0; lqn = 0; bqn = 0; }
+        if (tid == 0) { qcount = 0; lqn = 0; bqn = 0; segtop = 0; }
     };
     int dflags = 0;
     if (!REDO) {
@@ -4132,7 +4227,7 @@ template <int NC, bool MCH, typename TF, typename TO>
 static int splat_launch_diet(const GatherParams* gp, unsigned grid, hipStream_t st, int extra_lds, int lean, int32_t* info) {
     const bool ln = gp ? (NC >= 2 && OFL_SP_LEAN && splat_is_lean(gp->s)) : (NC >= 2 && lean != 0);
     const void* fn = ln ? (const void*)splat_gather2_kernel<NC, MCH, TF, TO, (NC >= 2)> : (const void*)splat_gather2_kernel<NC, MCH, TF, TO>;
-    constexpr unsigned kRedoGrid = 768;                      // the second launch walks the redo list with this many blocks (3 per CU)
+    constexpr unsigned kRedoGrid = OFL_SP_REDOGRID;          // the second launch walks the redo list with this many blocks (2 per CU: 65 KB of LDS each)
     if (!gp) {
         hipFuncAttributes fa;
         hipError_t e = hipFuncGetAttributes(&fa, fn);
