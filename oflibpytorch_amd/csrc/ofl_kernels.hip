@@ -2260,7 +2260,7 @@ struct GatherParams {
     uint32_t regs_img, rx_m, rx_s, ri_m, ri_s;
     int64_t rtotal, rper_xcd;
     int32_t* redo_cnt;     // [1] tiles of this pass the one-scan gather kernel left to the second launch (bands / fold)
-    uint32_t* redo_list;   // [4 * n * tiles][2] (tile, first row | end row << 8): the BANDS of rows they were split into
+    uint32_t* redo_list;   // [kSpTH * n * tiles][2] (tile, first row | end row << 8): the BANDS of rows they were split into
 };
 
 // XCD-aware 32-bit decode of (column, row, image) from the block index
@@ -3429,6 +3429,12 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
 #ifndef OFL_SP_REDOGRID
 #define OFL_SP_REDOGRID 512
 #endif
+#ifndef OFL_SP2_UNITTIME
+#define OFL_SP2_UNITTIME 0
+#endif
+#ifndef OFL_SP_PLAN
+#define OFL_SP_PLAN 1          // an overflowing tile's bands are planned from the exact record counts of its cell rows (0: 2 or 4 equal bands)
+#endif
 #ifndef OFL_SP_BIGBLOCK
 #define OFL_SP_BIGBLOCK 1      // the second launch orders a band's big cells by the whole block (0: a wave per cell, as the first launch)
 #endif
@@ -3660,7 +3666,9 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
     __shared__ __attribute__((aligned(16))) unsigned char raw[L::kRawBytes];
     __shared__ int qcount, lqn, bqn;
     __shared__ uint16_t lq[L::kLongQ];                                // cells with more than two records: phase S works on them lane by lane
-    __shared__ uint16_t bq[L::kBigQ];                                 // ... of those, the cells with more than kNet records: a wave each
+    __shared__ __attribute__((aligned(4))) uint16_t bq[L::kBigQ];     // ... of those, the cells with more than kNet records: a wave each
+    static_assert(sizeof(uint16_t) * L::kBigQ >= sizeof(int) * L::kCH, "the per-row counts of an overflowing tile live in the big-cell queue");
+    int* rowover = reinterpret_cast<int*>(bq);                        // (first launch) records per cell row of a tile that overflows: it never orders its cells
     constexpr int kSegN = (REDO && OFL_SP_BIGBLOCK) ? kQ : 1;         // (the second launch: big cells by the whole block -- sp2_big_cells_block)
     __shared__ uint16_t seg[kSegN], srt[kSegN], segb[kSegN];
     __shared__ uint32_t bqinfo[(REDO && OFL_SP_BIGBLOCK) ? L::kBigQ : 1];
@@ -3684,7 +3692,10 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
     int ri = (int)blockIdx.x;
     if (REDO && ri >= redo_n) return;
     do {                                                              // (REDO: units of the list until it is empty; else once)
-    int tx, ty, n, ua = 0, ub = kSpTH;
+#if OFL_SP2_UNITTIME
+    const uint64_t unit_t0 = wall_clock64();
+#endif
+    int tx, ty, n, ua = 0, ub = kSpTH, ufold = 0;                    // (ufold: the first launch knows this band cannot be summed in order)
     uint32_t tile;
     if (REDO) {
         const uint2 unit = reinterpret_cast<const uint2*>(p.redo_list)[ri];
@@ -3692,6 +3703,7 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
         // may not contain the "+s" pins of the kernarg pointer: "illegal VGPR to SGPR copy")
         tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)unit.x);
         ua = __builtin_amdgcn_readfirstlane((int)(unit.y & 0xffu)); ub = __builtin_amdgcn_readfirstlane((int)((unit.y >> 8) & 0xffu));
+        ufold = __builtin_amdgcn_readfirstlane((int)((unit.y >> 16) & 1u));
         const uint32_t nn = fastdiv(tile, p.mi_m, p.mi_s), rem = tile - nn * p.tiles_img, yy = fastdiv(rem, p.mx_m, p.mx_s);
         n = (int)nn; ty = (int)yy; tx = (int)(rem - yy * (uint32_t)p.tiles_x);
     } else {
@@ -3750,6 +3762,17 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
                     link[pos] = (uint16_t)expect;
                     // the cell's THIRD record makes it a cell phase S must order: exactly one thread sees two before its own
                     if ((expect >> 16) == 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)cell[k];
+                }
+            }
+            // (first launch) a tile that overflows: the records that do not fit are still COUNTED in their cells' words -- the tile's
+            // bands are planned from the exact counts of its cell rows (below).  wbase is the wave's end position by now: wave-uniform
+            if (!REDO && OFL_SP_PLAN && wbase > kQ) {
+                int wb = wbase - wtot;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pos = wb + __popcll(m[k] & below);
+                    wb += __popcll(m[k]);
+                    if (cell[k] >= 0 && pos >= kQ) atomicAdd(&cellw[cell[k]], 0x10000u);
                 }
             }
         }
@@ -3946,6 +3969,55 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
         // independent BANDS of rows (a band of r rows sees about (r + 1) / 17 of the records) that other blocks sum side by side
         const int nrec = __builtin_amdgcn_readfirstlane(qcount);
         int nb = 0;
+        if (OFL_SP_PLAN && nrec > kQ) {
+            // The bands are PLANNED: the records of every cell row are counted (the cells' words count the records that did not fit
+            // too) and the rows are cut into the fewest bands of at most kQ records each (a band of rows
+            // [a, b) holds cell rows a .. b), as evenly as 64 candidate limits allow: no band of the second launch overflows and scans
+            // again, and none is much heavier than its siblings (the second launch lasts as long as its heaviest unit:
+            // profiles/r6_splat_diet.txt, 7).
+            if (tid <= L::kCH) rowover[tid] = 0;                  // (17 counts, then the mask of cell rows that hold a cell of more than kSpLong records)
+            __syncthreads();
+            for (int i = tid; i < L::kCells; i += kSpNT2) {
+                const uint32_t cn = cellw[i] >> 16;
+                const uint32_t row = (uint32_t)i / (uint32_t)kCW;
+                if (cn != 0u) atomicAdd(&rowover[row], (int)cn);
+                if (cn > (uint32_t)kSpLong) atomicOr(&rowover[L::kCH], 1 << row);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // rows that cannot be summed in order whatever the band: one of the row's two cell rows holds too long a cell, or
+                // the two hold more than kQ records.  They become bands of their own (at most 4 rows), marked: the second launch
+                // folds them without scanning first
+                const uint32_t longrows = (uint32_t)rowover[L::kCH];
+                const bool own = tid < kSpTH && rowover[tid & (kSpTH - 1)] + rowover[(tid & (kSpTH - 1)) + 1] > kQ;
+                const uint32_t foldrows = ((longrows | (longrows >> 1)) & ((1u << kSpTH) - 1u)) | (uint32_t)__ballot(own);
+                const int lim = (kQ * (tid + 1)) >> 6;            // lane 63: kQ itself
+                uint32_t ends = 0u;
+                int a = 0, cnt = 0;
+                while (a < kSpTH) {
+                    int b = a + 1;
+                    if ((foldrows >> a) & 1u) {
+                        while (b < kSpTH && ((foldrows >> b) & 1u) && b - a < 4) ++b;
+                    } else {
+                        int sum = rowover[a] + rowover[b];
+                        while (b < kSpTH && !((foldrows >> b) & 1u) && sum + rowover[b + 1] <= lim) { ++b; sum += rowover[b]; }
+                    }
+                    ends |= 1u << b; ++cnt; a = b;
+                }
+                const int nbmin = __builtin_amdgcn_readlane(cnt, 63);
+                const int win = __ffsll((unsigned long long)__ballot(cnt == nbmin)) - 1;
+                ends = (uint32_t)__builtin_amdgcn_readlane((int)ends, win);
+                int base = 0;
+                if (tid == 0) base = atomicAdd(&p.redo_cnt[0], nbmin);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (tid < nbmin) {
+                    int b0 = 0, b1 = 0;
+                    for (int j = 0; j <= tid; ++j) { b0 = b1; b1 = __ffs((int)ends) - 1; ends &= ends - 1u; }
+                    reinterpret_cast<uint2*>(p.redo_list)[base + tid] = make_uint2(tile, (uint32_t)b0 | ((uint32_t)b1 << 8) | (((foldrows >> b0) & 1u) << 16));
+                }
+            }
+            return;
+        }
         if (nrec > kQ) nb = (nrec * (kSpTH / 2 + 1) > (kQ - kQ / 8) * kSpTH) ? 4 : 2;
         else if (order()) nb = 4;
         if (nb != 0) {
@@ -3990,17 +4062,20 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
         bool first = true;
         int a0 = ua, b0 = ub;
         while (a0 < ub) {                                      // (block-uniform)
-            zero_cells();
-            __syncthreads();
-            scan(a0, b0, first);
-            first = false;
-            __syncthreads();
-            bool fits = __builtin_amdgcn_readfirstlane(qcount) <= kQ;
-            if (fits) fits = !order();
-            if (!fits && b0 - a0 > 4) {                        // halve the band and try again
-                b0 = a0 + (b0 - a0) / 2;
+            bool fits = false;
+            if (ufold == 0) {
+                zero_cells();
                 __syncthreads();
-                continue;
+                scan(a0, b0, first);
+                first = false;
+                __syncthreads();
+                fits = __builtin_amdgcn_readfirstlane(qcount) <= kQ;
+                if (fits) fits = !order();
+                if (!fits && b0 - a0 > 4) {                    // halve the band and try again
+                    b0 = a0 + (b0 - a0) / 2;
+                    __syncthreads();
+                    continue;
+                }
             }
             if (fits) {
                 const bool mine = t.inimg && ly >= a0 && ly < b0;
@@ -4027,6 +4102,13 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
         block_flag_or(&s.dst_flags[n], dflags);              // one access per block on the image's word (see block_flag_or)
     }
     if (!REDO) break;
+#if OFL_SP2_UNITTIME     /* a measuring aid (tools/redo_unit_times.py; never in a default build): when each unit started and how long it took, in the list itself */
+    if (tid == 0) {
+        const uint64_t t1 = wall_clock64();
+        p.redo_list[2 * ri] = tile | ((uint32_t)((unit_t0 >> 3) & 0xffffu) << 16);
+        p.redo_list[2 * ri + 1] = (uint32_t)ua | ((uint32_t)ub << 8) | ((uint32_t)min((t1 - unit_t0) >> 2, (uint64_t)0xffffu) << 16);
+    }
+#endif
     if (tid == 0) next_unit = (int)gridDim.x + atomicAdd(&p.redo_cnt[1], 1);
     __syncthreads();                                          // (also: the next unit re-uses the LDS)
     ri = __builtin_amdgcn_readfirstlane(next_unit);
@@ -5044,7 +5126,7 @@ __attribute__((visibility("default"))) int ofl_splat_finalize_f32(
 // per-image fallback flags | list lengths | lists | redo list
 static int64_t splat_pass_words(int64_t images, int32_t h, int32_t w) {
     const int64_t tiles = images * ((w + kSpTW - 1) / kSpTW) * ((h + kSpTH - 1) / kSpTH);
-    return 8 + ((images + 3) & ~(int64_t)3) + ((tiles + 3) & ~(int64_t)3) + (int64_t)kBinCap * tiles + 8 * tiles;   // (+ the redo list: up to 4 bands per tile, 2 words each)
+    return 8 + ((images + 3) & ~(int64_t)3) + ((tiles + 3) & ~(int64_t)3) + (int64_t)kBinCap * tiles + 2 * kSpTH * tiles;   // (+ the redo list: up to kSpTH bands per tile, 2 words each)
 }
 static int64_t splat_chunk_images(int32_t n, int32_t h, int32_t w) {
     // one pass unless the caller bounds it (a testing aid) or the fallback accumulator of a pass would pass ~2^31 floats

@@ -9,7 +9,7 @@ import bench
 import oflibpytorch_amd as ofl
 from oflibpytorch_amd import _native
 dev = torch.device('cuda', 0)
-n, h, w = 16, 1080, 1920
+n, h, w = int(os.environ.get("OFL_BATCH", "16")), 1080, 1920
 _native.set_splat_gather_kernel(int(os.environ.get("OFL_SPLAT_KERNEL", "0")))
 f1 = bench.smooth_flow(n, h, w, float(os.environ.get("OFL_SIGMA", "8")), 1000, dev)
 _, _, img, m1, m2, tm = bench.make_inputs(n, h, w, dev, 0)
