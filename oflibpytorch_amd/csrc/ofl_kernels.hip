@@ -3432,6 +3432,12 @@ __device__ __forceinline__ void sp_tile_atomics(const GP& p, const SP& s, float*
 #ifndef OFL_SP2_UNITTIME
 #define OFL_SP2_UNITTIME 0
 #endif
+#ifndef OFL_SP2_SKIP
+#define OFL_SP2_SKIP 0         // a measuring aid (tools/prof_phase_insts.sh; WRONG results): the first launch without 1 phase S, 2 phase C, 4 finalize, 8 the records
+#endif
+#ifndef OFL_SP_ALLVALID
+#define OFL_SP_ALLVALID 1      // phase C leaves the mask channel out where every scanned pixel is valid (0: always summed)
+#endif
 #ifndef OFL_SP_PLAN
 #define OFL_SP_PLAN 1          // an overflowing tile's bands are planned from the exact record counts of its cell rows (0: 2 or 4 equal bands)
 #endif
@@ -3470,14 +3476,35 @@ __device__ __forceinline__ void sp2_data(const f4& av, const uint32_t* recB, uin
     if (NCH > NC) d[NC] = (float)(key & 1u);                              // the mask channel rides in the key
 }
 
+// The sums of one (pixel, x-corner) class in phase C: the density, then NV values -- the data channels, the mask channel last when
+// it is summed -- held in PAIRS: a product and an addition of two channels are one v_pk_mul_f32 / v_pk_add_f32 each (written with
+// scalars the compiler paired the density with channel 0 and channel 2 with channel 1, and moved registers about to do it).
+template <int NV> struct SpAcc {
+    float den;
+    f2 pr[NV / 2 > 0 ? NV / 2 : 1];
+    float last;                                                          // (an odd NV: its last value)
+    __device__ __forceinline__ void clear() {
+        den = 0.0f; last = 0.0f;
+#pragma unroll
+        for (int q = 0; q < (NV / 2 > 0 ? NV / 2 : 1); ++q) pr[q] = (f2){0.0f, 0.0f};
+    }
+    __device__ __forceinline__ float get(int c) const { return c == 0 ? den : ((c - 1) < 2 * (NV / 2) ? pr[(c - 1) / 2][(c - 1) & 1] : last); }
+    __device__ __forceinline__ void add(int c, float v) {
+        if (c == 0) den += v;
+        else if ((c - 1) < 2 * (NV / 2)) pr[(c - 1) / 2][(c - 1) & 1] += v;
+        else last += v;
+    }
+};
+
 // One record of the cell whose column is DC (-1, 0, +1) cells from the pair's middle cell and whose row serves corner row KY, added
 // to the sums of the destination pixels that read it (see sp_use): weight = wy[KY] * wx[kx], rounded, then product with the data
-// rounded, then added.
-template <int NC, int NCH, int DC, int KY>
-__device__ __forceinline__ void sp2_use(const f4* recA, const uint32_t* recB, uint32_t i, float (&a)[2][2][1 + NCH]) {
+// rounded, then added.  NV = NC (+ 1: the mask channel is summed -- a tile all of whose records are valid leaves it out: its sums
+// are the density's, the same additions of the same weights).
+template <int NC, int NV, int DC, int KY>
+__device__ __forceinline__ void sp2_use(const f4* recA, const uint32_t* recB, uint32_t i, SpAcc<NV> (&a)[2][2]) {
     const f4 av = recA[i];
-    float d[NCH > 0 ? NCH : 1];
-    sp2_data<NC, NCH>(av, recB, i, d);
+    float d[NV > 0 ? NV : 1];
+    sp2_data<NC, NV>(av, recB, i, d);
     const float wy = KY == 0 ? 1.0f - av[1] : av[1];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -3485,24 +3512,25 @@ __device__ __forceinline__ void sp2_use(const f4* recA, const uint32_t* recB, ui
         if (kx < 0 || kx > 1) continue;
         const float wx = kx == 0 ? 1.0f - av[0] : av[0];
         const float wgt = wy * wx;
-        a[k][kx][0] += wgt;
+        a[k][kx].den += wgt;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) a[k][kx][1 + c] += wgt * d[c];
+        for (int q = 0; q < NV / 2; ++q) a[k][kx].pr[q] += (f2){wgt, wgt} * (f2){d[2 * q], d[2 * q + 1]};
+        if (NV & 1) a[k][kx].last += wgt * d[NV - 1];
     }
 }
 
 // a pre-summed cell: part A of the records on its chain holds one f4 (the four corner classes) per channel
-template <int NCH, int DC, int KY>
-__device__ __forceinline__ void sp2_use_presum(const f4* recA, const uint16_t* link, uint32_t i, float (&a)[2][2][1 + NCH]) {
+template <int NV, int NCH, int DC, int KY>
+__device__ __forceinline__ void sp2_use_presum(const f4* recA, const uint16_t* link, uint32_t i, SpAcc<NV> (&a)[2][2]) {
 #pragma unroll
-    for (int c = 0; c < 1 + NCH; ++c) {
+    for (int c = 0; c < 1 + NV; ++c) {
         const f4 pv = recA[i];
         if (c < NCH) i = link[i];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int kx = k - DC;
             if (kx < 0 || kx > 1) continue;
-            a[k][kx][c] += pv[KY * 2 + kx];
+            a[k][kx].add(c, pv[KY * 2 + kx]);
         }
     }
 }
@@ -3665,6 +3693,7 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
     constexpr uint32_t kEnd = kSp2End;
     __shared__ __attribute__((aligned(16))) unsigned char raw[L::kRawBytes];
     __shared__ int qcount, lqn, bqn;
+    __shared__ int tile_inv;                                          // some scanned pixel is masked out of the mask channel (else phase C leaves that channel out)
     __shared__ uint16_t lq[L::kLongQ];                                // cells with more than two records: phase S works on them lane by lane
     __shared__ __attribute__((aligned(4))) uint16_t bq[L::kBigQ];     // ... of those, the cells with more than kNet records: a wave each
     static_assert(sizeof(uint16_t) * L::kBigQ >= sizeof(int) * L::kCH, "the per-row counts of an overflowing tile live in the big-cell queue");
@@ -3724,6 +3753,7 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
         int cell[4];
         unsigned long long m[4];
         int wtot = 0;
+        if (MCH && OFL_SP_ALLVALID && __ballot(mc4 != 0x01010101u) != 0ull) { if (lane == 0) tile_inv = 1; }   // (wave-uniform; rare)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cx = (int)__builtin_amdgcn_fmed3f(floorf(q.x[k]), -2.0f, (float)w) - dx0 + 1;
@@ -3733,7 +3763,7 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
             m[k] = __ballot(hit);
             wtot += __popcll(m[k]);
         }
-        if (wtot != 0) {                                   // wave-uniform
+        if (wtot != 0 && !(!REDO && (OFL_SP2_SKIP & 8))) {   // wave-uniform
             int wbase = 0;
             if (lane == 0) wbase = atomicAdd(&qcount, wtot);
             wbase = __builtin_amdgcn_readfirstlane(wbase);
@@ -3761,7 +3791,9 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
                     }
                     link[pos] = (uint16_t)expect;
                     // the cell's THIRD record makes it a cell phase S must order: exactly one thread sees two before its own
-                    if ((expect >> 16) == 2u) lq[atomicAdd(&lqn, 1)] = (uint16_t)cell[k];
+                    // (the bound: in a tile that overflows the count also counts records that did not fit -- below -- and "two before
+                    // my own" no longer means three records in LDS; such a tile never reads the queue)
+                    if ((expect >> 16) == 2u) { const int qi = atomicAdd(&lqn, 1); if (qi < L::kLongQ) lq[qi] = (uint16_t)cell[k]; }
                 }
             }
             // (first launch) a tile that overflows: the records that do not fit are still COUNTED in their cells' words -- the tile's
@@ -3905,15 +3937,14 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
     // ---- C: the sums of this thread's 2 destination pixels.  The pair reads 3 x 2 cells; every record of a cell is fetched once
     // and added to each corner-class sum it belongs to (sp2_use).
     using std::integral_constant;
-    auto sums = [&](int ly, int lx2, float (&tot)[2][1 + NCH]) {
-        float a[2][2][1 + NCH];                                   // [pixel of the pair][x-corner]: the corner row in hand
+    auto sums_nv = [&](auto nv_, int ly, int lx2, float (&tot)[2][1 + NCH]) {
+        constexpr int NV = decltype(nv_)::value;
+        SpAcc<NV> a[2][2];                                        // [pixel of the pair][x-corner]: the corner row in hand
         auto clear = [&]() {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int kx = 0; kx < 2; ++kx)
-#pragma unroll
-                    for (int c = 0; c < 1 + NCH; ++c) a[k][kx][c] = 0.0f;
+                for (int kx = 0; kx < 2; ++kx) a[k][kx].clear();
         };
         const int cm = max(lx2 + 1, 0);                            // cell column of pixel 1's x-corner 1 = of pixel 0's x-corner 0
         auto cell = [&](auto dc_, auto ky_) {
@@ -3924,9 +3955,9 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
             if (cur == kEnd) return;
             if ((cw >> 16) != kSp2Sum) {
 #pragma unroll 1
-                do { sp2_use<NC, NCH, DC, KY>(recA, recB, cur, a); cur = link[cur]; } while (cur != kEnd);
+                do { sp2_use<NC, NV, DC, KY>(recA, recB, cur, a); cur = link[cur]; } while (cur != kEnd);
             } else {                                               // phase S left the cell's class sums
-                sp2_use_presum<NCH, DC, KY>(recA, link, cur, a);
+                sp2_use_presum<NV, NCH, DC, KY>(recA, link, cur, a);
             }
         };
         clear();                                                   // corner row 0: classes 0, 1
@@ -3936,21 +3967,29 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = a[k][0][c] + a[k][1][c];
+            for (int c = 0; c < 1 + NV; ++c) tot[k][c] = a[k][0].get(c) + a[k][1].get(c);
         clear();                                                   // corner row 1: classes 2, 3
         cell(integral_constant<int, -1>{}, integral_constant<int, 1>{});
         cell(integral_constant<int, 0>{}, integral_constant<int, 1>{});
         cell(integral_constant<int, 1>{}, integral_constant<int, 1>{});
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k) {
 #pragma unroll
-            for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = (tot[k][c] + a[k][0][c]) + a[k][1][c];   // ((c0 + c1) + c2) + c3
+            for (int c = 0; c < 1 + NV; ++c) tot[k][c] = (tot[k][c] + a[k][0].get(c)) + a[k][1].get(c);   // ((c0 + c1) + c2) + c3
+            if (NV < NCH) tot[k][1 + NC] = tot[k][0];              // every record valid: the mask channel's sums are the density's
+        }
+    };
+    // (block-uniform) a tile -- or band -- none of whose scanned pixels is masked out sums no mask channel: it would repeat the density's
+    // additions, weight by weight (OFL_SP_ALLVALID 0: always summed)
+    auto sums = [&](int ly, int lx2, float (&tot)[2][1 + NCH]) {
+        if (MCH && OFL_SP_ALLVALID && __builtin_amdgcn_readfirstlane(tile_inv) == 0) sums_nv(integral_constant<int, NC>{}, ly, lx2, tot);
+        else sums_nv(integral_constant<int, NCH>{}, ly, lx2, tot);
     };
     auto zero_cells = [&]() {
 #pragma unroll
         for (int i = 0; i < kCellRounds; ++i)
             if (tid + i * kSpNT2 < kCellsP) cellw[tid + i * kSpNT2] = kSp2Empty;
-        if (tid == 0) { qcount = 0; lqn = 0; bqn = 0; segtop = 0; }
+        if (tid == 0) { qcount = 0; lqn = 0; bqn = 0; segtop = 0; tile_inv = 0; }
     };
     int dflags = 0;
     if (!REDO) {
@@ -4019,7 +4058,7 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
             return;
         }
         if (nrec > kQ) nb = (nrec * (kSpTH / 2 + 1) > (kQ - kQ / 8) * kSpTH) ? 4 : 2;
-        else if (order()) nb = 4;
+        else if (!(OFL_SP2_SKIP & 1) && order()) nb = 4;
         if (nb != 0) {
             if (tid < nb) {
                 int base = 0;
@@ -4049,9 +4088,9 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int c = 0; c < 1 + NCH; ++c) tot[k][c] = 0.0f;
-        if (t.inimg) sums(t.ly, t.lx2, tot);
+        if (t.inimg && !(OFL_SP2_SKIP & 2)) sums(t.ly, t.lx2, tot);
         OFL_OPAQUE_S(pp);
-        sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg, dflags);
+        if (!(OFL_SP2_SKIP & 4)) sp_finalize<NC, MCH, TF, TO>(s, t, tot, t.inimg, dflags);
     } else {
         // ================= the second launch: one BAND of rows [ua, ub) of a tile per list entry.  A band whose records still do not
         // fit (or that holds a cell of more than kSpLong records) is halved, down to 4 rows; a 4-row band that does not fit is

@@ -1,0 +1,9 @@
+import sys, torch, torch.nn.functional as F
+dev = torch.device('cuda', 0)
+for sig in (2.0, 8.0, 12.0):
+    for rep in range(3):
+        g = torch.Generator(device='cpu').manual_seed(1000)
+        lo = (torch.randn(16, 2, 27, 48, generator=g) * sig).to(dev)
+        f = F.interpolate(lo, size=(1080, 1920), mode='bicubic', align_corners=True).contiguous()
+        torch.cuda.synchronize()
+        print("sigma", sig, "rep", rep, float(f.abs().max()), flush=True)
