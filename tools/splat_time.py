@@ -36,5 +36,5 @@ for sigma in a.sigma:
             e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / a.iters)
         st = _native._last_splat_stats.cpu().tolist()
-        out.append("%s %.0f: %.4f (fold %d, banded %d)" % (name, sigma, sorted(ts)[len(ts) // 2], st[1], st[3]))
+        out.append("%s %.0f: %.4f (fold %d, banded %d%s)" % (name, sigma, sorted(ts)[len(ts) // 2], st[1], st[3], (", dbg %d %d" % (st[4], st[5])) if (st[4] or st[5]) else ""))
 print("%-28s %s" % (tag, " | ".join(out)), flush=True)
