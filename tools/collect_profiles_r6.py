@@ -10,7 +10,7 @@ names = {"bench.json": "r6_bench.json", "bench_kernel_stats.csv": "r6_bench_kern
          "bench_ops.txt": "r6_bench_ops_B16.txt", "ops_kernel_stats.csv": "r6_bench_ops_kernel_stats.csv", "bench_grad.txt": "r6_bench_grad_B16.txt",
          "splat_pmc_summary.txt": "r6_splat_gather_pmc_summary.txt", "splat_kernels.txt": "r6_splat_kernels.txt",
          "sigma_sweep.txt": "r6_sigma_sweep.txt", "bench_chan.txt": "r6_bench_chan.txt", "chan_pmc.txt": "r6_chan_pmc.txt",
-         "flags.txt": "r6_validation_wait.txt", "timeline.txt": "r6_step_timeline.txt", "small.txt": "r6_small_launches.txt", "fuzz.txt": "r6_fuzz.txt"}
+         "redo_units.txt": "r6_splat_second_launch_units.txt", "phase_insts.txt": "r6_splat_phase_insts.txt", "flags.txt": "r6_validation_wait.txt", "timeline.txt": "r6_step_timeline.txt", "small.txt": "r6_small_launches.txt", "fuzz.txt": "r6_fuzz.txt"}
 for a, b in names.items():
     p = os.path.join(SRC, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:

@@ -48,6 +48,12 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_INSTS_VALU SQ_INSTS_SAL
   (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/splat_$name -- python3 $R/tools/bench_ops.py --only apply_s --batch 16 --iters 5 > $O/splat_$name.log 2>&1)
 done
 { echo "$BOX"; python3 tools/pmc_summary.py $O splat_; } > $O/splat_pmc_summary.txt 2>&1
+# the second launch unit by unit (a -DOFL_SP2_UNITTIME=1 build: tools/build_variant.sh unittime -DOFL_SP2_UNITTIME=1), and the first launch's
+# dynamic instruction counts per wave
+if [ -f tools/microbench/var/unittime.so ]; then
+  { echo "$BOX"; for sg in 8 12; do for op in apply_s switch_ref; do OFL_HIP_LIB=$R/tools/microbench/var/unittime.so timeout 100 python tools/redo_unit_times.py --sigma $sg --op $op 2>&1 | grep -v amdgpu.ids | cut -c1-700; done; done; } > $O/redo_units.txt
+fi
+{ echo "$BOX"; VARIANTS=default bash tools/prof_phase_insts.sh r6final/phase_insts 2 8 2>&1 | tail -4; } > $O/phase_insts.txt
 # roughness sweep of the warp, the validation wait, the step's timeline at B = 8 and 64
 { echo "$BOX"; for s in 0.5 2 4 8 12 16; do python tools/ab_warp.py --sigma $s --reps 2 --only 1 2>/dev/null | grep "shear on" | tail -1 | sed "s/^/sigma $s  /"; done; } > $O/sigma_sweep.txt
 { echo "$BOX"; python tools/ab_flags.py; } > $O/flags.txt 2>/dev/null
