@@ -37,7 +37,7 @@ rows = ((lst[:, 1] >> 8) & 0xff).astype(int) - (lst[:, 1] & 0xff).astype(int)
 t0 = start.min()
 start = (start - t0) % (1 << 19)
 end = start + dur
-print("sigma %g B=%d %s: %d units (rows: %s), list cap %d" % (a.sigma, n, a.op, nu, dict(zip(*np.unique(rows, return_counts=True))), kBinCap))
+print("sigma %g B=%d %s: %d units (rows: %s), list cap %d" % (a.sigma, n, a.op, nu, {int(k): int(v) for k, v in zip(*np.unique(rows, return_counts=True))}, kBinCap))
 print("launch span %.1f us; sum of unit times %.1f us = %.1f us per slot over 512 slots; mean %.1f us, median %.1f, p90 %.1f, p99 %.1f, max %.1f"
       % (end.max() / 100, dur.sum() / 100, dur.sum() / 100 / 512, dur.mean() / 100, np.median(dur) / 100, np.percentile(dur, 90) / 100, np.percentile(dur, 99) / 100, dur.max() / 100))
 # units running at a time, in 10 us steps
