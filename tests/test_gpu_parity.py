@@ -649,6 +649,48 @@ def test_compressing_flows_stay_exact(patch, dev):
     assert np.array_equal(out[3].cpu().numpy(), rwarped)
 
 
+@pytest.mark.parametrize("c,with_holes", [(3, True), (2, False), (2, True)])
+def test_overflowing_tiles_are_summed_in_planned_bands(c, with_holes, dev):
+    """Round 6: a tile whose records overflow the LDS is cut into bands of rows by the FIRST launch, from the exact record counts of its
+    cell rows, and the second launch sums a band per block.  Here the frame is squeezed horizontally by a factor that grows from row to
+    row (1.2 at the top of every 16-row tile to 5.5 at its bottom): 3 000-odd records per tile in the strip, most of them in its lower
+    rows -- bands of very different heights.  Every band fits (no fold), every value is the reference's bit for bit; with holes in the
+    mask channel some tiles sum it and their neighbours leave it out (the all-valid shortcut of phase C)."""
+    from oflibpytorch_amd import _native
+    from oracle import oracle
+    _native.collect_splat_stats = True
+    n, h, w = 2, 96, 640
+    xs = torch.arange(w, dtype=torch.float32).view(1, w)
+    ys = torch.arange(h, dtype=torch.float32).view(h, 1)
+    squeeze = 1.2 + 4.3 * ((ys % 16) / 15.0)                            # per row
+    x0, d0 = 24.0, 256.0
+    inside = (xs >= x0) & (xs < x0 + 560.0)
+    dest = torch.where(inside, d0 + (xs - x0) / squeeze, xs.expand(h, w))
+    flow = torch.zeros(n, 2, h, w)
+    flow[:, 0] = (dest - xs).view(1, h, w)
+    flow = (flow + _smooth(n, h, w, 0.02, 7, torch.device('cpu'))).contiguous().to(dev)
+    g = torch.Generator().manual_seed(12)
+    data = (torch.rand(n, c, h, w, generator=g) * 100 - 20).to(dev)
+    wm = inside.expand(h, w).view(1, h, w).expand(n, h, w).contiguous().to(dev)
+    ca = torch.ones(n, h, w, dtype=torch.bool)
+    if with_holes:
+        ca[:, 20:40, 100:300] = False
+        ca[1, 70:75] = False
+    ca = ca.to(dev)
+    kw = dict(weight_mask=wm, chan_mask_a=ca, want_mask_chan=True, want_density=True, want_warped=True, occlude=False)
+    outs = [_native.splat_fwd(flow, data, **kw) for _ in range(2)]
+    st = _native._last_splat_stats.cpu().tolist()
+    assert st[0] == 0 and st[1] == 0 and st[3] >= 8, st                 # no fallback image, no fold, band units in the second launch
+    dd = np.concatenate([data.cpu().numpy(), ca.cpu().numpy()[:, None].astype(np.float32)], 1)
+    ref, rwarped, rden = oracle.apply_s_flow(flow.cpu().numpy(), dd, wm.cpu().numpy(), False, return_density=True)
+    assert rden.max() > 5.0
+    for out in outs:
+        assert np.array_equal(out[0].cpu().numpy(), ref[:, :c])
+        assert np.array_equal(out[1].cpu().numpy(), ref[:, c])
+        assert np.array_equal(out[2].cpu().numpy(), rden)
+        assert np.array_equal(out[3].cpu().numpy(), rwarped)
+
+
 @pytest.mark.parametrize("c,squeeze,cols", [(3, 7.2, 40), (2, 9.2, 31), (3, 5.3, 52), (2, 7.6, 38)])
 def test_many_medium_cells_in_one_tile_stay_exact(c, squeeze, cols, dev):
     """A strip of the frame squeezed horizontally: `cols` destination columns in which EVERY cell holds `squeeze` records, and
