@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""A GPU box health check that touches nothing of this repo: plain torch ops with allocator reuse (a box of the pool once faulted in
+exactly this after an unrelated crash; every `gpurun` call of the round's last hours starts with it)."""
 import sys, torch, torch.nn.functional as F
 dev = torch.device('cuda', 0)
 for sig in (2.0, 8.0, 12.0):
