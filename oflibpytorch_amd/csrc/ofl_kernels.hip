@@ -3696,7 +3696,7 @@ __global__ __launch_bounds__(kSpNT2, REDO ? 4 : OFL_SP_MINB2) void splat_gather2
     __shared__ int tile_inv;                                          // some scanned pixel is masked out of the mask channel (else phase C leaves that channel out)
     __shared__ uint16_t lq[L::kLongQ];                                // cells with more than two records: phase S works on them lane by lane
     __shared__ __attribute__((aligned(4))) uint16_t bq[L::kBigQ];     // ... of those, the cells with more than kNet records: a wave each
-    static_assert(sizeof(uint16_t) * L::kBigQ >= sizeof(int) * L::kCH, "the per-row counts of an overflowing tile live in the big-cell queue");
+    static_assert(sizeof(uint16_t) * L::kBigQ >= sizeof(int) * (L::kCH + 1), "the per-row counts of an overflowing tile (and the mask of its too-long rows) live in the big-cell queue");
     int* rowover = reinterpret_cast<int*>(bq);                        // (first launch) records per cell row of a tile that overflows: it never orders its cells
     constexpr int kSegN = (REDO && OFL_SP_BIGBLOCK) ? kQ : 1;         // (the second launch: big cells by the whole block -- sp2_big_cells_block)
     __shared__ uint16_t seg[kSegN], srt[kSegN], segb[kSegN];
