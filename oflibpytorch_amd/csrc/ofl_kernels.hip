@@ -2400,6 +2400,9 @@ __device__ __forceinline__ int row_pk_max_dpp(int v) {
     return kSubLanes == 16 ? pk_max16(v, OFL_DPP(v, 0x140)) : v;
 }
 
+#ifndef OFL_BIN_SMALLDIV
+#define OFL_BIN_SMALLDIV 1
+#endif
 constexpr int kBinLocal = 64;   // destination tiles one 64 x 16 source region aggregates in LDS (more: straight to the global counters)
 
 // image n leaves the gather path (a list overflowed / a subtile is torn over the frame): its flag, and the statistics of
@@ -2407,6 +2410,11 @@ constexpr int kBinLocal = 64;   // destination tiles one 64 x 16 source region a
 __device__ __forceinline__ void sp_flag_image(const GatherParams& p, int n) {
     if (atomicOr(&p.img_over[n], 1) == 0) { atomicOr(&p.stats[0], 1); atomicAdd(&p.stats[2], 1); }
 }
+
+// a / b for 0 <= a < 4096, 1 <= b <= 64, exactly: (a + 0.5) * rcp(b) lies at least 0.5 / b >= 2^-7 away from every integer, far beyond the error
+// of v_rcp_f32 and two roundings (the compiler's 32-bit division is ~20 instructions, and the bin kernel is bound by the instructions it
+// issues: 625 per wave = 66 of its 73 us, profiles/r6_splat_diet.txt)
+__device__ __forceinline__ int small_div(int a, int b) { return (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b)); }
 
 template <typename TF, bool LEAN = false>
 __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
@@ -2492,7 +2500,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
         lt[g] = -1; rank[g] = 0;
         fast[g] = local && cnt[g] <= kSubLanes;
         if (fast[g] && j0 < cnt[g]) {
-            const int jy = j0 / ntx[g];
+            const int jy = OFL_BIN_SMALLDIV ? small_div(j0, ntx[g]) : j0 / ntx[g];
             lt[g] = (ty0[g] + jy - bty0) * bntx + (tx0[g] + (j0 - jy * ntx[g]) - btx0);
             rank[g] = atomicAdd(&lcount[lt[g]], 1);
         }
@@ -2500,7 +2508,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     if (local) {
         __syncthreads();
         if (tid < bnt && lcount[tid] > 0) {
-            const int ly_ = tid / bntx;
+            const int ly_ = OFL_BIN_SMALLDIV ? small_div(tid, bntx) : tid / bntx;
             const int64_t d = (int64_t)n * p.tiles_img + (bty0 + ly_) * p.tiles_x + btx0 + (tid - ly_ * bntx);
             const int start = atomicAdd(&p.cnt[d], lcount[tid]);
             lbase[tid] = start;
@@ -2510,7 +2518,7 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (lt[g] >= 0) {
-                const int ly_ = lt[g] / bntx;
+                const int ly_ = OFL_BIN_SMALLDIV ? small_div(lt[g], bntx) : lt[g] / bntx;
                 const int64_t d = (int64_t)n * p.tiles_img + (bty0 + ly_) * p.tiles_x + btx0 + (lt[g] - ly_ * bntx);
                 const int pos = lbase[lt[g]] + rank[g];
                 if (pos < kBinCap) p.list[d * kBinCap + pos] = subid[g];
