@@ -2387,17 +2387,20 @@ __device__ __forceinline__ void sp_src_done(const SP& s, int sx4, int sy, bool i
 }
 
 // min / max of two packed 16-bit fields over the lanes of a subtile (16: a DPP row, 8: half a row; every lane gets the result)
+// (OFL_DPPU: these four controls are permutations of a row -- every lane has a source, so the "old" value of update_dpp is never used and
+// need not be copied in first: one v_mov_b32_dpp per step instead of a v_mov_b32 and one)
+#define OFL_DPPU(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xf, 0xf, true)
 __device__ __forceinline__ int row_pk_min_dpp(int v) {
-    v = pk_min16(v, OFL_DPP(v, 0xB1)); v = pk_min16(v, OFL_DPP(v, 0x4E));
+    v = pk_min16(v, OFL_DPPU(v, 0xB1)); v = pk_min16(v, OFL_DPPU(v, 0x4E));
     if (kSubLanes == 4) return v;                                          // (a quad: the two quad permutations complete it)
-    v = pk_min16(v, OFL_DPP(v, 0x141));
-    return kSubLanes == 16 ? pk_min16(v, OFL_DPP(v, 0x140)) : v;          // (8 lanes: the half-row mirror completes it)
+    v = pk_min16(v, OFL_DPPU(v, 0x141));
+    return kSubLanes == 16 ? pk_min16(v, OFL_DPPU(v, 0x140)) : v;         // (8 lanes: the half-row mirror completes it)
 }
 __device__ __forceinline__ int row_pk_max_dpp(int v) {
-    v = pk_max16(v, OFL_DPP(v, 0xB1)); v = pk_max16(v, OFL_DPP(v, 0x4E));
+    v = pk_max16(v, OFL_DPPU(v, 0xB1)); v = pk_max16(v, OFL_DPPU(v, 0x4E));
     if (kSubLanes == 4) return v;
-    v = pk_max16(v, OFL_DPP(v, 0x141));
-    return kSubLanes == 16 ? pk_max16(v, OFL_DPP(v, 0x140)) : v;
+    v = pk_max16(v, OFL_DPPU(v, 0x141));
+    return kSubLanes == 16 ? pk_max16(v, OFL_DPPU(v, 0x140)) : v;
 }
 
 #ifndef OFL_BIN_SMALLDIV
@@ -2465,11 +2468,16 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
         minx[g] = (int)(short)(lo & 0xffff); miny[g] = lo >> 16; maxx[g] = (int)(short)(hi & 0xffff); maxy[g] = hi >> 16;
         any[g] = maxx[g] >= minx[g] && maxy[g] >= miny[g];               // something of this subtile lands inside the image
         // destination tiles of the subtile (as packed 16-bit pairs, for the block-wide union)
-        const int tlo = any[g] ? (int)((uint32_t)(minx[g] / kSpTW) | ((uint32_t)(miny[g] / kSpTH) << 16)) : 0x7fff7fff;
-        const int thi = any[g] ? (int)((uint32_t)(maxx[g] / kSpTW) | ((uint32_t)(maxy[g] / kSpTH) << 16)) : (int)0xffffffffu;
+        // (the extents are never negative where they are used: unsigned divisions -- shifts; the signed ones cost three instructions more each)
+        const int tlo = any[g] ? (int)(((uint32_t)minx[g] / (uint32_t)kSpTW) | (((uint32_t)miny[g] / (uint32_t)kSpTH) << 16)) : 0x7fff7fff;
+        const int thi = any[g] ? (int)(((uint32_t)maxx[g] / (uint32_t)kSpTW) | (((uint32_t)maxy[g] / (uint32_t)kSpTH) << 16)) : (int)0xffffffffu;
+        // (the subtiles of a ROW of 16 lanes first, by DPP; then one readlane per row instead of one per subtile)
+        int rlo = tlo, rhi = thi;
+        if (kSubLanes <= 4) { rlo = pk_min16(rlo, OFL_DPPU(rlo, 0x141)); rhi = pk_max16(rhi, OFL_DPPU(rhi, 0x141)); }
+        if (kSubLanes <= 8) { rlo = pk_min16(rlo, OFL_DPPU(rlo, 0x140)); rhi = pk_max16(rhi, OFL_DPPU(rhi, 0x140)); }
 #pragma unroll
-        for (int l = 0; l < 64; l += kSubLanes) {
-            blo_w = pk_min16(blo_w, __builtin_amdgcn_readlane(tlo, l)); bhi_w = pk_max16(bhi_w, __builtin_amdgcn_readlane(thi, l));
+        for (int l = 0; l < 64; l += 16) {
+            blo_w = pk_min16(blo_w, __builtin_amdgcn_readlane(rlo, l)); bhi_w = pk_max16(bhi_w, __builtin_amdgcn_readlane(rhi, l));
         }
     }
     if (lane == 0) { red[wave][0] = blo_w; red[wave][1] = bhi_w; }
@@ -2487,8 +2495,8 @@ __global__ __launch_bounds__(256) void splat_bin_kernel(const GatherParams p) {
     bool fast[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        tx0[g] = minx[g] / kSpTW; ty0[g] = miny[g] / kSpTH;
-        const int tx1 = maxx[g] / kSpTW, ty1 = maxy[g] / kSpTH;
+        tx0[g] = (int)((uint32_t)minx[g] / (uint32_t)kSpTW); ty0[g] = (int)((uint32_t)miny[g] / (uint32_t)kSpTH);
+        const int tx1 = (int)((uint32_t)maxx[g] / (uint32_t)kSpTW), ty1 = (int)((uint32_t)maxy[g] / (uint32_t)kSpTH);
         ntx[g] = tx1 - tx0[g] + 1; cnt[g] = any[g] ? ntx[g] * (ty1 - ty0[g] + 1) : 0;
         subid[g] = (uint32_t)((sy[g] / kSubH) * p.subs_x + rx * 4 + sub);
         if (cnt[g] > kBinSpread) {                                       // a subtile torn over the whole frame: two-pass path
